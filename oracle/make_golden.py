@@ -1,0 +1,285 @@
+"""Generates tests/golden/*.npz by running the REFERENCE's own Python on synthetic inputs.
+
+Run in the build container only (needs /root/reference):
+    PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden
+Fixtures hold inputs (or the seeds that regenerate them + a checksum) and the
+reference's outputs -- data only, never reference source text.
+"""
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from foundpose_amd import synthetic
+from foundpose_amd.vit_config import VitArch
+from oracle import ref_shim
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+TINY = VitArch("tiny-reg", dim=128, depth=3, heads=2, ffn="mlp", hidden=512, registers=4,
+               pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
+
+
+def checksum(*arrays) -> np.float64:
+    s = 0.0
+    for a in arrays:
+        a = np.asarray(a, np.float64).ravel()
+        s += float((a * np.cos(np.arange(a.size) * 0.37)).sum())
+    return np.float64(s)
+
+
+def t2n(x):
+    return x.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------ matching cases
+MATCH_CASES = {
+    # name: dict(T, pmin, pmax, W, planted template, noise, top_n, top_k, soft, bank_seed, q_seed, dup)
+    "match_planted": dict(T=24, pmin=30, pmax=60, W=128, tpl=7, noise=0.05, top_n=5, top_k=300, soft=False, bank_seed=7, q_seed=100, dup=0),
+    "match_ties": dict(T=24, pmin=40, pmax=70, W=96, tpl=3, noise=0.0, top_n=5, top_k=300, soft=False, bank_seed=8, q_seed=101, dup=12),
+    "match_boundary": dict(T=30, pmin=150, pmax=220, W=256, tpl=11, noise=0.3, top_n=5, top_k=50, soft=False, bank_seed=9, q_seed=102, dup=20),
+    "match_soft": dict(T=16, pmin=30, pmax=50, W=64, tpl=5, noise=0.05, top_n=3, top_k=20, soft=True, bank_seed=10, q_seed=103, dup=0),
+    "match_partialsort": dict(T=400, pmin=8, pmax=16, W=128, tpl=123, noise=0.05, top_n=5, top_k=300, soft=False, bank_seed=12, q_seed=104, dup=0),
+}
+
+
+def build_match_inputs(c):
+    """Deterministic inputs of a matching case (shared by the generator and the tests)."""
+    bank = synthetic.make_bank_features(c["T"], 256, c["pmin"], c["pmax"], seed=c["bank_seed"])
+    centroids = synthetic.pick_centroids(bank["feat_vectors"], c["W"], seed=c["bank_seed"] + 1000)
+    pts, feats = synthetic.make_planted_query(bank, c["tpl"], 37, seed=c["q_seed"], noise=c["noise"])
+    if c["dup"]:
+        # duplicate some query features at other grid cells -> exact distance ties
+        d = c["dup"]
+        feats = torch.cat([feats, feats[:d]], 0)
+        extra = pts[:d].clone()
+        extra[:, 1] = 518.0 - 7.0  # bottom row of the grid, unused by make_planted_query's first rows? keep distinct anyway
+        extra[:, 0] = torch.arange(d).float() * 14.0 + 7.0
+        pts = torch.cat([pts, extra], 0)
+    return bank, centroids, pts.contiguous(), feats.contiguous()
+
+
+def gen_match(ref):
+    for name, c in MATCH_CASES.items():
+        bank, centroids, pts, feats = build_match_inputs(c)
+        T = c["T"]
+        opts = ref.repre_util.TemplateDescOpts(tfidf_soft_assign=c["soft"])
+        # word assignment (the k-means 1-NN assignment of the bank builder)
+        words_index = ref.knn_util.KNN(k=1, metric="l2")
+        words_index.fit(centroids)
+        _, wid = words_index.search(bank["feat_vectors"])
+        feat_to_cluster_ids = wid[:, 0].to(torch.int32)
+        descs, idfs = ref.template_util.calc_tfidf_descriptors(
+            feat_vectors=bank["feat_vectors"], feat_to_word_ids=feat_to_cluster_ids,
+            feat_to_template_ids=bank["feat_to_template_ids"], feat_words=centroids,
+            num_templates=T, tfidf_knn_k=opts.tfidf_knn_k, tfidf_soft_assign=opts.tfidf_soft_assign,
+            tfidf_soft_sigma_squared=opts.tfidf_soft_sigma_squared,
+        )
+        repre = ref.repre_util.FeatureBasedObjectRepre(
+            vertices=bank["vertices"], feat_vectors=bank["feat_vectors"],
+            feat_to_vertex_ids=bank["feat_to_vertex_ids"], feat_to_template_ids=bank["feat_to_template_ids"],
+            feat_to_cluster_ids=feat_to_cluster_ids, feat_cluster_centroids=centroids,
+            feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts,
+        )
+        vw = ref.knn_util.KNN(k=opts.tfidf_knn_k, metric=opts.tfidf_knn_metric)
+        vw.fit(centroids)
+        tpl_idx = []
+        for t in range(T):
+            ids = torch.nonzero(bank["feat_to_template_ids"] == t).flatten()
+            idx = ref.knn_util.KNN(k=1, metric="l2")
+            idx.fit(bank["feat_vectors"][ids])
+            tpl_idx.append(idx)
+        corresp = ref.corresp_util.establish_correspondences(
+            query_points=pts, query_features=feats, object_repre=repre,
+            template_matching_type="tfidf", feat_matching_type="cyclic_buddies",
+            top_n_templates=c["top_n"], top_k_buddies=c["top_k"],
+            visual_words_knn_index=vw, template_knn_indices=tpl_idx, debug=True,
+        )
+        out = {
+            "input_checksum": checksum(bank["feat_vectors"], centroids, pts, feats),
+            "feat_to_cluster_ids": t2n(feat_to_cluster_ids),
+            "word_idfs": t2n(idfs), "template_descs": t2n(descs),
+            "template_ids": np.array([int(cc["template_id"]) for cc in corresp], np.int64),
+            "template_scores": np.array([float(cc["template_score"]) for cc in corresp], np.float32),
+        }
+        for i, cc in enumerate(corresp):
+            out[f"coord_2d_ids_{i}"] = t2n(cc["coord_2d_ids"]).astype(np.int64)
+            out[f"nn_vertex_ids_{i}"] = t2n(cc["nn_vertex_ids"]).astype(np.int64)
+            out[f"coord_conf_{i}"] = t2n(cc["coord_conf"]).astype(np.float32)
+            out[f"coord_2d_{i}"] = t2n(cc["coord_2d"]).astype(np.float32)
+            out[f"coord_3d_{i}"] = t2n(cc["coord_3d"]).astype(np.float32)
+            out[f"nn_dists_{i}"] = t2n(cc["nn_dists"]).astype(np.float32)
+        np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+        print(name, "templates", out["template_ids"], "k", [len(out[f'coord_2d_ids_{i}']) for i in range(len(corresp))])
+
+
+# ------------------------------------------------------------------ point utils / sampling / PCA
+def gen_points(ref):
+    fu, pu = ref.feature_util, ref.projector_util
+    out = {}
+    for s in (518, 420):
+        out[f"grid_{s}"] = t2n(fu.generate_grid_points((s, s), 14.0))
+    g = torch.Generator().manual_seed(5)
+    mask = (torch.rand(518, 518, generator=g) > 0.6).to(torch.uint8)
+    pts = fu.generate_grid_points((518, 518), 14.0)
+    out["mask_seed"] = np.int64(5)
+    out["filtered_random"] = t2n(fu.filter_points_by_mask(pts, mask))
+    out["filtered_disc"] = t2n(fu.filter_points_by_mask(pts, synthetic.make_disc_mask(518)))
+    fmap = torch.randn(48, 37, 37, generator=g)
+    qp = fu.filter_points_by_mask(pts, synthetic.make_disc_mask(518))
+    offgrid = torch.rand(64, 2, generator=g) * 518.0
+    out["fmap"] = t2n(fmap)
+    out["offgrid_points"] = t2n(offgrid)
+    out["sampled_grid"] = t2n(fu.sample_feature_map_at_points(fmap, qp, (518, 518)))
+    out["sampled_offgrid"] = t2n(fu.sample_feature_map_at_points(fmap, offgrid, (518, 518)))
+    # PCA: fit through the reference projector (sklearn), then transform.
+    x = torch.randn(600, 48, generator=g) * torch.linspace(2.0, 0.2, 48) + torch.linspace(-1, 1, 48)
+    proj = pu.PCAProjector(n_components=16)
+    proj.fit(x)
+    td = pu.projector_to_tensordict(proj)["pca_projector"]
+    proj2 = pu.projector_from_tensordict({"pca_projector": td})
+    y = pu.project_features(x[:100], [proj2])
+    out["pca_x"] = t2n(x[:100])
+    out["pca_components"] = t2n(td["components"]).astype(np.float32)
+    out["pca_mean"] = t2n(td["mean"]).astype(np.float32)
+    out["pca_y"] = t2n(y).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "points_sample_pca.npz"), **out)
+    print("points_sample_pca", {k: np.asarray(v).shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------ extractor wrapper
+def _make_ref_extractor(ref, arch, sd, image_size, name):
+    base = f"dinov2_{arch.name}".replace("-", "_")
+    ref_shim.set_backbone(base, lambda pretrained=True: ref_shim.HFBackboneAdapter(sd, arch, image_size))
+    return ref.dinov2_utils.DinoFeatureExtractor(name)
+
+
+def gen_extractor(ref):
+    from foundpose_amd.vit_config import ARCHS
+
+    ARCHS[TINY.name] = TINY
+    # (a) tiny architecture, full outputs, two layers, with and without the final norm
+    sd = synthetic.make_vit_state_dict(TINY, seed=1234)
+    imgs = synthetic.make_crops(2, 56, seed=0)
+    out = {"weights_seed": np.int64(1234), "image_seed": np.int64(0),
+           "input_checksum": checksum(imgs, sd["blocks.1.attn.qkv.weight"], sd["pos_embed"])}
+    for layer, norm in ((1, 1), (2, 1), (0, 0)):
+        ex = _make_ref_extractor(ref, TINY, sd, 56, f"dinov2_version=tiny-reg_stride=14_facet=token_layer={layer}_logbin=0_norm={norm}")
+        with torch.no_grad():
+            o = ex(imgs)
+        out[f"fmap_l{layer}_n{norm}"] = t2n(o["feature_maps"]).astype(np.float32)
+        out[f"cls_l{layer}_n{norm}"] = t2n(o["cls_tokens"]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "extractor_tiny.npz"), **out)
+    print("extractor_tiny", out["fmap_l1_n1"].shape)
+
+    # (b) ViT-S/14-reg at 518 (no pos-embed interpolation), the shipped LM-O extractor name.
+    arch = ARCHS["vits14-reg"]
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    imgs = synthetic.make_crops(1, 518, seed=1)
+    ex = _make_ref_extractor(ref, arch, sd, 518, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1")
+    with torch.no_grad():
+        o = ex(imgs)
+    fm = t2n(o["feature_maps"]).astype(np.float32)
+    np.savez_compressed(
+        os.path.join(OUT, "extractor_vits14reg_518.npz"),
+        weights_seed=np.int64(1234), image_seed=np.int64(1),
+        input_checksum=checksum(imgs, sd["blocks.9.attn.qkv.weight"]),
+        fmap_sub=fm[:, ::8, ::3, ::3], cls=t2n(o["cls_tokens"]).astype(np.float32),
+        fmap_mean=np.float64(fm.mean()), fmap_abs_mean=np.float64(np.abs(fm).mean()),
+    )
+    print("extractor_vits14reg_518", fm.shape, float(np.abs(fm).mean()))
+
+
+# ------------------------------------------------------------------ composite hot section
+def gen_hot_section(ref):
+    """infer.py:468-542 driven through the reference's functions on a tiny extractor."""
+    from foundpose_amd.vit_config import ARCHS
+
+    ARCHS[TINY.name] = TINY
+    fu, pu = ref.feature_util, ref.projector_util
+    S, cell = 112, 14.0  # 8x8 patch grid; pos-embed interpolated from the 4x4 table
+    sd = synthetic.make_vit_state_dict(TINY, seed=77)
+    # HF interpolates its 4x4 table to 8x8 itself (size-based, antialias): same flavour as the -reg hub models.
+    ex = _make_ref_extractor(ref, TINY, sd, 56, "dinov2_version=tiny-reg_stride=14_facet=token_layer=2_logbin=0_norm=1")
+    g = torch.Generator().manual_seed(42)
+    T = 12
+    tpl_imgs = torch.rand(T, 3, S, S, generator=g)
+    tpl_masks = (torch.rand(T, S, S, generator=g) > 0.35).to(torch.uint8)
+    grid = fu.generate_grid_points((S, S), cell)
+    feats, f2t, verts = [], [], []
+    with torch.no_grad():
+        for t in range(T):
+            fm = ex(tpl_imgs[t:t + 1])["feature_maps"][0]
+            qp = fu.filter_points_by_mask(grid, tpl_masks[t])
+            feats.append(fu.sample_feature_map_at_points(fm, qp, (S, S)).contiguous())
+            f2t.append(torch.full((len(qp),), t, dtype=torch.int32))
+            verts.append(torch.cat([qp, torch.full((len(qp), 1), float(t))], 1))
+    raw = torch.cat(feats, 0)
+    f2t = torch.cat(f2t)
+    verts = torch.cat(verts, 0)
+    proj = pu.PCAProjector(n_components=32)
+    proj.fit(raw)
+    td = pu.projector_to_tensordict(proj)["pca_projector"]
+    proj = pu.projector_from_tensordict({"pca_projector": td})
+    bank_feats = pu.project_features(raw, [proj]).contiguous()
+    W = 48
+    centroids = synthetic.pick_centroids(bank_feats, W, seed=3)
+    opts = ref.repre_util.TemplateDescOpts()
+    k1 = ref.knn_util.KNN(k=1, metric="l2"); k1.fit(centroids)
+    f2c = k1.search(bank_feats)[1][:, 0].to(torch.int32)
+    descs, idfs = ref.template_util.calc_tfidf_descriptors(
+        bank_feats, f2c, f2t, centroids, T, opts.tfidf_knn_k, opts.tfidf_soft_assign, opts.tfidf_soft_sigma_squared)
+    repre = ref.repre_util.FeatureBasedObjectRepre(
+        vertices=verts, feat_vectors=bank_feats, feat_to_vertex_ids=torch.arange(len(verts), dtype=torch.int32),
+        feat_to_template_ids=f2t, feat_to_cluster_ids=f2c, feat_cluster_centroids=centroids,
+        feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj])
+    vw = ref.knn_util.KNN(k=3, metric="l2"); vw.fit(centroids)
+    tpl_idx = []
+    for t in range(T):
+        idx = ref.knn_util.KNN(k=1, metric="l2"); idx.fit(bank_feats[f2t == t]); tpl_idx.append(idx)
+    # query = template 4 + noise, its own mask
+    q_img = (tpl_imgs[4] + 0.02 * torch.randn(3, S, S, generator=g)).clamp(0, 1)
+    q_mask = tpl_masks[4]
+    with torch.no_grad():
+        fmap = ex(q_img.unsqueeze(0))["feature_maps"][0]
+        qp = fu.filter_points_by_mask(grid, q_mask)
+        qf = fu.sample_feature_map_at_points(fmap, qp, (S, S)).contiguous()
+        qfp = pu.project_features(qf, repre.feat_raw_projectors).contiguous()
+        corresp = ref.corresp_util.establish_correspondences(
+            query_points=qp, query_features=qfp, object_repre=repre, template_matching_type="tfidf",
+            feat_matching_type="cyclic_buddies", top_n_templates=5, top_k_buddies=300,
+            visual_words_knn_index=vw, template_knn_indices=tpl_idx, debug=True)
+    out = dict(
+        weights_seed=np.int64(77), data_seed=np.int64(42), image_size=np.int64(S),
+        tpl_imgs=(t2n(tpl_imgs) * 255).round().astype(np.uint8) if False else t2n(tpl_imgs).astype(np.float16),
+        tpl_masks=t2n(tpl_masks), q_img=t2n(q_img).astype(np.float32),
+        pca_components=t2n(td["components"]).astype(np.float32), pca_mean=t2n(td["mean"]).astype(np.float32),
+        bank_feats=t2n(bank_feats).astype(np.float32), f2t=t2n(f2t), vertices=t2n(verts).astype(np.float32),
+        centroids=t2n(centroids).astype(np.float32), idfs=t2n(idfs), template_descs=t2n(descs),
+        fmap=t2n(fmap).astype(np.float32), query_points=t2n(qp), query_features=t2n(qf), query_features_proj=t2n(qfp),
+        template_ids=np.array([int(c["template_id"]) for c in corresp], np.int64),
+        template_scores=np.array([float(c["template_score"]) for c in corresp], np.float32),
+    )
+    for i, c in enumerate(corresp):
+        out[f"coord_2d_ids_{i}"] = t2n(c["coord_2d_ids"]).astype(np.int64)
+        out[f"nn_vertex_ids_{i}"] = t2n(c["nn_vertex_ids"]).astype(np.int64)
+        out[f"coord_conf_{i}"] = t2n(c["coord_conf"]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "hot_section_tiny.npz"), **out)
+    print("hot_section_tiny", out["template_ids"], out["template_scores"], "Q", len(qp))
+
+
+def main():
+    if not ref_shim.reference_available():
+        sys.exit("reference not present; fixtures can only be generated in the build container")
+    os.makedirs(OUT, exist_ok=True)
+    ref = ref_shim.import_reference()
+    gen_match(ref)
+    gen_points(ref)
+    gen_extractor(ref)
+    gen_hot_section(ref)
+
+
+if __name__ == "__main__":
+    main()

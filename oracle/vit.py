@@ -1,0 +1,169 @@
+"""CPU oracle for the feature-extraction half (TEST INFRASTRUCTURE ONLY).
+
+fp32 torch-CPU restatement of what the reference's extractor computes
+(/root/reference/utils/dinov2_utils.py:115-158 over the DINOv2 backbone called at
+dinov2_utils.py:82,257).  The backbone lives in the un-vendored submodule
+external/dinov2 (empty in the mount, SHA unrecorded) -> PARITY UNPINNED for the
+backbone arithmetic; it is restated from the published DINOv2 architecture
+(vision_transformer.py / layers/{patch_embed,attention,block,mlp,swiglu_ffn,layer_scale}.py)
+and cross-checked in tests against transformers' independent Dinov2WithRegisters model.
+The wrapper logic around it (hook on blocks[layer], CLS/register slicing, final norm,
+reshape/permute) IS pinned against the reference wrapper (tests/golden/extractor_*.npz).
+
+`quant="bf16"` is "oracle B": every GEMM operand is rounded to bf16 at the points where
+the MI355X bf16 path casts (LN outputs, qkv, softmax probabilities, attention output,
+GELU output, weights), accumulation in fp32.
+"""
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from foundpose_amd.vit_config import VitArch
+
+IMNET_MEAN = (0.485, 0.456, 0.406)
+IMNET_STD = (0.229, 0.224, 0.225)
+
+
+def _q(x: torch.Tensor, quant: Optional[str]) -> torch.Tensor:
+    if quant == "bf16":
+        return x.to(torch.bfloat16).to(torch.float32)
+    return x
+
+
+def normalize_images(images: torch.Tensor) -> torch.Tensor:
+    mean = torch.tensor(IMNET_MEAN, dtype=images.dtype).view(1, 3, 1, 1)
+    std = torch.tensor(IMNET_STD, dtype=images.dtype).view(1, 3, 1, 1)
+    return (images - mean) / std
+
+
+def interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: int) -> torch.Tensor:
+    """Upstream `interpolate_pos_encoding` ([upstream] dinov2/models/vision_transformer.py)."""
+    n = pos_embed.shape[1] - 1
+    m = int(math.sqrt(n))
+    if gh * gw == n and gh == gw:
+        return pos_embed
+    cls_pos, patch_pos = pos_embed[:, :1], pos_embed[:, 1:]
+    dim = pos_embed.shape[-1]
+    kwargs = {}
+    if arch.interp_offset:
+        kwargs["scale_factor"] = (float(gh + arch.interp_offset) / m, float(gw + arch.interp_offset) / m)
+    else:
+        kwargs["size"] = (gh, gw)
+    patch_pos = F.interpolate(
+        patch_pos.reshape(1, m, m, dim).permute(0, 3, 1, 2), mode="bicubic",
+        antialias=arch.interp_antialias, **kwargs,
+    )
+    assert patch_pos.shape[-2:] == (gh, gw)
+    patch_pos = patch_pos.permute(0, 2, 3, 1).reshape(1, -1, dim)
+    return torch.cat([cls_pos, patch_pos], dim=1)
+
+
+def embed_tokens(sd: Dict[str, torch.Tensor], arch: VitArch, x: torch.Tensor, quant=None) -> torch.Tensor:
+    """Normalised image -> [B, 1+R+Np, D] token sequence (cls, registers, patches)."""
+    B, _, H, W = x.shape
+    gh, gw = H // arch.patch, W // arch.patch
+    w = _q(sd["patch_embed.proj.weight"], quant)
+    t = F.conv2d(_q(x, quant), w, sd["patch_embed.proj.bias"], stride=arch.patch)
+    t = t.flatten(2).transpose(1, 2)  # [B, Np, D], row-major over (gy, gx)
+    t = torch.cat([sd["cls_token"].expand(B, -1, -1), t], dim=1)
+    t = t + interpolate_pos_embed(sd["pos_embed"], arch, gh, gw)
+    if arch.registers:
+        t = torch.cat([t[:, :1], sd["register_tokens"].expand(B, -1, -1), t[:, 1:]], dim=1)
+    return t
+
+
+def block_forward(sd, arch: VitArch, i: int, x: torch.Tensor, quant=None) -> torch.Tensor:
+    p = f"blocks.{i}."
+    B, N, D = x.shape
+    h, hd = arch.heads, arch.head_dim
+    y = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
+    qkv = F.linear(_q(y, quant), _q(sd[p + "attn.qkv.weight"], quant), sd[p + "attn.qkv.bias"])
+    qkv = _q(qkv, quant).reshape(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    attn = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+    attn = attn.softmax(dim=-1)
+    if quant == "bf16":
+        # the kernel rounds un-normalised probabilities exp(s - max) to bf16 before P@V and
+        # divides by the fp32 row sum afterwards
+        s = (q @ k.transpose(-2, -1)) * (hd ** -0.5)
+        e = torch.exp(s - s.amax(dim=-1, keepdim=True))
+        o = (_q(e, quant) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        o = attn @ v
+    o = o.transpose(1, 2).reshape(B, N, D)
+    o = F.linear(_q(o, quant), _q(sd[p + "attn.proj.weight"], quant), sd[p + "attn.proj.bias"])
+    x = x + sd[p + "ls1.gamma"] * o
+    y = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
+    if arch.ffn == "mlp":
+        hdn = F.linear(_q(y, quant), _q(sd[p + "mlp.fc1.weight"], quant), sd[p + "mlp.fc1.bias"])
+        hdn = F.gelu(hdn)  # exact erf GELU
+        o = F.linear(_q(hdn, quant), _q(sd[p + "mlp.fc2.weight"], quant), sd[p + "mlp.fc2.bias"])
+    else:
+        x12 = F.linear(_q(y, quant), _q(sd[p + "mlp.w12.weight"], quant), sd[p + "mlp.w12.bias"])
+        x1, x2 = x12.chunk(2, dim=-1)
+        hdn = F.silu(x1) * x2
+        o = F.linear(_q(hdn, quant), _q(sd[p + "mlp.w3.weight"], quant), sd[p + "mlp.w3.bias"])
+    return x + sd[p + "ls2.gamma"] * o
+
+
+@torch.no_grad()
+def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quant=None, all_blocks=False) -> torch.Tensor:
+    """Output of blocks[layer] for [0,1] images (what the reference's forward hook captures).
+
+    `all_blocks=True` keeps running to the last block like the reference does
+    (dinov2_utils.py:257 runs the entire model) -- only used by the cpu_baseline timing.
+    """
+    x = embed_tokens(sd, arch, normalize_images(images), quant)
+    out = None
+    last = arch.depth - 1 if all_blocks else layer
+    for i in range(last + 1):
+        x = block_forward(sd, arch, i, x, quant)
+        if i == layer:
+            out = x
+    return out
+
+
+@torch.no_grad()
+def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False):
+    """-> {"cls_tokens": [B,D], "feature_maps": [B,D,Hp,Wp]} exactly like the reference wrapper."""
+    B, _, H, W = images.shape
+    hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks)
+    cls, patch = hs[:, :1], hs[:, 1 + arch.registers:]
+    if apply_norm:
+        tok = F.layer_norm(torch.cat([cls, patch], 1), (arch.dim,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)
+        cls, patch = tok[:, :1], tok[:, 1:]
+    gh, gw = H // arch.patch, W // arch.patch
+    fmap = patch.reshape(B, gh, gw, arch.dim).permute(0, 3, 1, 2)
+    return {"cls_tokens": cls[:, 0], "feature_maps": fmap}
+
+
+# ---- point utilities + sampling + PCA (utils/feature_util.py:25-131, projector_util.py:66-69)
+
+def generate_grid_points(grid_size, cell_size: float = 1.0) -> torch.Tensor:
+    cols, rows = int(grid_size[0] / cell_size), int(grid_size[1] / cell_size)
+    half = cell_size / 2.0
+    x = torch.linspace(half, grid_size[0] - half, cols, dtype=torch.float)
+    y = torch.linspace(half, grid_size[1] - half, rows, dtype=torch.float)
+    gx, gy = torch.meshgrid(x, y, indexing="xy")
+    return torch.vstack((gx.flatten(), gy.flatten())).T
+
+
+def filter_points_by_mask(points: torch.Tensor, mask: torch.Tensor) -> torch.Tensor:
+    pi = (points + 0.5).int()
+    valid = (pi[:, 0] > 0) & (pi[:, 0] < mask.shape[1]) & (pi[:, 1] > 0) & (pi[:, 1] < mask.shape[0])
+    pi = pi[valid]
+    return points[valid][mask[pi[:, 1], pi[:, 0]].bool()]
+
+
+def sample_feature_map_at_points(feature_map_chw: torch.Tensor, points: torch.Tensor, image_size) -> torch.Tensor:
+    uv = torch.div(2.0, torch.as_tensor(image_size)) * points - 1.0
+    feats = F.grid_sample(feature_map_chw.unsqueeze(0), uv.unsqueeze(0).unsqueeze(2), align_corners=False)
+    return feats[0, :, :, 0].permute(1, 0)
+
+
+def pca_transform(x: torch.Tensor, components: torch.Tensor, mean: torch.Tensor) -> torch.Tensor:
+    """sklearn PCA.transform without whitening: X @ C^T - (mu @ C^T)."""
+    return x @ components.T - (mean.reshape(1, -1) @ components.T)
