@@ -1,0 +1,119 @@
+"""ctypes binding of libfoundpose_amd.so (the C ABI in include/foundpose_amd.h).
+
+There is NO fallback: if the library is missing or a call fails, this raises. The product
+path never computes on the CPU and never touches oracle/.
+"""
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
+
+FP_F32, FP_BF16 = 0, 1
+ABI_VERSION = 1
+
+vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+
+
+class VitBlock(C.Structure):
+    _fields_ = [(n, vp) for n in (
+        "ln1_w", "ln1_b", "ln2_w", "ln2_b", "ls1", "ls2",
+        "qkv_w", "proj_w", "fc1_w", "fc2_w",
+        "qkv_b", "proj_b", "fc1_b", "fc2_b")]
+
+
+class VitModel(C.Structure):
+    _fields_ = [
+        ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
+        ("ffn_swiglu", i32), ("weight_dtype", i32),
+        ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)),
+    ]
+
+
+class VitWorkspace(C.Structure):
+    _fields_ = [
+        ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("vt", vp), ("h", vp),
+        ("m_pad", i32), ("m_patch_pad", i32), ("vt_ld", i32),
+    ]
+
+
+_PROTOS = {
+    "fp_abi_version": [],
+    "fp_sqnorm_rows": [vp, i64, i32, vp, vp],
+    "fp_normalize_rows": [vp, i64, i32, f32, vp, vp],
+    "fp_knn_l2": [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp],
+    "fp_tfidf_build": [vp, vp, i32, vp, i32, vp, i32, i32, f32, i32, vp, vp, f32, vp],
+    "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32,
+                          vp, vp, vp, vp, vp, vp, vp, vp, vp],
+    "fp_sample_bilinear": [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
+    "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
+    "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
+    "fp_vit_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, vp, vp, vp],
+    "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
+    "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
+    "fp_gemm_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_attention": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
+    "fp_gemm_qkv_bf16": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_convert_f32_to_bf16": [vp, vp, i64, vp],
+}
+
+_lib = None
+
+
+class FoundPoseNativeError(RuntimeError):
+    pass
+
+
+def lib() -> C.CDLL:
+    """Loads the HIP library (after torch, so both share one libamdhip64 runtime)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FoundPoseNativeError(
+                f"{LIB_PATH} is missing: build it with `python -m foundpose_amd.build` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        handle.fp_last_error.restype = C.c_char_p
+        handle.fp_last_error.argtypes = []
+        for name, args in _PROTOS.items():
+            fn = getattr(handle, name)  # AttributeError here = header/library mismatch
+            fn.argtypes = args
+            fn.restype = i32
+        if handle.fp_abi_version() != ABI_VERSION:
+            raise FoundPoseNativeError("libfoundpose_amd.so ABI version mismatch; rebuild")
+        _lib = handle
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(_PROTOS) + ["fp_last_error"])
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise FoundPoseNativeError(f"{name} failed (code {rc}): {lib().fp_last_error().decode()}")
+
+
+def ptr(t) -> vp:
+    """Device pointer of a tensor (None -> NULL)."""
+    if t is None:
+        return vp(0)
+    return vp(t.data_ptr())
+
+
+def stream() -> vp:
+    return vp(torch.cuda.current_stream().cuda_stream)
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise FoundPoseNativeError(
+                "foundpose_amd runs on the MI355X only: got a CPU tensor (move inputs to 'cuda'; no CPU fallback exists)")

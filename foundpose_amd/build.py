@@ -1,0 +1,57 @@
+"""Builds foundpose_amd/lib/libfoundpose_amd.so with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m foundpose_amd.build [--force]
+"""
+
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIBDIR = os.path.join(HERE, "lib")
+OBJDIR = os.path.join(HERE, "lib", "obj")
+SO = os.path.join(LIBDIR, "libfoundpose_amd.so")
+SOURCES = ["api.cpp", "f32_tile.hip", "match.hip", "gemm_bf16.hip", "attn.hip", "vit.hip"]
+HEADERS = ["common.hpp", "kernels.hpp", os.path.join("..", "..", "include", "foundpose_amd.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value"]
+
+
+def _newer(a, b):
+    return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def build(force: bool = False, verbose: bool = True) -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
+    jobs = []
+    for src in SOURCES:
+        sp = os.path.join(CSRC, src)
+        obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
+        stale = force or _newer(sp, obj) or any(_newer(h, obj) for h in hdr_paths)
+        jobs.append((sp, obj, stale))
+
+    def compile_one(job):
+        sp, obj, stale = job
+        if not stale:
+            return
+        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+
+    with ThreadPoolExecutor(max_workers=min(6, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, jobs))
+    objs = [j[1] for j in jobs]
+    if force or any(_newer(o, SO) for o in objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO, *objs]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return SO
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv))

@@ -1,0 +1,332 @@
+// C ABI of libfoundpose_amd.so (declared in include/foundpose_amd.h): argument checking, scratch carving
+// and kernel sequencing.  No allocation, no synchronisation, no global mutable state.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/foundpose_amd.h"
+#include "common.hpp"
+#include "kernels.hpp"
+
+static thread_local char g_err[512] = "";
+
+void fp_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+#define TRY(expr)              \
+  do {                         \
+    int rc__ = (expr);         \
+    if (rc__ != FP_OK) return rc__; \
+  } while (0)
+#define HIP_TRY(expr, what)                                             \
+  do {                                                                  \
+    hipError_t e__ = (expr);                                            \
+    if (e__ != hipSuccess) {                                            \
+      fp_set_error("%s: %s", what, hipGetErrorString(e__));             \
+      return FP_ERR_HIP;                                                \
+    }                                                                   \
+  } while (0)
+
+static F32TileArgs zero_tile_args() {
+  F32TileArgs a;
+  memset(&a, 0, sizeof(a));
+  return a;
+}
+
+extern "C" {
+
+int fp_abi_version(void) { return FP_ABI_VERSION; }
+const char* fp_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------ matching half
+int fp_sqnorm_rows(const float* x, int64_t n, int d, float* out, fp_stream_t stream) {
+  FP_REQUIRE(x && out, "fp_sqnorm_rows: null pointer");
+  return launch_sqnorm_rows(x, n, d, d, out, ST(stream));
+}
+
+int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, fp_stream_t stream) {
+  FP_REQUIRE(x && out, "fp_normalize_rows: null pointer");
+  return launch_normalize_rows(x, n, d, eps, out, ST(stream));
+}
+
+int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n, int d,
+              int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream) {
+  FP_REQUIRE(q && q_sqnorm && db && db_sqnorm && scratch && out_idx, "fp_knn_l2: null pointer");
+  FP_REQUIRE(k >= 1 && n >= 1 && d >= 4, "fp_knn_l2: bad sizes (n=%d d=%d k=%d)", n, d, k);
+  if (m == 0) return FP_OK;
+  F32TileArgs a = zero_tile_args();
+  a.A = q; a.lda = d; a.B = db; a.ldb = d; a.K = d; a.M = m; a.N = n;
+  a.a_sqnorm = q_sqnorm; a.b_sqnorm = db_sqnorm;
+  if (k == 1) {
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(scratch);
+    HIP_TRY(hipMemsetAsync(best, 0xFF, (size_t)m * 8, ST(stream)), "fp_knn_l2: memset");
+    a.row_best = best; a.row_stride = 0; a.col_best = nullptr;
+    TRY(f32_tile_launch(F32_EPI_DIST_ARGMIN, a, m, n, 1, ST(stream)));
+    return launch_unpack_best(best, m, out_d2, out_idx, ST(stream));
+  }
+  FP_REQUIRE(out_d2, "fp_knn_l2: out_d2 is required for k > 1");
+  float* dist = reinterpret_cast<float*>(scratch);
+  a.out = dist; a.ldo = n;
+  TRY(f32_tile_launch(F32_EPI_DIST_STORE, a, m, n, 1, ST(stream)));
+  return launch_topk_rows(dist, m, n, n, nullptr, k, 0, out_d2, out_idx, ST(stream));
+}
+
+int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, const int32_t* seg_off, int num_segs,
+                   const float* idf, int num_words, int soft_assign, float soft_sigma_squared, int sqrt_dists,
+                   float* desc, float* desc_n, float eps, fp_stream_t stream) {
+  FP_REQUIRE(word_ids && word_d2 && seg_off && idf && desc, "fp_tfidf_build: null pointer");
+  return launch_tfidf_build(word_ids, word_d2, knn_k, seg_off, num_segs, idf, num_words, soft_assign,
+                            soft_sigma_squared, sqrt_dists, desc, desc_n, eps, ST(stream));
+}
+
+int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
+                   int max_det_per_obj, const float* bank_n, const int32_t* obj_tpl_off, int num_obj,
+                   int max_templates, int num_words, int n_top, float* scratch_sims, float* out_scores,
+                   int32_t* out_ids, fp_stream_t stream) {
+  FP_REQUIRE(desc_n && det_seg_off && det_num_templates && bank_n && obj_tpl_off && scratch_sims && out_scores && out_ids,
+             "fp_cosine_topk: null pointer");
+  FP_REQUIRE(num_obj >= 1 && max_templates >= 1 && n_top >= 1, "fp_cosine_topk: bad sizes");
+  if (num_det == 0) return FP_OK;
+  F32TileArgs a = zero_tile_args();
+  a.A = desc_n; a.lda = num_words; a.B = bank_n; a.ldb = num_words; a.K = num_words;
+  a.a_seg_off = det_seg_off; a.b_seg_off = obj_tpl_off;
+  a.out = scratch_sims; a.ldo = max_templates; a.out_row_global = 1;
+  TRY(f32_tile_launch(F32_EPI_STORE, a, max_det_per_obj, max_templates, num_obj, ST(stream)));
+  return launch_topk_rows(scratch_sims, num_det, max_templates, max_templates, det_num_templates, n_top, 1,
+                          out_scores, out_ids, ST(stream));
+}
+
+int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
+                      const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
+                      const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
+                      const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
+                      void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
+                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d,
+                      fp_stream_t stream) {
+  FP_REQUIRE(query_feats && query_sqnorm && query_points && q_off && bank_feats && bank_sqnorm && tpl_off && vertices &&
+                 tpl_ids && feat_base && scratch && out_count && out_q_ids && out_feat_ids && out_dists && out_conf &&
+                 out_coord_2d && out_coord_3d,
+             "fp_cyclic_buddies: null pointer");
+  FP_REQUIRE(q_max >= 1 && p_max >= 1 && n_slots >= 1, "fp_cyclic_buddies: bad sizes");
+  const int pairs = num_det * n_slots;
+  if (pairs == 0) return FP_OK;
+  unsigned long long* row_best = reinterpret_cast<unsigned long long*>(scratch);
+  unsigned long long* col_best = row_best + (size_t)pairs * q_max;
+  HIP_TRY(hipMemsetAsync(row_best, 0xFF, (size_t)pairs * (q_max + p_max) * 8, ST(stream)), "fp_cyclic_buddies: memset");
+  F32TileArgs a = zero_tile_args();
+  a.A = query_feats; a.lda = d; a.B = bank_feats; a.ldb = d; a.K = d;
+  a.a_seg_off = q_off; a.pair_a_div = n_slots;
+  a.b_seg_off = tpl_off; a.pair_b_seg = tpl_ids;
+  a.a_sqnorm = query_sqnorm; a.b_sqnorm = bank_sqnorm;
+  a.row_best = row_best; a.row_stride = q_max; a.col_best = col_best; a.col_stride = p_max;
+  TRY(f32_tile_launch(F32_EPI_DIST_ARGMIN, a, q_max, p_max, pairs, ST(stream)));
+  CyclicArgs c;
+  memset(&c, 0, sizeof(c));
+  c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_off = tpl_off; c.feat_base = feat_base;
+  c.points = query_points; c.vertices = vertices;
+  c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max;
+  c.n_slots = n_slots; c.top_k = top_k; c.k_max = k_max; c.q_max = q_max;
+  c.out_count = out_count; c.out_q_ids = out_q_ids; c.out_feat_ids = out_feat_ids; c.out_dists = out_dists;
+  c.out_conf = out_conf; c.out_coord_2d = out_coord_2d; c.out_coord_3d = out_coord_3d;
+  return launch_cyclic_select(c, pairs, ST(stream));
+}
+
+int fp_sample_bilinear(const float* fmap, int64_t stride_img, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                       int C, int H, int W, int img_w, int img_h, const float* points, const int32_t* point_img,
+                       int num_points, float* out, fp_stream_t stream) {
+  FP_REQUIRE(fmap && points && out, "fp_sample_bilinear: null pointer");
+  SampleArgs a;
+  a.fmap = fmap; a.stride_img = stride_img; a.stride_c = stride_c; a.stride_h = stride_h; a.stride_w = stride_w;
+  a.C = C; a.H = H; a.W = W; a.img_w = img_w; a.img_h = img_h;
+  a.points = points; a.point_img = point_img; a.num_points = num_points; a.out = out;
+  return launch_sample_bilinear(a, ST(stream));
+}
+
+int fp_pca_project(const float* x, int n, int D, const float* components, int d, const float* mean_proj, float* out,
+                   fp_stream_t stream) {
+  FP_REQUIRE(x && components && out, "fp_pca_project: null pointer");
+  if (n == 0) return FP_OK;
+  F32TileArgs a = zero_tile_args();
+  a.A = x; a.lda = D; a.B = components; a.ldb = D; a.K = D; a.M = n; a.N = d;
+  a.out = out; a.ldo = d; a.bias = mean_proj;
+  return f32_tile_launch(mean_proj ? F32_EPI_SUB_VEC : F32_EPI_STORE, a, n, d, 1, ST(stream));
+}
+
+// ------------------------------------------------------------------ ViT building blocks
+int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
+                fp_stream_t stream) {
+  FP_REQUIRE(images && out, "fp_patchify: null pointer");
+  return patchify_launch(images, B, H, W, patch, out, ld_out, out_dtype, ST(stream));
+}
+
+int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
+                 int out_dtype, int dim, int out_rows, int out_rows_per_img, int in_rows_per_img, int in_skip,
+                 fp_stream_t stream) {
+  FP_REQUIRE(x && weight && bias && out, "fp_layernorm: null pointer");
+  LayerNormArgs a;
+  a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
+  a.out_dtype = out_dtype; a.dim = dim; a.out_rows = out_rows;
+  a.out_rows_per_img = out_rows_per_img > 0 ? out_rows_per_img : (out_rows > 0 ? out_rows : 1);
+  a.in_rows_per_img = in_rows_per_img > 0 ? in_rows_per_img : a.out_rows_per_img;
+  a.in_skip = in_skip;
+  return layernorm_launch(a, ST(stream));
+}
+
+int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                 const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream) {
+  FP_REQUIRE(A && W && out, "fp_gemm_bf16: null pointer");
+  FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
+                 epilogue == GEMM_EPI_BIAS_F32,
+             "fp_gemm_bf16: epilogue %d is not available through this entry point", epilogue);
+  FP_REQUIRE(epilogue != GEMM_EPI_LS_RESID_F32 || gamma, "fp_gemm_bf16: gamma required");
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
+  return gemm_bf16_launch(epilogue, a, ST(stream));
+}
+
+int fp_gemm_qkv_bf16(const void* A, int lda, const void* W, int ldw, int M, int M_valid, int dim, const float* bias,
+                     void* qkv, void* vt, int vt_ld, int n_tok, fp_stream_t stream) {
+  FP_REQUIRE(A && W && qkv && vt && bias, "fp_gemm_qkv_bf16: null pointer");
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = 3 * dim; a.K = dim; a.M_valid = M_valid; a.bias = bias; a.out = qkv; a.ldo = 3 * dim;
+  a.vt = reinterpret_cast<__bf16*>(vt); a.vt_ld = vt_ld; a.vit_dim = dim; a.tok_n = n_tok;
+  return gemm_bf16_launch(GEMM_EPI_QKV_BF16, a, ST(stream));
+}
+
+int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
+                const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream) {
+  FP_REQUIRE(A && W && out, "fp_gemm_f32: null pointer");
+  FP_REQUIRE(epilogue == F32_EPI_STORE || epilogue == F32_EPI_BIAS || epilogue == F32_EPI_BIAS_GELU ||
+                 epilogue == F32_EPI_LS_RESID || epilogue == F32_EPI_SUB_VEC,
+             "fp_gemm_f32: epilogue %d is not available through this entry point", epilogue);
+  FP_REQUIRE(epilogue != F32_EPI_LS_RESID || gamma, "fp_gemm_f32: gamma required");
+  if (M == 0) return FP_OK;
+  F32TileArgs a = zero_tile_args();
+  a.A = A; a.lda = lda; a.B = W; a.ldb = ldw; a.K = K; a.M = M; a.N = N;
+  a.out = out; a.ldo = ldo; a.bias = bias; a.gamma = gamma;
+  return f32_tile_launch(epilogue, a, M, N, 1, ST(stream));
+}
+
+int fp_attention(const void* qkv, int ld_qkv, const void* vt, int vt_ld, void* out, int ld_out, int B, int n_tok,
+                 int dim, int heads, int dtype, fp_stream_t stream) {
+  FP_REQUIRE(qkv && out, "fp_attention: null pointer");
+  AttnArgs a;
+  a.qkv = qkv; a.ld_qkv = ld_qkv; a.vt = vt; a.vt_ld = vt_ld; a.out = out; a.ld_out = ld_out;
+  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads;
+  return attn_launch(a, dtype, ST(stream));
+}
+
+int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream) {
+  FP_REQUIRE(in && out, "fp_convert_f32_to_bf16: null pointer");
+  return convert_f32_to_bf16_launch(in, out, n, ST(stream));
+}
+
+// ------------------------------------------------------------------ ViT forward (launch sequence in C++)
+int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
+                   int layer, fp_stream_t stream) {
+  FP_REQUIRE(m && ws && images && m->blocks, "fp_vit_forward: null pointer");
+  FP_REQUIRE(layer >= 0 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);
+  if (m->ffn_swiglu) {
+    fp_set_error("fp_vit_forward: SwiGLU FFN (ViT-g) is not implemented yet");
+    return FP_ERR_UNSUPPORTED;
+  }
+  FP_REQUIRE(H % m->patch == 0 && W % m->patch == 0, "fp_vit_forward: image size must be a multiple of the patch size");
+  const int D = m->dim, np = (H / m->patch) * (W / m->patch), ntok = 1 + m->registers + np;
+  const int Mtok = B * ntok, Mp = B * np;
+  FP_REQUIRE(ws->m_pad >= Mtok && ws->m_pad % 128 == 0, "fp_vit_forward: workspace m_pad (%d) too small for %d tokens or not a multiple of 128", ws->m_pad, Mtok);
+  FP_REQUIRE(ws->m_patch_pad >= Mp && ws->m_patch_pad % 128 == 0, "fp_vit_forward: workspace m_patch_pad too small");
+  FP_REQUIRE(ws->patches && ws->x && ws->y && ws->qkv && ws->h, "fp_vit_forward: workspace buffer missing");
+  hipStream_t st = ST(stream);
+  const bool bf = m->weight_dtype == FP_DTYPE_BF16;
+  if (bf) FP_REQUIRE(ws->vt && ws->vt_ld % 64 == 0 && ws->vt_ld >= ntok, "fp_vit_forward: V^T workspace missing / too small");
+
+  // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
+  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, m->weight_dtype, st));
+  TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
+  if (bf) {
+    GemmBf16Args g;
+    memset(&g, 0, sizeof(g));
+    g.A = reinterpret_cast<const __bf16*>(ws->patches); g.lda = m->patch_k_pad;
+    g.W = reinterpret_cast<const __bf16*>(m->patch_w); g.ldw = m->patch_k_pad;
+    g.M = ws->m_patch_pad; g.N = D; g.K = m->patch_k_pad; g.M_valid = Mp; g.bias = m->patch_b;
+    g.out = ws->x; g.ldo = D; g.pos = m->pos_patch; g.tok_np = np; g.tok_n = ntok; g.tok_skip = 1 + m->registers;
+    TRY(gemm_bf16_launch(GEMM_EPI_TOKENS_F32, g, st));
+  } else {
+    F32TileArgs a = zero_tile_args();
+    a.A = reinterpret_cast<const float*>(ws->patches); a.lda = m->patch_k_pad;
+    a.B = reinterpret_cast<const float*>(m->patch_w); a.ldb = m->patch_k_pad; a.K = m->patch_k_pad; a.M = Mp; a.N = D;
+    a.out = ws->x; a.ldo = D; a.bias = m->patch_b; a.pos = m->pos_patch; a.tok_np = np; a.tok_n = ntok;
+    a.tok_skip = 1 + m->registers;
+    TRY(f32_tile_launch(F32_EPI_TOKENS, a, Mp, D, 1, st));
+  }
+
+  LayerNormArgs ln;
+  ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = m->weight_dtype;
+  ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
+  AttnArgs at;
+  at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.vt = ws->vt; at.vt_ld = ws->vt_ld; at.out = ws->y; at.ld_out = D;
+  at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
+
+  for (int i = 0; i <= layer; ++i) {
+    const fp_vit_block& b = m->blocks[i];
+    // x += ls1 * proj(attn(ln1(x)))
+    ln.weight = b.ln1_w; ln.bias = b.ln1_b;
+    TRY(layernorm_launch(ln, st));
+    if (bf) {
+      TRY(fp_gemm_qkv_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, Mtok, D, b.qkv_b, ws->qkv, ws->vt, ws->vt_ld, ntok, stream));
+      TRY(attn_launch(at, FP_DTYPE_BF16, st));
+      TRY(fp_gemm_bf16(ws->y, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+    } else {
+      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.qkv_w, D, Mtok, 3 * D, D, b.qkv_b, nullptr, (float*)ws->qkv, 3 * D, F32_EPI_BIAS, stream));
+      TRY(attn_launch(at, FP_DTYPE_F32, st));
+      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.proj_w, D, Mtok, D, D, b.proj_b, b.ls1, ws->x, D, F32_EPI_LS_RESID, stream));
+    }
+    // x += ls2 * fc2(gelu(fc1(ln2(x))))
+    ln.weight = b.ln2_w; ln.bias = b.ln2_b;
+    TRY(layernorm_launch(ln, st));
+    if (bf) {
+      TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
+      TRY(fp_gemm_bf16(ws->h, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+    } else {
+      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_BIAS_GELU, stream));
+      TRY(fp_gemm_f32((const float*)ws->h, m->hidden, (const float*)b.fc2_w, m->hidden, Mtok, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, F32_EPI_LS_RESID, stream));
+    }
+  }
+  return FP_OK;
+}
+
+int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int n_patches, int apply_norm,
+                    float* fmap, float* cls, fp_stream_t stream) {
+  FP_REQUIRE(m && ws && fmap, "fp_vit_features: null pointer");
+  const int D = m->dim, ntok = 1 + m->registers + n_patches;
+  hipStream_t st = ST(stream);
+  if (apply_norm) {
+    LayerNormArgs ln;
+    ln.x = ws->x; ln.ld_x = D; ln.weight = m->norm_w; ln.bias = m->norm_b; ln.eps = 1e-6f;
+    ln.out_dtype = FP_DTYPE_F32; ln.dim = D; ln.in_rows_per_img = ntok; ln.ld_out = D;
+    ln.out = fmap; ln.out_rows = B * n_patches; ln.out_rows_per_img = n_patches; ln.in_skip = 1 + m->registers;
+    TRY(layernorm_launch(ln, st));
+    if (cls) {
+      ln.out = cls; ln.out_rows = B; ln.out_rows_per_img = 1; ln.in_skip = 0;
+      TRY(layernorm_launch(ln, st));
+    }
+  } else {
+    HIP_TRY(hipMemcpy2DAsync(fmap, (size_t)n_patches * D * 4, ws->x + (size_t)(1 + m->registers) * D, (size_t)ntok * D * 4,
+                             (size_t)n_patches * D * 4, B, hipMemcpyDeviceToDevice, st), "fp_vit_features: copy");
+    if (cls)
+      HIP_TRY(hipMemcpy2DAsync(cls, (size_t)D * 4, ws->x, (size_t)ntok * D * 4, (size_t)D * 4, B, hipMemcpyDeviceToDevice, st),
+              "fp_vit_features: copy cls");
+  }
+  return FP_OK;
+}
+
+}  // extern "C"

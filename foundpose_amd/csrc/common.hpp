@@ -1,0 +1,85 @@
+// Shared device/host helpers for the gfx950 kernels (wave64, MFMA, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+#define FP_DEVICE __device__ __forceinline__
+
+// ---- status codes of the C ABI (include/foundpose_amd.h)
+enum : int {
+  FP_OK = 0,
+  FP_ERR_INVALID = 1,   // bad argument (shape / alignment / dtype)
+  FP_ERR_UNSUPPORTED = 2,
+  FP_ERR_HIP = 3,       // a HIP runtime call or launch failed
+};
+
+void fp_set_error(const char* fmt, ...);
+
+#define FP_REQUIRE(cond, ...)              \
+  do {                                     \
+    if (!(cond)) {                         \
+      fp_set_error(__VA_ARGS__);           \
+      return FP_ERR_INVALID;               \
+    }                                      \
+  } while (0)
+
+#define FP_CHECK_LAUNCH(name)                                              \
+  do {                                                                     \
+    hipError_t e__ = hipGetLastError();                                    \
+    if (e__ != hipSuccess) {                                               \
+      fp_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+      return FP_ERR_HIP;                                                   \
+    }                                                                      \
+  } while (0)
+
+// ---- bf16 <-> f32
+FP_DEVICE float bf16_to_f32(__bf16 v) { return (float)v; }
+
+FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
+  f32x2 p = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
+}
+
+// ---- wave-level reductions (64 lanes)
+FP_DEVICE float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+FP_DEVICE float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+FP_DEVICE unsigned long long wave_min_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned long long t = __shfl_xor(v, o, 64);
+    v = t < v ? t : v;
+  }
+  return v;
+}
+
+// Non-negative floats order like their bit patterns: (d2, index) -> one u64 key whose
+// unsigned order is "smaller distance first, ties -> lower index".
+FP_DEVICE unsigned long long pack_dist_idx(float d2, unsigned idx) {
+  return ((unsigned long long)__float_as_uint(d2) << 32) | idx;
+}
+
+// XCD-aware bijective block remap (guide section 5.5 T1): consecutive logical tiles share an XCD's L2.
+FP_DEVICE unsigned xcd_remap(unsigned bid, unsigned nwg) {
+  const unsigned nx = 8;
+  unsigned q = nwg / nx, r = nwg % nx;
+  unsigned xcd = bid % nx, idx = bid / nx;
+  unsigned base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }

@@ -1,0 +1,125 @@
+// Internal launch interfaces between the C ABI (api.cpp) and the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---------------------------------------------------------------- f32_tile.hip
+enum : int {
+  F32_EPI_STORE = 0,        // out = acc
+  F32_EPI_DIST_STORE = 1,   // out = max(0, fma(-2, acc, |a|^2 + |b|^2))
+  F32_EPI_DIST_ARGMIN = 2,  // atomicMin of (d2,idx) keys per row and per column
+  F32_EPI_SUB_VEC = 3,      // out = acc - vec[j]          (PCA: X C^T - mu C^T)
+  F32_EPI_BIAS = 4,         // out = acc + bias[j]
+  F32_EPI_BIAS_GELU = 5,    // out = gelu_erf(acc + bias[j])
+  F32_EPI_LS_RESID = 6,     // out += gamma[j] * (acc + bias[j])
+  F32_EPI_TOKENS = 7,       // patch-embed scatter into the token sequence (+ pos-embed)
+};
+
+struct F32TileArgs {
+  const float* A; int lda;
+  const float* B; int ldb;
+  int K, M, N;
+  // ragged grouping (device tables, may be null): pair -> segment of A rows / B rows
+  const int* a_seg_off; const int* pair_a_seg; int pair_a_div;  // pair_a_div > 0: segment = pair / pair_a_div
+  const int* b_seg_off; const int* pair_b_seg;
+  // epilogue operands
+  float* out; int ldo; long long out_pair_stride; int out_row_global;  // out_row_global: row index = a_off + i
+  const float* a_sqnorm; const float* b_sqnorm;
+  unsigned long long* row_best; int row_stride;
+  unsigned long long* col_best; int col_stride;
+  const float* bias; const float* gamma;
+  const float* pos; int tok_np, tok_n, tok_skip;
+};
+
+int f32_tile_launch(int epi, const F32TileArgs& a, int max_m, int max_n, int pairs, hipStream_t st);
+
+// ---------------------------------------------------------------- match.hip
+struct CyclicArgs {
+  const int* q_off;        // [B+1] query-point segment per detection
+  const int* tpl_ids;      // [B*n_slots] global template id per (detection, slot); <0 = empty slot
+  const int* tpl_off;      // [T_total+1] feature segment per template
+  const int* feat_base;    // [B] first feature row of the detection's object (ids are reported object-local)
+  const float* points;     // [sumQ, 2]
+  const float* vertices;   // [N_f, 3]
+  const unsigned long long* row_best; int row_stride;  // [pairs, row_stride] (d2, template patch)
+  const unsigned long long* col_best; int col_stride;  // [pairs, col_stride] (d2, query patch)
+  int n_slots, top_k, k_max, q_max;
+  int* out_count;          // [pairs]
+  int* out_q_ids;          // [pairs, k_max]
+  int* out_feat_ids;       // [pairs, k_max]
+  float* out_dists;        // [pairs, k_max]
+  float* out_conf;         // [pairs, k_max]
+  float* out_coord_2d;     // [pairs, k_max, 2]
+  float* out_coord_3d;     // [pairs, k_max, 3]
+};
+
+struct SampleArgs {
+  const float* fmap; long long stride_img, stride_c, stride_h, stride_w;
+  int C, H, W, img_w, img_h;
+  const float* points; const int* point_img; int num_points;
+  float* out;  // [num_points, C]
+};
+
+int launch_sqnorm_rows(const float* x, long long n, int d, int ld, float* out, hipStream_t st);
+int launch_normalize_rows(const float* x, long long n, int d, float eps, float* out, hipStream_t st);
+int launch_topk_rows(const float* vals, int rows, int n, int ld, const int* row_len, int k, int largest,
+                     float* out_val, int* out_idx, hipStream_t st);
+int launch_tfidf_build(const int* word_ids, const float* word_d2, int knn_k, const int* seg_off, int num_segs,
+                       const float* idf, int num_words, int soft, float sigma_sq, int sqrt_dists,
+                       float* desc, float* desc_n, float eps, hipStream_t st);
+int launch_cyclic_select(const CyclicArgs& a, int num_pairs, hipStream_t st);
+int launch_sample_bilinear(const SampleArgs& a, hipStream_t st);
+int launch_sqrt_inplace(float* x, long long n, hipStream_t st);
+
+// ---------------------------------------------------------------- gemm_bf16.hip
+enum : int {
+  GEMM_EPI_BIAS_BF16 = 0,     // out(bf16) = acc + bias
+  GEMM_EPI_GELU_BF16 = 1,     // out(bf16) = gelu_erf(acc + bias)
+  GEMM_EPI_QKV_BF16 = 2,      // q,k -> out(bf16) [M,3D];  v -> vt[b][h][d][t] (keys contiguous)
+  GEMM_EPI_LS_RESID_F32 = 3,  // out(f32) += gamma * (acc + bias)      (LayerScale + residual)
+  GEMM_EPI_TOKENS_F32 = 4,    // patch-embed rows scattered into the token sequence (+ bias + pos-embed)
+  GEMM_EPI_BIAS_F32 = 5,      // out(f32) = acc + bias
+};
+
+struct GemmBf16Args {
+  const __bf16* A; int lda;   // [M, K] activations (M padded to 128)
+  const __bf16* W; int ldw;   // [N, K] weights (torch Linear layout)
+  int M, N, K, M_valid;
+  const float* bias;          // [N] or null
+  const float* gamma;         // [N] LayerScale
+  void* out; int ldo;
+  const float* pos;           // [Np, ldo] fp32 pos-embed rows of the patch tokens
+  int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
+  __bf16* vt; int vt_ld; int vit_dim;
+};
+
+int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
+
+// ---------------------------------------------------------------- dtypes of the C ABI
+enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1 };
+
+// ---------------------------------------------------------------- attn.hip
+struct AttnArgs {
+  const void* qkv; int ld_qkv;   // [B*N, 3D] (bf16 or f32): q | k | v column blocks, head-major inside
+  const void* vt; int vt_ld;     // bf16 only: V^T [B][D][vt_ld] (keys contiguous, zero padded)
+  void* out; int ld_out;         // [B*N, D]
+  int batch, n_tok, dim, heads;
+};
+int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
+
+// ---------------------------------------------------------------- vit.hip
+struct LayerNormArgs {
+  const float* x; int ld_x;      // fp32 residual stream
+  const float* weight; const float* bias; float eps;
+  void* out; int ld_out; int out_dtype;
+  int dim;
+  int out_rows;                  // rows to produce
+  int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi
+};
+int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
+
+int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
+                    int out_dtype, hipStream_t st);
+int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
+int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
+int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st);

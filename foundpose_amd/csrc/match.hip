@@ -1,0 +1,331 @@
+// Descriptor-matching kernels that are not GEMM-shaped (HBM/latency-bound integer + fp32 work):
+// row norms, canonical row top-k, tf-idf histogram, cyclic best-buddy selection, bilinear sampling.
+//
+// Reference behaviour restated (paths under /root/reference):
+//   topk_rows ........ faiss heap result order (utils/knn_util.py:83) / torch.topk (utils/template_util.py:172)
+//                      canonical order here: best value first, ties -> lowest index
+//   tfidf_build ...... utils/template_util.py:31-71 (weights, L2-normalise per query, tf = w/Q,
+//                      scatter_add_ in flattened order) + the query side of cosine_similarity (:167)
+//   cyclic_select .... utils/corresp_util.py:49-70,135-155
+//   sample_bilinear .. utils/feature_util.py:100-131 (grid_sample bilinear, zeros, align_corners=False)
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+// ------------------------------------------------------------------ |x|^2 per row, k-ascending fmaf chain
+__global__ void sqnorm_rows_kernel(const float* __restrict__ x, long long n, int d, int ld, float* __restrict__ out) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float4* r = reinterpret_cast<const float4*>(x + i * ld);
+  float acc = 0.f;
+  for (int k = 0; k < d / 4; ++k) {
+    float4 v = r[k];
+    acc = fmaf(v.x, v.x, acc);
+    acc = fmaf(v.y, v.y, acc);
+    acc = fmaf(v.z, v.z, acc);
+    acc = fmaf(v.w, v.w, acc);
+  }
+  out[i] = acc;
+}
+
+// x / max(sqrt(|x|^2), eps) per row (bank-side cosine normalisation; |x|^2 as above)
+__global__ void normalize_rows_kernel(const float* __restrict__ x, long long n, int d, float eps, float* __restrict__ out) {
+  // one wave per row; lane 0 computes the chain so the order matches the oracle
+  long long row = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const int lane = threadIdx.x & 63;
+  const float* r = x + row * d;
+  float acc = 0.f;
+  if (lane == 0)
+    for (int k = 0; k < d; ++k) acc = fmaf(r[k], r[k], acc);
+  acc = __shfl(acc, 0, 64);
+  const float nrm = fmaxf(sqrtf(acc), eps);
+  for (int k = lane; k < d; k += 64) out[row * d + k] = r[k] / nrm;
+}
+
+// ------------------------------------------------------------------ canonical top-k along rows
+FP_DEVICE unsigned order_key(float v, bool largest) {
+  unsigned b = __float_as_uint(v);
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending float order as unsigned
+  return largest ? ~b : b;
+}
+
+// One wave per row. k selection passes; each pass takes the smallest (key, index) above the previous one.
+__global__ void topk_rows_kernel(const float* __restrict__ vals, int rows, int n, int ld, const int* __restrict__ row_len,
+                                 int k, int largest, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const int len = row_len ? row_len[row] : n;
+  const float* r = vals + (size_t)row * ld;
+  unsigned long long prev = 0;
+  bool have_prev = false;
+  for (int s = 0; s < k; ++s) {
+    unsigned long long best = ~0ull;
+    for (int j = lane; j < len; j += 64) {
+      unsigned long long key = ((unsigned long long)order_key(r[j], largest) << 32) | (unsigned)j;
+      if ((!have_prev || key > prev) && key < best) best = key;
+    }
+    best = wave_min_u64(best);
+    if (lane == 0) {
+      if (best != ~0ull) {
+        int j = (int)(best & 0xffffffffu);
+        out_idx[(size_t)row * k + s] = j;
+        out_val[(size_t)row * k + s] = r[j];
+      } else {
+        out_idx[(size_t)row * k + s] = -1;
+        out_val[(size_t)row * k + s] = largest ? -INFINITY : INFINITY;
+      }
+    }
+    prev = best;
+    have_prev = true;
+  }
+}
+
+// ------------------------------------------------------------------ tf-idf descriptor per detection
+// One block (256 threads) per segment (a detection's query patches, or a template's patches on the
+// bank-builder side). Thread t owns the bins with (id & 255) == t and walks the (q, j) entries in
+// flattened order, so every bin sees its addends in exactly the order scatter_add_ applies them.
+__global__ __launch_bounds__(256) void tfidf_build_kernel(
+    const int* __restrict__ word_ids, const float* __restrict__ word_d2, int knn_k, const int* __restrict__ seg_off,
+    const float* __restrict__ idf, int num_words, int soft, float two_sigma_sq, int sqrt_dists,
+    float* __restrict__ desc, float* __restrict__ desc_n, float eps) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* bins = reinterpret_cast<float*>(smem_raw);            // [num_words]
+  int* ids = reinterpret_cast<int*>(bins + num_words);         // [chunk]
+  float* vals = reinterpret_cast<float*>(ids + 4096);          // [chunk]
+  __shared__ float s_nrm;
+
+  const int seg = blockIdx.x, tid = threadIdx.x;
+  const int q0 = seg_off[seg], Q = seg_off[seg + 1] - q0;
+  for (int w = tid; w < num_words; w += 256) bins[w] = 0.f;
+  const float fQ = (float)Q;
+  const int total = Q * knn_k;
+  for (int base = 0; base < total; base += 4096) {
+    __syncthreads();
+    const int cnt = min(4096, total - base);
+    // stage (id, tf*idf) for entries [base, base+cnt); entry e -> query e / k, neighbour e % k
+    for (int e = tid; e < cnt; e += 256) {
+      const int g = base + e;
+      const int q = g / knn_k, j = g - q * knn_k;
+      const int* idr = word_ids + (size_t)(q0 + q) * knn_k;
+      const float* dr = word_d2 + (size_t)(q0 + q) * knn_k;
+      float nrm2 = 0.f, wj = 1.f;
+      for (int t = 0; t < knn_k; ++t) {
+        float w = 1.f;
+        if (soft) {
+          float x = sqrt_dists ? sqrtf(dr[t]) : dr[t];
+          w = expf(-(x * x) / two_sigma_sq);
+        }
+        nrm2 = nrm2 + w * w;  // sequential, like a 3-element fp32 sum
+        if (t == j) wj = w;
+      }
+      const float wn = wj / fmaxf(sqrtf(nrm2), 1e-12f);
+      const float tf = wn / fQ;
+      const int id = idr[j];
+      ids[e] = id;
+      vals[e] = tf * idf[id];
+    }
+    __syncthreads();
+    for (int e = 0; e < cnt; ++e) {
+      const int id = ids[e];
+      if ((id & 255) == tid) bins[id] += vals[e];
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float acc = 0.f;
+    for (int w = 0; w < num_words; ++w) acc = fmaf(bins[w], bins[w], acc);
+    s_nrm = fmaxf(sqrtf(acc), eps);
+  }
+  __syncthreads();
+  const float nrm = s_nrm;
+  for (int w = tid; w < num_words; w += 256) {
+    const float v = bins[w];
+    desc[(size_t)seg * num_words + w] = v;
+    if (desc_n) desc_n[(size_t)seg * num_words + w] = v / nrm;
+  }
+}
+
+// ------------------------------------------------------------------ cyclic best buddies: select + gather
+__global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
+  __shared__ unsigned long long keys[2048];
+  __shared__ int q2o_s[2048];
+  const int pair = blockIdx.x, tid = threadIdx.x;
+  const int det = pair / a.n_slots;
+  const int q0 = a.q_off[det], Q = a.q_off[det + 1] - q0;
+  const int tpl = a.tpl_ids[pair];
+  const int kk = min(a.top_k, Q);
+  if (tid == 0) a.out_count[pair] = (tpl >= 0) ? kk : 0;
+  if (tpl < 0 || Q == 0) return;
+  const int f0 = a.tpl_off[tpl];
+  const unsigned long long* rb = a.row_best + (size_t)pair * a.row_stride;
+  const unsigned long long* cb = a.col_best + (size_t)pair * a.col_stride;
+  const float* pts = a.points + (size_t)q0 * 2;
+
+  for (int i = tid; i < 2048; i += 256) {
+    unsigned long long key = ~0ull;
+    if (i < Q) {
+      const int o = (int)(rb[i] & 0xffffffffu);        // query -> nearest template patch
+      const int c = (int)(cb[o] & 0xffffffffu);        // that patch -> nearest query patch
+      q2o_s[i] = o;
+      const float dx = __fsub_rn(pts[2 * i], pts[2 * c]);
+      const float dy = __fsub_rn(pts[2 * i + 1], pts[2 * c + 1]);
+      const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));  // no fma contraction
+      key = pack_dist_idx(d, (unsigned)i);
+    }
+    keys[i] = key;
+  }
+  __syncthreads();
+  // bitonic sort of 2048 keys, ascending: (cycle distance, query index)
+  for (int size = 2; size <= 2048; size <<= 1) {
+    for (int stride = size >> 1; stride > 0; stride >>= 1) {
+      for (int t = tid; t < 1024; t += 256) {
+        const int lo = 2 * t - (t & (stride - 1));
+        const int hi = lo + stride;
+        const bool up = ((lo & size) == 0);
+        unsigned long long x = keys[lo], y = keys[hi];
+        if ((x > y) == up) { keys[lo] = y; keys[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  const float dmax = __uint_as_float((unsigned)(keys[kk - 1] >> 32));
+  const size_t ob = (size_t)pair * a.k_max;
+  for (int r = tid; r < kk; r += 256) {
+    const unsigned long long key = keys[r];
+    const int qi = (int)(key & 0xffffffffu);
+    const float d = __uint_as_float((unsigned)(key >> 32));
+    const int feat = f0 + q2o_s[qi];
+    a.out_q_ids[ob + r] = qi;
+    a.out_feat_ids[ob + r] = feat - a.feat_base[det];
+    a.out_dists[ob + r] = d;
+    a.out_conf[ob + r] = 1.0f - d / dmax;
+    a.out_coord_2d[(ob + r) * 2 + 0] = pts[2 * qi];
+    a.out_coord_2d[(ob + r) * 2 + 1] = pts[2 * qi + 1];
+    const float* v = a.vertices + (size_t)feat * 3;
+    a.out_coord_3d[(ob + r) * 3 + 0] = v[0];
+    a.out_coord_3d[(ob + r) * 3 + 1] = v[1];
+    a.out_coord_3d[(ob + r) * 3 + 2] = v[2];
+  }
+}
+
+// ------------------------------------------------------------------ bilinear sampling of a feature map
+// One wave per point. fmap addressed through element strides so both the token-major [Np, D] image the
+// extractor produces (a CHW *view*, like the reference's) and a contiguous CHW tensor work.
+__global__ void sample_bilinear_kernel(SampleArgs a) {
+  const int p = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (p >= a.num_points) return;
+  const int lane = threadIdx.x & 63;
+  const int img = a.point_img ? a.point_img[p] : 0;
+  const float px = a.points[2 * p], py = a.points[2 * p + 1];
+  // uv = (2/size) * p - 1   (fp32, no fma: feature_util.py:119)
+  const float u = __fsub_rn(__fmul_rn(__fdiv_rn(2.0f, (float)a.img_w), px), 1.0f);
+  const float v = __fsub_rn(__fmul_rn(__fdiv_rn(2.0f, (float)a.img_h), py), 1.0f);
+  // grid_sample unnormalise, align_corners=False: ((c + 1) * size - 1) / 2
+  const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(u, 1.f), (float)a.W), 1.f), 2.f);
+  const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(v, 1.f), (float)a.H), 1.f), 2.f);
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
+  const float w_nw = wx0 * wy0, w_ne = wx1 * wy0, w_sw = wx0 * wy1, w_se = wx1 * wy1;
+  const bool vx0 = x0 >= 0 && x0 < a.W, vx1 = x1 >= 0 && x1 < a.W, vy0 = y0 >= 0 && y0 < a.H, vy1 = y1 >= 0 && y1 < a.H;
+  const float* base = a.fmap + (size_t)img * a.stride_img;
+  for (int c = lane; c < a.C; c += 64) {
+    const float* bc = base + (size_t)c * a.stride_c;
+    float acc = 0.f;
+    if (vx0 && vy0) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y0 * a.stride_h + (size_t)x0 * a.stride_w], w_nw));
+    if (vx1 && vy0) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y0 * a.stride_h + (size_t)x1 * a.stride_w], w_ne));
+    if (vx0 && vy1) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y1 * a.stride_h + (size_t)x0 * a.stride_w], w_sw));
+    if (vx1 && vy1) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y1 * a.stride_h + (size_t)x1 * a.stride_w], w_se));
+    a.out[(size_t)p * a.C + c] = acc;
+  }
+}
+
+__global__ void unpack_best_kernel(const unsigned long long* __restrict__ best, long long n, float* __restrict__ d2, int* __restrict__ idx) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const unsigned long long b = best[i];
+  if (d2) d2[i] = __uint_as_float((unsigned)(b >> 32));
+  idx[i] = (int)(b & 0xffffffffu);
+}
+
+__global__ void sqrt_inplace_kernel(float* x, long long n) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = sqrtf(x[i]);
+}
+
+}  // namespace
+
+int launch_sqnorm_rows(const float* x, long long n, int d, int ld, float* out, hipStream_t st) {
+  FP_REQUIRE(d % 4 == 0 && ld % 4 == 0, "sqnorm_rows: d and ld must be multiples of 4");
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(sqnorm_rows_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, d, ld, out);
+  FP_CHECK_LAUNCH("sqnorm_rows");
+  return FP_OK;
+}
+
+int launch_normalize_rows(const float* x, long long n, int d, float eps, float* out, hipStream_t st) {
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(normalize_rows_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, x, n, d, eps, out);
+  FP_CHECK_LAUNCH("normalize_rows");
+  return FP_OK;
+}
+
+int launch_topk_rows(const float* vals, int rows, int n, int ld, const int* row_len, int k, int largest,
+                     float* out_val, int* out_idx, hipStream_t st) {
+  FP_REQUIRE(k >= 1, "topk_rows: k must be >= 1");
+  if (rows == 0) return FP_OK;
+  hipLaunchKernelGGL(topk_rows_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, vals, rows, n, ld, row_len, k, largest, out_val, out_idx);
+  FP_CHECK_LAUNCH("topk_rows");
+  return FP_OK;
+}
+
+int launch_tfidf_build(const int* word_ids, const float* word_d2, int knn_k, const int* seg_off, int num_segs,
+                       const float* idf, int num_words, int soft, float sigma_sq, int sqrt_dists,
+                       float* desc, float* desc_n, float eps, hipStream_t st) {
+  FP_REQUIRE(num_words > 0 && num_words <= 16384, "tfidf_build: num_words out of range");
+  FP_REQUIRE(knn_k >= 1 && knn_k <= 16, "tfidf_build: knn_k out of range");
+  if (num_segs == 0) return FP_OK;
+  size_t lds = (size_t)num_words * 4 + 4096 * 8;
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfidf_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4 + 4096 * 8);
+    attr = true;
+  }
+  hipLaunchKernelGGL(tfidf_build_kernel, dim3(num_segs), dim3(256), lds, st, word_ids, word_d2, knn_k, seg_off, idf,
+                     num_words, soft, 2.0f * sigma_sq, sqrt_dists, desc, desc_n, eps);
+  FP_CHECK_LAUNCH("tfidf_build");
+  return FP_OK;
+}
+
+int launch_cyclic_select(const CyclicArgs& a, int num_pairs, hipStream_t st) {
+  FP_REQUIRE(a.q_max <= 2048, "cyclic_select: more than 2048 query points per detection (got %d)", a.q_max);
+  FP_REQUIRE(a.top_k >= 1 && a.k_max >= a.top_k, "cyclic_select: bad top_k / k_max");
+  if (num_pairs == 0) return FP_OK;
+  hipLaunchKernelGGL(cyclic_select_kernel, dim3(num_pairs), dim3(256), 0, st, a);
+  FP_CHECK_LAUNCH("cyclic_select");
+  return FP_OK;
+}
+
+int launch_sample_bilinear(const SampleArgs& a, hipStream_t st) {
+  if (a.num_points == 0) return FP_OK;
+  hipLaunchKernelGGL(sample_bilinear_kernel, dim3(cdiv(a.num_points, 4)), dim3(256), 0, st, a);
+  FP_CHECK_LAUNCH("sample_bilinear");
+  return FP_OK;
+}
+
+int launch_sqrt_inplace(float* x, long long n, hipStream_t st) {
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(sqrt_inplace_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n);
+  FP_CHECK_LAUNCH("sqrt_inplace");
+  return FP_OK;
+}
+
+int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st) {
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(unpack_best_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, best, n, d2, idx);
+  FP_CHECK_LAUNCH("unpack_best");
+  return FP_OK;
+}

@@ -1,0 +1,135 @@
+// Memory-bound ViT glue kernels: LayerNorm (+cast, + token re-indexing), patch extraction with the
+// ImageNet normalisation folded in, CLS/register token rows.
+//
+// Reference behaviour restated: T.Normalize(mean,std) (/root/reference/utils/dinov2_utils.py:111-123),
+// the backbone's patch_embed unfold, nn.LayerNorm(eps=1e-6) inside the blocks and the final
+// `self.model.norm(tokens)` on CLS+patch tokens with the register tokens dropped (dinov2_utils.py:138-142,304).
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace {
+
+// One wave per row; the row lives in registers (D/128 float2 per lane, D <= 2048), two-pass mean/var.
+template <int MAXI>
+__global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.out_rows) return;
+  const int lane = threadIdx.x & 63;
+  const int img = row / a.out_rows_per_img, p = row - img * a.out_rows_per_img;
+  const float* x = a.x + ((size_t)img * a.in_rows_per_img + a.in_skip + p) * a.ld_x;
+  const int n2 = a.dim >> 7;  // float2 per lane
+  float2 v[MAXI];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < n2) {
+      v[i] = *reinterpret_cast<const float2*>(x + (i * 64 + lane) * 2);
+      s += v[i].x + v[i].y;
+    }
+  const float mean = wave_sum(s) / (float)a.dim;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < n2) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean;
+      ss += dx * dx + dy * dy;
+    }
+  const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < n2) {
+      const int c = (i * 64 + lane) * 2;
+      const float2 w = *reinterpret_cast<const float2*>(a.weight + c);
+      const float2 b = *reinterpret_cast<const float2*>(a.bias + c);
+      const float y0 = (v[i].x - mean) * rstd * w.x + b.x;
+      const float y1 = (v[i].y - mean) * rstd * w.y + b.y;
+      if (a.out_dtype == FP_DTYPE_BF16)
+        *reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c) = pack_bf16x2(y0, y1);
+      else
+        *reinterpret_cast<float2*>(reinterpret_cast<float*>(a.out) + (size_t)row * a.ld_out + c) = make_float2(y0, y1);
+    }
+}
+
+// images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
+// column = c*P*P + py*P + px (the flattening of the conv weight [D,3,P,P]); columns >= 3*P*P are zero.
+template <typename T>
+__global__ void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld) {
+  const long long total = (long long)B * (H / P) * (W / P) * ld;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= total) return;
+  const int col = (int)(e % ld);
+  const long long row = e / ld;
+  const int gw = W / P, gh = H / P, np = gw * gh;
+  const int b = (int)(row / np), pi = (int)(row % np);
+  const int gy = pi / gw, gx = pi - gy * gw;
+  float v = 0.f;
+  if (col < 3 * P * P) {
+    const int c = col / (P * P), rem = col - c * P * P;
+    const int py = rem / P, px = rem - py * P;
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+    const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    const float x = img[(((size_t)b * 3 + c) * H + gy * P + py) * W + gx * P + px];
+    v = __fdiv_rn(__fsub_rn(x, mean), stdv);
+  }
+  out[e] = (T)v;
+}
+
+__global__ void prefix_tokens_kernel(const float* __restrict__ prefix, int n_prefix, int dim, float* __restrict__ tokens, int batch, int n_tok) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long total = (long long)batch * n_prefix * dim;
+  if (e >= total) return;
+  const int c = (int)(e % dim);
+  const int r = (int)((e / dim) % n_prefix);
+  const int b = (int)(e / ((long long)dim * n_prefix));
+  tokens[((size_t)b * n_tok + r) * dim + c] = prefix[(size_t)r * dim + c];
+}
+
+__global__ void f32_to_bf16_kernel(const float* __restrict__ in, __bf16* __restrict__ out, long long n) {
+  long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) {
+    *reinterpret_cast<unsigned*>(out + i) = pack_bf16x2(in[i], in[i + 1]);
+  } else if (i < n) {
+    out[i] = (__bf16)in[i];
+  }
+}
+
+}  // namespace
+
+int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
+  FP_REQUIRE(a.dim % 128 == 0 && a.dim <= 2048, "layernorm: dim must be a multiple of 128 and <= 2048 (got %d)", a.dim);
+  FP_REQUIRE(a.ld_x % 2 == 0 && a.ld_out % 2 == 0, "layernorm: leading dims must be even");
+  if (a.out_rows == 0) return FP_OK;
+  hipLaunchKernelGGL(layernorm_kernel<16>, dim3(cdiv(a.out_rows, 4)), dim3(256), 0, st, a);
+  FP_CHECK_LAUNCH("layernorm");
+  return FP_OK;
+}
+
+int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
+                    int out_dtype, hipStream_t st) {
+  FP_REQUIRE(height % patch == 0 && width % patch == 0, "patchify: image %dx%d is not a multiple of the patch size %d", height, width, patch);
+  FP_REQUIRE(ld_out >= 3 * patch * patch, "patchify: ld_out too small");
+  const long long total = (long long)batch * (height / patch) * (width / patch) * ld_out;
+  if (total == 0) return FP_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (out_dtype == FP_DTYPE_BF16)
+    hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out);
+  else
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out);
+  FP_CHECK_LAUNCH("patchify");
+  return FP_OK;
+}
+
+int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st) {
+  const long long total = (long long)batch * n_prefix * dim;
+  if (total == 0) return FP_OK;
+  hipLaunchKernelGGL(prefix_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, prefix, n_prefix, dim, tokens, batch, n_tok);
+  FP_CHECK_LAUNCH("prefix_tokens");
+  return FP_OK;
+}
+
+int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st) {
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, st, in, reinterpret_cast<__bf16*>(out), n);
+  FP_CHECK_LAUNCH("f32_to_bf16");
+  return FP_OK;
+}

@@ -1,0 +1,190 @@
+"""DINOv2 patch-feature extractor with the reference's interface
+(/root/reference/utils/dinov2_utils.py:25-158), executed by hand-written gfx950 kernels.
+
+Differences that do not change results:
+  * blocks after `layer` are not executed (the reference runs the whole backbone and keeps only the hooked
+    block's output, dinov2_utils.py:257) and no autograd graph is built;
+  * weights: the reference downloads the pretrained hub checkpoint (`pretrained=True`, dinov2_utils.py:82);
+    there is no network here, so pass `state_dict=` (upstream DINOv2 key names) or get seeded random weights.
+Not implemented (unused by the shipped configs): stride != 14 and the key/query/value facets.
+"""
+
+import ctypes as C
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib, synthetic
+from ._lib import call, ptr, stream
+from .vit_config import ARCHS, ExtractorSpec, VitArch, parse_extractor_name
+
+
+def _interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: int) -> torch.Tensor:
+    """Pos-embed table for a gh x gw patch grid (host-side weight preparation, once per resolution)."""
+    n = pos_embed.shape[1] - 1
+    m = int(math.sqrt(n))
+    if gh * gw == n and gh == gw:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    grid = pos_embed[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2)
+    if arch.interp_offset:
+        kw = {"scale_factor": (float(gh + arch.interp_offset) / m, float(gw + arch.interp_offset) / m)}
+    else:
+        kw = {"size": (gh, gw)}
+    grid = F.interpolate(grid, mode="bicubic", antialias=arch.interp_antialias, **kw)
+    if tuple(grid.shape[-2:]) != (gh, gw):
+        raise RuntimeError("pos-embed interpolation produced an unexpected grid")
+    return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)
+
+
+class DinoFeatureExtractor(torch.nn.Module):
+    def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
+                 precision: str = "bf16", arch: Optional[VitArch] = None) -> None:
+        super().__init__()
+        if arch is not None:  # non-hub architecture (unit tests use a tiny one)
+            ARCHS[arch.name] = arch
+        spec: ExtractorSpec = parse_extractor_name(model_name)
+        self.version, self.stride, self.facet = spec.version, spec.stride, spec.facet
+        self.layer, self.apply_norm = spec.layer, spec.apply_norm
+        self.arch: VitArch = arch if arch is not None else spec.arch
+        self.model_base_name = f"dinov2_{self.version}".replace("-", "_")
+        self.patch_size = self.arch.patch
+        if self.stride != self.patch_size:
+            raise NotImplementedError("stride != patch size (pos-embed re-striding) is not implemented on the MI355X path")
+        if self.facet != "token":
+            raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path (shipped configs use 'token')")
+        if not 0 <= self.layer < self.arch.depth:
+            raise ValueError(f"layer {self.layer} out of range for {self.version}")
+        if precision not in ("bf16", "fp32"):
+            raise ValueError("precision must be 'bf16' or 'fp32'")
+        self.precision = precision
+        self._sd = state_dict if state_dict is not None else synthetic.make_vit_state_dict(self.arch, seed)
+        self._device: Optional[torch.device] = None
+        self._w: Dict[str, torch.Tensor] = {}
+        self._model = None
+        self._blocks = None
+        self._grids: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
+        self._ws: Dict[Tuple[int, int, int], Tuple[_lib.VitWorkspace, list]] = {}
+        self.num_patches: Optional[Tuple[int, int]] = None
+
+    # ---- device placement (same call pattern as the reference: extractor.to(device))
+    def to(self, device=None, *args, **kwargs):  # type: ignore[override]
+        dev = torch.device(device if device is not None else "cuda")
+        if dev.type != "cuda":
+            raise _lib.FoundPoseNativeError("DinoFeatureExtractor runs on the MI355X only (device must be 'cuda'); no CPU path exists")
+        self._prepare(dev)
+        return self
+
+    def cuda(self, device=None):  # type: ignore[override]
+        return self.to("cuda" if device is None else device)
+
+    def _prepare(self, dev: torch.device) -> None:
+        a, sd = self.arch, self._sd
+        wdt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        w: Dict[str, torch.Tensor] = {}
+
+        def mat(key):
+            w[key] = sd[key].to(dev, torch.float32).to(wdt).contiguous()
+            return w[key]
+
+        def vec(key):
+            w[key] = sd[key].to(dev, torch.float32).reshape(-1).contiguous()
+            return w[key]
+
+        kp = 3 * a.patch * a.patch
+        kpad = (kp + 63) // 64 * 64
+        pw = torch.zeros(a.dim, kpad, dtype=torch.float32, device=dev)
+        pw[:, :kp] = sd["patch_embed.proj.weight"].to(dev, torch.float32).reshape(a.dim, kp)
+        w["patch_w"] = pw.to(wdt).contiguous()
+        vec("patch_embed.proj.bias")
+        vec("norm.weight")
+        vec("norm.bias")
+        blocks = (_lib.VitBlock * a.depth)()
+        for i in range(a.depth):
+            p = f"blocks.{i}."
+            b = blocks[i]
+            b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
+            b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))
+            b.ls1, b.ls2 = ptr(vec(p + "ls1.gamma")), ptr(vec(p + "ls2.gamma"))
+            b.qkv_w, b.qkv_b = ptr(mat(p + "attn.qkv.weight")), ptr(vec(p + "attn.qkv.bias"))
+            b.proj_w, b.proj_b = ptr(mat(p + "attn.proj.weight")), ptr(vec(p + "attn.proj.bias"))
+            if a.ffn == "mlp":
+                b.fc1_w, b.fc1_b = ptr(mat(p + "mlp.fc1.weight")), ptr(vec(p + "mlp.fc1.bias"))
+                b.fc2_w, b.fc2_b = ptr(mat(p + "mlp.fc2.weight")), ptr(vec(p + "mlp.fc2.bias"))
+        m = _lib.VitModel()
+        m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
+        m.ffn_swiglu = int(a.ffn != "mlp")
+        m.weight_dtype = _lib.FP_BF16 if self.precision == "bf16" else _lib.FP_F32
+        m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
+        m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
+        m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
+        self._w, self._model, self._blocks, self._device = w, m, blocks, dev
+        self._grids.clear()
+        self._ws.clear()
+
+    def _grid_tables(self, gh: int, gw: int):
+        key = (gh, gw)
+        if key not in self._grids:
+            a, sd = self.arch, self._sd
+            pos = _interpolate_pos_embed(sd["pos_embed"].float(), a, gh, gw)[0]  # [1+Np, D]
+            rows = [sd["cls_token"].float().reshape(1, -1) + pos[:1]]
+            if a.registers:
+                rows.append(sd["register_tokens"].float().reshape(a.registers, -1))
+            prefix = torch.cat(rows, 0).to(self._device).contiguous()
+            self._grids[key] = (pos[1:].to(self._device).contiguous(), prefix)
+        return self._grids[key]
+
+    def _workspace(self, B: int, gh: int, gw: int):
+        key = (B, gh, gw)
+        if key not in self._ws:
+            a, dev = self.arch, self._device
+            adt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+            np_, ntok = gh * gw, 1 + a.registers + gh * gw
+            m_pad = (B * ntok + 127) // 128 * 128
+            mp_pad = (B * np_ + 127) // 128 * 128
+            vt_ld = (ntok + 63) // 64 * 64
+            bufs = [
+                torch.zeros(mp_pad, self._model.patch_k_pad, dtype=adt, device=dev),
+                torch.zeros(m_pad, a.dim, dtype=torch.float32, device=dev),
+                torch.zeros(m_pad, a.dim, dtype=adt, device=dev),
+                torch.zeros(m_pad, 3 * a.dim, dtype=adt, device=dev),
+                torch.zeros(B, a.dim, vt_ld, dtype=torch.bfloat16, device=dev),
+                torch.zeros(m_pad, a.hidden, dtype=adt, device=dev),
+            ]
+            ws = _lib.VitWorkspace()
+            ws.patches, ws.x, ws.y, ws.qkv, ws.vt, ws.h = (ptr(t) for t in bufs)
+            ws.m_pad, ws.m_patch_pad, ws.vt_ld = m_pad, mp_pad, vt_ld
+            self._ws[key] = (ws, bufs)
+        return self._ws[key]
+
+    # ---- forward
+    def forward_tokens(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+        """-> (fmap [B, Np, D] fp32 token-major, cls [B, D] fp32); the batched fast-path entry."""
+        if self._model is None:
+            raise _lib.FoundPoseNativeError("call extractor.to('cuda') before running it")
+        _lib.require_cuda(images)
+        if images.dim() != 4 or images.shape[1] != 3:
+            raise ValueError("images must be [B, 3, H, W]")
+        images = images.float().contiguous()
+        B, _, H, W = images.shape
+        if H % self.patch_size or W % self.patch_size:
+            raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {self.patch_size}")
+        gh, gw = H // self.patch_size, W // self.patch_size
+        pos_patch, prefix = self._grid_tables(gh, gw)
+        self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
+        ws, _ = self._workspace(B, gh, gw)
+        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        fmap = torch.empty(B, gh * gw, self.arch.dim, dtype=torch.float32, device=images.device)
+        cls = torch.empty(B, self.arch.dim, dtype=torch.float32, device=images.device)
+        call("fp_vit_features", C.byref(self._model), C.byref(ws), B, gh * gw, int(self.apply_norm), ptr(fmap), ptr(cls), stream())
+        self.num_patches = (gh, gw)
+        return fmap, cls
+
+    def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
+        B, _, H, W = images.shape
+        fmap, cls = self.forward_tokens(images)
+        gh, gw = H // self.patch_size, W // self.patch_size
+        # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output
+        return {"cls_tokens": cls, "feature_maps": fmap.reshape(B, gh, gw, self.arch.dim).permute(0, 3, 1, 2)}

@@ -1,0 +1,152 @@
+"""Batched descriptor matching on the MI355X: visual-word k-NN -> tf-idf -> template retrieval ->
+cyclic best buddies -> 2D-3D correspondences, for B detections at once.
+
+This is the batched form of `establish_correspondences` (/root/reference/utils/corresp_util.py:73-169 with
+utils/template_util.py:126-176); the reference processes one detection at a time on the CPU through faiss.
+Detections must be grouped by object (ascending object index) so the bank is streamed once per object group.
+"""
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence
+
+import torch
+
+from . import ops
+from ._lib import call, ptr, stream, require_cuda
+from .bank import DeviceBank
+
+
+@dataclass
+class MatchResult:
+    """Padded device tensors; slot j of detection b is valid for the first counts[b, j] entries."""
+
+    template_ids: torch.Tensor     # [B, n] i32 object-local template ids (-1 = no template)
+    template_scores: torch.Tensor  # [B, n] f32 cosine similarity
+    counts: torch.Tensor           # [B, n] i32
+    q_ids: torch.Tensor            # [B, n, K] i32  (coord_2d_ids)
+    feat_ids: torch.Tensor         # [B, n, K] i32  (nn_vertex_ids)
+    dists: torch.Tensor            # [B, n, K] f32  cycle distances in px
+    conf: torch.Tensor             # [B, n, K] f32
+    coord_2d: torch.Tensor         # [B, n, K, 2] f32
+    coord_3d: torch.Tensor         # [B, n, K, 3] f32
+    query_tfidf: Optional[torch.Tensor] = None  # [B, W] (debug)
+    word_ids: Optional[torch.Tensor] = None     # [sumQ, k]
+
+    def corresp_list(self, b: int, debug: bool = False) -> List[Dict]:
+        """The reference's List[Dict] for detection b (keys as in corresp_util.py:142-163)."""
+        counts = self.counts[b].tolist()
+        tids = self.template_ids[b].tolist()
+        out = []
+        for j, (c, tid) in enumerate(zip(counts, tids)):
+            if tid < 0:
+                continue
+            d = {
+                "template_id": self.template_ids[b, j].to(torch.int64),
+                "template_score": self.template_scores[b, j],
+                "coord_2d": self.coord_2d[b, j, :c],
+                "coord_2d_ids": self.q_ids[b, j, :c].to(torch.int64),
+                "coord_3d": self.coord_3d[b, j, :c],
+                "coord_conf": self.conf[b, j, :c],
+                "nn_vertex_ids": self.feat_ids[b, j, :c].to(torch.int64),
+            }
+            if debug:
+                d["nn_dists"] = self.dists[b, j, :c]
+                d["nn_indices"] = d["nn_vertex_ids"]
+            out.append(d)
+        return out
+
+
+def match_batch(
+    bank: DeviceBank,
+    query_features: torch.Tensor,   # [sumQ, d] f32, detections concatenated
+    query_points: torch.Tensor,     # [sumQ, 2] f32
+    q_counts: Sequence[int],        # Q_b per detection (host)
+    det_obj: Optional[Sequence[int]] = None,  # object index per detection, ascending (host); default all 0
+    top_n_templates: int = 5,
+    top_k_buddies: int = 300,
+    keep_debug: bool = False,
+) -> MatchResult:
+    require_cuda(query_features, query_points)
+    dev = query_features.device
+    B = len(q_counts)
+    det_obj = [0] * B if det_obj is None else list(det_obj)
+    if any(det_obj[i] > det_obj[i + 1] for i in range(B - 1)):
+        raise ValueError("detections must be grouped by object (ascending object index)")
+    if query_features.shape[1] != bank.feat_dim:
+        raise ValueError(f"query features have {query_features.shape[1]} dims, bank has {bank.feat_dim}")
+    qf = query_features.float().contiguous()
+    qp = query_points.float().contiguous()
+    q_off_h = [0]
+    for c in q_counts:
+        q_off_h.append(q_off_h[-1] + int(c))
+    sumQ = q_off_h[-1]
+    if qf.shape[0] != sumQ:
+        raise ValueError("query_features rows do not match sum(q_counts)")
+    q_max = max(1, max(q_counts) if B else 1)
+    n, K = top_n_templates, top_k_buddies
+    q_off = torch.tensor(q_off_h, dtype=torch.int32, device=dev)
+
+    q_sqn = ops.sqnorm_rows(qf)
+
+    # ---- per object group: nearest visual words (k-NN, k = tfidf_knn_k) and tf-idf descriptors
+    W = bank.num_words
+    desc = torch.empty(B, W, dtype=torch.float32, device=dev)
+    desc_n = torch.empty(B, W, dtype=torch.float32, device=dev)
+    groups = []  # (obj, first_det, end_det)
+    i = 0
+    while i < B:
+        j = i
+        while j < B and det_obj[j] == det_obj[i]:
+            j += 1
+        groups.append((det_obj[i], i, j))
+        i = j
+    word_ids_all = []
+    for obj, d0, d1 in groups:
+        o = bank.objects[obj]
+        r0, r1 = q_off_h[d0], q_off_h[d1]
+        if o.opts.tfidf_knn_metric != "l2":
+            raise ValueError(f"Metric {o.opts.tfidf_knn_metric} is not supported on this path.")
+        w_d2, w_ids = ops.knn_l2(qf[r0:r1], o.words, o.opts.tfidf_knn_k, q_sqn[r0:r1], o.words_sqn)
+        seg = (q_off[d0:d1 + 1] - r0).contiguous()
+        dsc, dsc_n = ops.tfidf_build(w_ids, w_d2, seg, o.idf, o.opts.tfidf_soft_assign,
+                                     o.opts.tfidf_soft_sigma_squared, sqrt_dists=True)
+        desc[d0:d1] = dsc
+        desc_n[d0:d1] = dsc_n
+        if keep_debug:
+            word_ids_all.append(w_ids)
+
+    # ---- template retrieval: cosine vs the object's template descriptors, top-n
+    det_seg_h = [0] * (bank.num_objects + 1)
+    for obj, d0, d1 in groups:
+        det_seg_h[obj + 1] = d1 - d0
+    for k_ in range(bank.num_objects):
+        det_seg_h[k_ + 1] += det_seg_h[k_]
+    # detections are sorted by object, so object o's detections are rows det_seg_h[o]:det_seg_h[o+1]
+    det_seg = torch.tensor(det_seg_h, dtype=torch.int32, device=dev)
+    det_nt = torch.tensor([bank.objects[o].num_templates for o in det_obj], dtype=torch.int32, device=dev)
+    max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
+    sims = torch.empty(B, bank.max_templates, dtype=torch.float32, device=dev)
+    t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
+    t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
+    call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
+         ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), stream())
+
+    # ---- cyclic best buddies against the retrieved templates + correspondence assembly
+    tpl_base = torch.tensor([bank.objects[o].tpl_base for o in det_obj], dtype=torch.int32, device=dev)
+    feat_base = torch.tensor([bank.objects[o].feat_base for o in det_obj], dtype=torch.int32, device=dev)
+    t_glob = torch.where(t_ids >= 0, t_ids + tpl_base[:, None], t_ids).contiguous()
+    pairs = B * n
+    scratch = torch.empty(pairs * (q_max + bank.p_max), dtype=torch.int64, device=dev)
+    counts = torch.zeros(B, n, dtype=torch.int32, device=dev)
+    q_ids = torch.full((B, n, K), -1, dtype=torch.int32, device=dev)
+    feat_ids = torch.full((B, n, K), -1, dtype=torch.int32, device=dev)
+    dists = torch.zeros(B, n, K, dtype=torch.float32, device=dev)
+    conf = torch.zeros(B, n, K, dtype=torch.float32, device=dev)
+    c2d = torch.zeros(B, n, K, 2, dtype=torch.float32, device=dev)
+    c3d = torch.zeros(B, n, K, 3, dtype=torch.float32, device=dev)
+    call("fp_cyclic_buddies", ptr(qf), ptr(q_sqn), ptr(qp), ptr(q_off), B, q_max, ptr(bank.feats), ptr(bank.feat_sqn),
+         ptr(bank.tpl_off), bank.p_max, ptr(bank.vertices), ptr(t_glob), ptr(feat_base), n, bank.feat_dim, K, K,
+         ptr(scratch), ptr(counts), ptr(q_ids), ptr(feat_ids), ptr(dists), ptr(conf), ptr(c2d), ptr(c3d), stream())
+    return MatchResult(t_ids, t_scores, counts, q_ids, feat_ids, dists, conf, c2d, c3d,
+                       query_tfidf=desc if keep_debug else None,
+                       word_ids=torch.cat(word_ids_all, 0) if keep_debug and word_ids_all else None)

@@ -1,0 +1,147 @@
+"""Tensor-level wrappers over the C ABI: allocate outputs/scratch with torch, pass raw pointers.
+
+torch is plumbing here (device memory + the current HIP stream); every computation is a
+hand-written gfx950 kernel behind include/foundpose_amd.h.
+"""
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, ptr, stream, require_cuda
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def sqnorm_rows(x: torch.Tensor) -> torch.Tensor:
+    require_cuda(x)
+    x = _f32c(x)
+    out = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    call("fp_sqnorm_rows", ptr(x), x.shape[0], x.shape[1], ptr(out), stream())
+    return out
+
+
+def normalize_rows(x: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    require_cuda(x)
+    x = _f32c(x)
+    out = torch.empty_like(x)
+    call("fp_normalize_rows", ptr(x), x.shape[0], x.shape[1], eps, ptr(out), stream())
+    return out
+
+
+_KNN_SCRATCH_BYTES = 1 << 29  # rows are processed in chunks so the [m, n] distance scratch stays <= 512 MiB
+
+
+def knn_l2(q: torch.Tensor, db: torch.Tensor, k: int, q_sqnorm: Optional[torch.Tensor] = None,
+           db_sqnorm: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (squared distances [m,k] f32, indices [m,k] int32), ascending, ties -> lowest index."""
+    require_cuda(q, db)
+    q, db = _f32c(q), _f32c(db)
+    m, d = q.shape
+    n = db.shape[0]
+    if db.shape[1] != d:
+        raise ValueError(f"dimension mismatch: queries {d} vs database {db.shape[1]}")
+    if n == 0:
+        raise ValueError("empty database")
+    k_eff = min(k, n)
+    qn = sqnorm_rows(q) if q_sqnorm is None else q_sqnorm
+    dn = sqnorm_rows(db) if db_sqnorm is None else db_sqnorm
+    d2 = torch.empty(m, k_eff, dtype=torch.float32, device=q.device)
+    idx = torch.empty(m, k_eff, dtype=torch.int32, device=q.device)
+    if m > 0:
+        per_row = 8 if k_eff == 1 else n * 4
+        chunk = max(1, min(m, _KNN_SCRATCH_BYTES // per_row))
+        scratch = torch.empty(chunk * per_row, dtype=torch.uint8, device=q.device)
+        for r0 in range(0, m, chunk):
+            r1 = min(m, r0 + chunk)
+            call("fp_knn_l2", ptr(q[r0:r1]), ptr(qn[r0:r1]), r1 - r0, ptr(db), ptr(dn), n, d, k_eff,
+                 ptr(scratch), ptr(d2[r0:r1]), ptr(idx[r0:r1]), stream())
+    if k_eff < k:  # faiss pads missing neighbours with (inf, -1)
+        pad_d = torch.full((m, k - k_eff), float("inf"), dtype=torch.float32, device=q.device)
+        pad_i = torch.full((m, k - k_eff), -1, dtype=torch.int32, device=q.device)
+        d2, idx = torch.cat([d2, pad_d], 1), torch.cat([idx, pad_i], 1)
+    return d2, idx
+
+
+def tfidf_build(word_ids: torch.Tensor, word_d2: torch.Tensor, seg_off: torch.Tensor, idf: torch.Tensor,
+                soft_assign: bool, soft_sigma_squared: float, sqrt_dists: bool, eps: float = 1e-8):
+    """-> (desc [S, W], desc_n [S, W]) for S = len(seg_off) - 1 point sets."""
+    require_cuda(word_ids, word_d2, seg_off, idf)
+    num_segs = seg_off.shape[0] - 1
+    W = idf.shape[0]
+    desc = torch.empty(num_segs, W, dtype=torch.float32, device=idf.device)
+    desc_n = torch.empty_like(desc)
+    call("fp_tfidf_build", ptr(word_ids), ptr(word_d2), word_ids.shape[1], ptr(seg_off), num_segs, ptr(idf), W,
+         int(soft_assign), float(soft_sigma_squared), int(sqrt_dists), ptr(desc), ptr(desc_n), eps, stream())
+    return desc, desc_n
+
+
+def sample_bilinear(fmap_bchw: torch.Tensor, points: torch.Tensor, point_img: Optional[torch.Tensor],
+                    image_size: Tuple[int, int]) -> torch.Tensor:
+    """fmap_bchw: [B,C,H,W] fp32 with arbitrary strides (no copy); points [P,2] in image coords."""
+    require_cuda(fmap_bchw, points)
+    if fmap_bchw.dtype != torch.float32:
+        fmap_bchw = fmap_bchw.float()
+    points = _f32c(points)
+    B, Cc, H, W = fmap_bchw.shape
+    sb, sc, sh, sw = fmap_bchw.stride()
+    out = torch.empty(points.shape[0], Cc, dtype=torch.float32, device=points.device)
+    call("fp_sample_bilinear", ptr(fmap_bchw), sb, sc, sh, sw, Cc, H, W, int(image_size[0]), int(image_size[1]),
+         ptr(points), ptr(point_img), points.shape[0], ptr(out), stream())
+    return out
+
+
+def pca_project(x: torch.Tensor, components: torch.Tensor, mean_proj: Optional[torch.Tensor]) -> torch.Tensor:
+    require_cuda(x, components)
+    x, components = _f32c(x), _f32c(components)
+    out = torch.empty(x.shape[0], components.shape[0], dtype=torch.float32, device=x.device)
+    call("fp_pca_project", ptr(x), x.shape[0], x.shape[1], ptr(components), components.shape[0], ptr(mean_proj),
+         ptr(out), stream())
+    return out
+
+
+def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias=None, gamma=None, out=None, epilogue: int = 0) -> torch.Tensor:
+    require_cuda(a, w)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    call("fp_gemm_f32", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, ptr(bias), ptr(gamma), ptr(out),
+         out.stride(0), epilogue, stream())
+    return out
+
+
+def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma=None, out=None, epilogue: int = 0,
+              m_valid: Optional[int] = None) -> torch.Tensor:
+    require_cuda(a, w, bias)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        dt = torch.float32 if epilogue in (3, 5) else torch.bfloat16
+        out = torch.zeros(M, N, dtype=dt, device=a.device)
+    call("fp_gemm_bf16", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid,
+         ptr(bias), ptr(gamma), ptr(out), out.stride(0), epilogue, stream())
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_dtype: torch.dtype, eps: float = 1e-6):
+    require_cuda(x, weight, bias)
+    rows, D = x.shape
+    out = torch.empty(rows, D, dtype=out_dtype, device=x.device)
+    call("fp_layernorm", ptr(x), x.stride(0), ptr(weight), ptr(bias), eps, ptr(out), D,
+         _lib.FP_BF16 if out_dtype == torch.bfloat16 else _lib.FP_F32, D, rows, rows, rows, 0, stream())
+    return out
+
+
+def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, vt: Optional[torch.Tensor] = None):
+    require_cuda(qkv)
+    bf = qkv.dtype == torch.bfloat16
+    out = torch.zeros(qkv.shape[0], dim, dtype=qkv.dtype, device=qkv.device)
+    call("fp_attention", ptr(qkv), qkv.stride(0), ptr(vt), 0 if vt is None else vt.shape[-1], ptr(out), dim,
+         batch, n_tok, dim, heads, _lib.FP_BF16 if bf else _lib.FP_F32, stream())
+    return out

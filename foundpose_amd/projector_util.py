@@ -1,0 +1,77 @@
+"""PCA projection of raw ViT features (mirror of /root/reference/utils/projector_util.py).
+
+`transform` = X @ C^T - (mu @ C^T) (sklearn PCA.transform without whitening, projector_util.py:66-69)
+as one exact-fp32 MFMA GEMM with the subtraction fused; no host round trip. `fit` is the offline
+bank-builder step (sklearn SVD in the reference) and is not part of the inference path.
+"""
+
+from typing import Any, Dict, List, Optional
+
+import torch
+
+from . import ops
+
+
+class Projector:
+    def fit(self, data_x: torch.Tensor, data_y: Optional[torch.Tensor] = None, **kwargs: Any) -> None:
+        raise NotImplementedError
+
+    def transform(self, data_x: torch.Tensor) -> torch.Tensor:
+        raise NotImplementedError
+
+
+class PCAProjector(Projector):
+    def __init__(self, n_components: int, whiten: bool = False, **kwargs: Dict[str, Any]) -> None:
+        self.n_components = n_components
+        self.whiten = whiten
+        self.components: Optional[torch.Tensor] = None  # [n_components, D]
+        self.mean: Optional[torch.Tensor] = None        # [D]
+        self.extra: Dict[str, torch.Tensor] = {}        # explained_variance etc., carried through save/load
+        self._dev: Dict[Any, Any] = {}
+
+    def fit(self, data_x: torch.Tensor, data_y: Optional[torch.Tensor] = None, **kwargs: Any) -> None:
+        raise NotImplementedError(
+            "PCA fitting belongs to the offline bank builder (scripts/gen_repre.py in the reference); "
+            "load a fitted projector with projector_from_tensordict")
+
+    def _device_state(self, device):
+        key = str(device)
+        if key not in self._dev:
+            comps = self.components.to(device=device, dtype=torch.float32).contiguous()
+            mean = self.mean.to(device=device, dtype=torch.float32).reshape(1, -1).contiguous()
+            mean_proj = ops.pca_project(mean, comps, None).reshape(-1).contiguous()  # mu @ C^T, same kernel
+            self._dev[key] = (comps, mean_proj)
+        return self._dev[key]
+
+    def transform(self, data_x: torch.Tensor) -> torch.Tensor:
+        if self.components is None:
+            raise RuntimeError("PCAProjector has no components (load it from a tensordict)")
+        comps, mean_proj = self._device_state(data_x.device)
+        return ops.pca_project(data_x, comps, mean_proj)
+
+
+def project_features(feat_vectors: torch.Tensor, projectors: List[Projector], batch_size: int = 4096) -> torch.Tensor:
+    for projector in projectors:
+        feat_vectors = projector.transform(feat_vectors)
+    return feat_vectors
+
+
+def projector_to_tensordict(projector: Projector) -> Dict[str, Any]:
+    if isinstance(projector, PCAProjector):
+        d = {"components": projector.components, "mean": projector.mean, "whiten": torch.tensor(projector.whiten)}
+        d.update(projector.extra)
+        return {"pca_projector": d}
+    raise ValueError(f"Unknown projector type: {type(projector)}")
+
+
+def projector_from_tensordict(projector_dict: Dict[str, Any]) -> Projector:
+    if "pca_projector" in projector_dict:
+        p = projector_dict["pca_projector"]
+        comps = torch.as_tensor(p["components"])
+        # like the reference, the stored `whiten` flag is not applied at transform time (projector_util.py:128)
+        proj = PCAProjector(n_components=comps.shape[0], whiten=bool(torch.as_tensor(p.get("whiten", False))))
+        proj.components = comps.float()
+        proj.mean = torch.as_tensor(p["mean"]).float()
+        proj.extra = {k: v for k, v in p.items() if k not in ("components", "mean", "whiten")}
+        return proj
+    raise ValueError("Unknown projector type.")

@@ -1,0 +1,169 @@
+/* foundpose_amd -- C ABI of the MI355X (gfx950) FoundPose hot path.
+ *
+ * The reference (facebookresearch/foundpose) has NO native/FFI layer: its boundary for this path is the
+ * Python call surface used by scripts/infer.py:468-542.  This header is the new native boundary that the
+ * drop-in Python modules in foundpose_amd/ (same names and signatures as the reference's utils modules) bind with
+ * ctypes.  Each entry point cites the reference computation it replaces (paths relative to the reference
+ * root).  Conventions:
+ *   - every pointer is a DEVICE pointer unless it says "host"; the caller owns all memory (no allocation
+ *     inside the library), including scratch; all work is enqueued on `stream` (a hipStream_t), nothing
+ *     synchronises; the library keeps no mutable global state besides the thread-local error string
+ *   - return value: 0 = ok, 1 = invalid argument, 2 = unsupported, 3 = HIP failure; fp_last_error() gives text
+ *   - indices on the device are int32; distances/scores fp32; L2 distances are SQUARED (faiss convention)
+ *   - canonical ordering of every top-k: best value first, ties broken by the lowest index
+ */
+#ifndef FOUNDPOSE_AMD_H
+#define FOUNDPOSE_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fp_stream_t; /* hipStream_t */
+
+enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
+
+#define FP_ABI_VERSION 1
+int fp_abi_version(void);
+const char* fp_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Descriptor matching half
+ * ---------------------------------------------------------------------------------------------- */
+
+/* out[i] = |x_i|^2 as a k-ascending fp32 fma chain.  Part of faiss IndexFlatL2 (utils/knn_util.py:48-50). */
+int fp_sqnorm_rows(const float* x, int64_t n, int d, float* out, fp_stream_t stream);
+
+/* out = x / max(|x|, eps) per row: the per-operand normalisation of torch cosine_similarity
+ * (utils/template_util.py:167); run once per bank on template_descs. */
+int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, fp_stream_t stream);
+
+/* Exact brute-force L2 k-NN: KNN.fit + KNN.search with metric "l2" (utils/knn_util.py:38-106).
+ * q [m,d], db [n,d], precomputed squared norms of both.  k == 1 needs scratch of m*8 bytes,
+ * k > 1 needs scratch of m*n*4 bytes.  out_d2 [m,k] (squared), out_idx [m,k] int32. */
+int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n,
+              int d, int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream);
+
+/* tf-idf descriptors for `num_segs` point sets (one detection's query patches each):
+ * calc_tfidf (utils/template_util.py:31-71) + the query-side normalisation of cosine_similarity.
+ * word_ids/word_d2 [sumQ, knn_k] from fp_knn_l2 against the visual words; seg_off [num_segs+1].
+ * sqrt_dists=1 applies the sqrt of find_nearest_object_features (template_util.py:26-27) before the
+ * soft-assignment weights (the bank side, template_util.py:112-119, passes 0).
+ * desc [num_segs, num_words]; desc_n (may be null) = desc / max(|desc|, eps). */
+int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, const int32_t* seg_off, int num_segs,
+                   const float* idf, int num_words, int soft_assign, float soft_sigma_squared, int sqrt_dists,
+                   float* desc, float* desc_n, float eps, fp_stream_t stream);
+
+/* Template retrieval: cosine similarity of each detection's descriptor against the template descriptors of
+ * its object + top-n (tfidf_matching, utils/template_util.py:167-174).  Detections are grouped by object:
+ * det_seg_off [num_obj+1] over rows of desc_n, obj_tpl_off [num_obj+1] over rows of bank_n (both
+ * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims [num_det, max_templates].  out_scores/out_ids [num_det, n_top]; ids are
+ * object-local template ids. */
+int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
+                   int max_det_per_obj,
+                   const float* bank_n, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,
+                   int n_top, float* scratch_sims, float* out_scores, int32_t* out_ids, fp_stream_t stream);
+
+/* Cyclic best-buddy matching of every detection against its n_slots retrieved templates and assembly of the
+ * 2D-3D correspondences (cyclic_buddies_matching + the gather in establish_correspondences,
+ * utils/corresp_util.py:34-70,107-155).
+ *   query_feats [sumQ,d], query_sqnorm [sumQ], query_points [sumQ,2], q_off [B+1]
+ *   bank_feats [N_f,d] sorted by template, bank_sqnorm [N_f], tpl_off [T_total+1], vertices [N_f,3]
+ *   tpl_ids [B*n_slots] GLOBAL template ids (object's first template + local id), <0 = empty slot
+ *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
+ *   scratch: B*n_slots*(q_max + p_max)*8 bytes
+ * outputs, padded to k_max >= top_k per (detection, slot): count, query ids, object feature ids (= the
+ * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d. */
+int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
+                      const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
+                      const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
+                      const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
+                      void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
+                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d,
+                      fp_stream_t stream);
+
+/* sample_feature_map_at_points (utils/feature_util.py:100-131): bilinear grid_sample, zeros padding,
+ * align_corners=False.  fmap addressed by element strides (image, channel, y, x); point_img (may be null)
+ * maps each point to its image.  out [num_points, C]. */
+int fp_sample_bilinear(const float* fmap, int64_t stride_img, int64_t stride_c, int64_t stride_h, int64_t stride_w,
+                       int C, int H, int W, int img_w, int img_h, const float* points, const int32_t* point_img,
+                       int num_points, float* out, fp_stream_t stream);
+
+/* PCAProjector.transform (utils/projector_util.py:66-69): out = x @ C^T - mean_proj, mean_proj = mu @ C^T
+ * (computed with the same kernel by passing x = mu, n = 1, mean_proj = null). */
+int fp_pca_project(const float* x, int n, int D, const float* components, int d, const float* mean_proj,
+                   float* out, fp_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Feature extraction half (DINOv2 ViT; the reference reaches it through
+ * DinoFeatureExtractor.forward, utils/dinov2_utils.py:115-158)
+ * ---------------------------------------------------------------------------------------------- */
+
+typedef struct {
+  const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ls1, *ls2; /* fp32 [D] */
+  const void *qkv_w, *proj_w, *fc1_w, *fc2_w;             /* [N,K] row-major (torch Linear), bf16 or f32 */
+  const float *qkv_b, *proj_b, *fc1_b, *fc2_b;            /* fp32 */
+} fp_vit_block;
+
+typedef struct {
+  int dim, depth, heads, hidden, registers, patch;
+  int ffn_swiglu;          /* 1 for ViT-g (not implemented yet -> FP_ERR_UNSUPPORTED) */
+  int weight_dtype;        /* FP_BF16 | FP_F32: dtype of the matrices and of the activation buffers */
+  const void* patch_w;     /* [D, patch_k_pad]: conv weight flattened (c,py,px), zero padded */
+  int patch_k_pad;         /* multiple of 64 */
+  const float* patch_b;    /* [D] */
+  const float* pos_patch;  /* [Np, D] pos-embed rows of the patch tokens for the current grid */
+  const float* prefix;     /* [1+registers, D]: cls_token + pos[0], then the register tokens */
+  const float *norm_w, *norm_b;
+  const fp_vit_block* blocks; /* HOST array of `depth` entries */
+} fp_vit_model;
+
+typedef struct {
+  void* patches; /* [m_patch_pad, patch_k_pad] activation dtype */
+  float* x;      /* [m_pad, D] fp32 residual stream */
+  void* y;       /* [m_pad, D] activation dtype (LN output / attention output) */
+  void* qkv;     /* [m_pad, 3D] */
+  void* vt;      /* bf16 only: [B, D, vt_ld] zero-initialised once by the caller */
+  void* h;       /* [m_pad, hidden] */
+  int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
+  int m_patch_pad; /* multiple of 128, >= B*Np */
+  int vt_ld;     /* multiple of 64, >= tokens per image */
+} fp_vit_workspace;
+
+/* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token
+ * (what the reference's forward hook captures, dinov2_utils.py:160-211), blocks after `layer` are not run. */
+int fp_vit_forward(const fp_vit_model* model, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
+                   int layer, fp_stream_t stream);
+
+/* Final LayerNorm on CLS + patch tokens with the register tokens dropped (dinov2_utils.py:138-142,304):
+ * fmap [B, Np, D] fp32 token-major (the reference's [B,D,Hp,Wp] is a permuted view of it), cls [B, D].
+ * apply_norm = 0 copies the raw tokens. */
+int fp_vit_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int n_patches, int apply_norm,
+                    float* fmap, float* cls, fp_stream_t stream);
+
+/* Building blocks, exported for unit tests and for callers that schedule the layers themselves. */
+int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
+                fp_stream_t stream);
+int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
+                 int out_dtype, int dim, int out_rows, int out_rows_per_img, int in_rows_per_img, int in_skip,
+                 fp_stream_t stream);
+/* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32 */
+int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                 const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
+/* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual */
+int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
+                const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);
+/* qkv [B*N, 3D] (+ vt for bf16) -> out [B*N, D] */
+int fp_attention(const void* qkv, int ld_qkv, const void* vt, int vt_ld, void* out, int ld_out, int B, int n_tok,
+                 int dim, int heads, int dtype, fp_stream_t stream);
+/* qkv projection with the bf16 epilogue that also writes V^T (used by fp_vit_forward) */
+int fp_gemm_qkv_bf16(const void* A, int lda, const void* W, int ldw, int M, int M_valid, int dim, const float* bias,
+                     void* qkv, void* vt, int vt_ld, int n_tok, fp_stream_t stream);
+int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FOUNDPOSE_AMD_H */

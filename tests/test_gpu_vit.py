@@ -1,0 +1,193 @@
+"""GPU parity: ViT kernels (through the C ABI) vs a plain fp32 torch reference of the same op, and the
+extractor vs the oracle / the reference-wrapper fixtures.
+
+Tolerances: fp32 kernels 1e-4 relative (accumulation order); bf16 kernels vs a reference fed the SAME
+bf16-rounded operands: 2^-8 relative of the output scale (one bf16 rounding of the result) unless noted.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd import synthetic
+from foundpose_amd.vit_config import ARCHS
+from oracle import vit as ov
+from tests.helpers import TINY, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    a, b = a.double(), b.double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_layernorm():
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(0)
+    for D in (128, 384, 1024, 1536):
+        x = torch.randn(300, D, generator=g) * 3 + 1
+        w, b = torch.randn(D, generator=g), torch.randn(D, generator=g)
+        ref = torch.nn.functional.layer_norm(x, (D,), w, b, eps=1e-6)
+        y32 = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), torch.float32).cpu()
+        assert rel_err(y32, ref) < 2e-6
+        y16 = ops.layernorm(x.cuda(), w.cuda(), b.cuda(), torch.bfloat16).cpu()
+        assert torch.equal(y16, y32.to(torch.bfloat16)) or rel_err(y16.float(), ref) < 2 ** -8
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (1408, 3072, 1024), (384, 1024, 4096), (128, 128, 640)])
+def test_gemm_bf16_epilogues(M, N, K):
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = (torch.randn(M, K, generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16)
+    bias = torch.randn(N, generator=g)
+    gamma = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = a.double() @ w.double().T + bias.double()
+    scale = float(ref.abs().max())
+    out = ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), epilogue=5).cpu()  # bias -> f32
+    assert float((out.double() - ref).abs().max()) < 2e-5 * scale * max(1, K / 1024)
+    out = ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), epilogue=0).cpu()  # bias -> bf16
+    assert float((out.double() - ref).abs().max()) < 2 ** -8 * scale
+    out = ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), epilogue=1).cpu()  # gelu -> bf16
+    gref = torch.nn.functional.gelu(ref)
+    assert float((out.double() - gref).abs().max()) < 2 ** -8 * scale
+    x = resid.clone().cuda()
+    ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), gamma=gamma.cuda(), out=x, epilogue=3)  # x += gamma * (.)
+    rref = resid.double() + gamma.double() * ref
+    assert float((x.cpu().double() - rref).abs().max()) < 3e-5 * float(rref.abs().max()) * max(1, K / 1024)
+    # M_valid: rows beyond it must be left untouched
+    out = torch.full((M, N), 7.0, dtype=torch.float32).cuda()
+    ops.gemm_bf16(a.cuda(), w.cuda(), bias.cuda(), out=out, epilogue=5, m_valid=M - 5)
+    assert torch.all(out[M - 5:] == 7.0) and torch.all(out[:M - 5] != 7.0)
+
+
+@pytest.mark.parametrize("M,N,K", [(100, 70, 64), (300, 256, 1024), (37, 130, 36)])
+def test_gemm_f32_exact_chain(M, N, K):
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(1)
+    a, w = torch.randn(M, K, generator=g), torch.randn(N, K, generator=g)
+    out = ops.gemm_f32(a.cuda(), w.cuda(), epilogue=0).cpu()
+    assert rel_err(out, a.double() @ w.double().T) < 1e-5
+    # bit-exact vs a k-ordered fmaf chain (same property the distance kernels rely on)
+    from oracle import clib
+    chain = np.stack([clib.dot_rows(w.numpy(), a[i].numpy()) for i in range(min(M, 8))])
+    assert np.array_equal(out[:chain.shape[0]].numpy(), chain)
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 6), (3, 905, 2), (2, 64, 1), (1, 130, 16)])
+def test_attention_bf16_and_f32(B, N, heads):
+    from foundpose_amd import ops
+    D = heads * 64
+    g = torch.Generator().manual_seed(N)
+    qkv = torch.randn(B * N, 3 * D, generator=g) * 1.5
+    def ref_attn(x):
+        q, k, v = x.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+        p = torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1)
+        return (p @ v).transpose(1, 2).reshape(B * N, D)
+    o32 = ops.attention(qkv.cuda(), B, N, D, heads).cpu()
+    assert rel_err(o32, ref_attn(qkv)) < 1e-5
+    q16 = qkv.to(torch.bfloat16)
+    npad = (N + 63) // 64 * 64
+    vt = torch.zeros(B, D, npad, dtype=torch.bfloat16)
+    vt[:, :, :N] = q16[:, 2 * D:].reshape(B, N, D).permute(0, 2, 1)
+    o16 = ops.attention(q16.cuda(), B, N, D, heads, vt=vt.cuda()).cpu()
+    ref = ref_attn(q16.float())
+    # P is rounded to bf16 before P@V and the output to bf16: a few 2^-8 of the output scale
+    assert float((o16.double() - ref).abs().max()) < 3 * 2 ** -8 * float(ref.abs().max())
+
+
+def _extractor(arch, name, seed, precision):
+    from foundpose_amd import feature_util
+    ex = feature_util.make_feature_extractor(name, seed=seed, precision=precision, arch=arch if arch is TINY else None)
+    return ex.to("cuda")
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("bf16", 6e-2)])
+def test_extractor_tiny_vs_reference_wrapper_fixture(precision, tol):
+    g = load_golden("extractor_tiny")
+    imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"])).cuda()
+    for layer, norm in ((1, 1), (2, 1), (0, 0)):
+        ex = _extractor(TINY, f"dinov2_version=tiny-reg_stride=14_facet=token_layer={layer}_logbin=0_norm={norm}", int(g["weights_seed"]), precision)
+        o = ex(imgs)
+        fm = o["feature_maps"]
+        assert fm.shape == (2, 128, 4, 4) and not fm.is_contiguous()  # a permuted view, like the reference
+        ref = g[f"fmap_l{layer}_n{norm}"]
+        np.testing.assert_allclose(fm.cpu().numpy(), ref, rtol=0, atol=tol * np.abs(ref).max())
+        np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g[f"cls_l{layer}_n{norm}"], rtol=0, atol=tol * np.abs(ref).max())
+
+
+def test_extractor_tiny_bf16_vs_quantisation_aware_oracle():
+    """bf16 path vs oracle B (operands rounded to bf16 at the kernel's cast points): much tighter than vs fp32."""
+    sd = synthetic.make_vit_state_dict(TINY, seed=1234)
+    imgs = synthetic.make_crops(2, 56, seed=0)
+    ex = _extractor(TINY, "dinov2_version=tiny-reg_stride=14_facet=token_layer=2_logbin=0_norm=1", 1234, "bf16")
+    fm = ex(imgs.cuda())["feature_maps"].cpu()
+    ref_b = ov.extractor_forward(sd, TINY, imgs, 2, True, quant="bf16")["feature_maps"]
+    ref_a = ov.extractor_forward(sd, TINY, imgs, 2, True)["feature_maps"]
+    eb, ea = rel_err(fm, ref_b), rel_err(fm, ref_a)
+    assert eb < 1.5e-2, (eb, ea)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 8e-2)])
+def test_extractor_vits14reg_518_vs_reference_wrapper_fixture(precision, tol):
+    g = load_golden("extractor_vits14reg_518")
+    imgs = synthetic.make_crops(1, 518, seed=int(g["image_seed"])).cuda()
+    ex = _extractor(None, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1", int(g["weights_seed"]), precision)
+    o = ex(imgs)
+    fm = o["feature_maps"].cpu().numpy()
+    assert fm.shape == (1, 384, 37, 37)
+    scale = np.abs(g["fmap_sub"]).max()
+    np.testing.assert_allclose(fm[:, ::8, ::3, ::3], g["fmap_sub"], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
+
+
+def test_extractor_batch_invariance_and_420():
+    """Each image of a batch gets the same features as when run alone; 420x420 crops take the interpolated pos-embed."""
+    ex = _extractor(None, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1", 1234, "bf16")
+    imgs = synthetic.make_crops(3, 420, seed=5).cuda()
+    all_ = ex(imgs)["feature_maps"].clone()
+    one = ex(imgs[1:2])["feature_maps"]
+    assert all_.shape == (3, 384, 30, 30)
+    assert torch.equal(all_[1], one[0])
+    sd = synthetic.make_vit_state_dict(ARCHS["vits14-reg"], seed=1234)
+    ref = ov.extractor_forward(sd, ARCHS["vits14-reg"], imgs[1:2].cpu(), 9, True)["feature_maps"]
+    assert rel_err(one.cpu(), ref) < 8e-2
+
+
+def test_hot_section_composite_fp32():
+    """infer.py:468-542 end to end on the MI355X (fp32 mode) vs the reference-run fixture: same templates,
+    bit-exact correspondences given the fixture's projected features, features within 1e-4."""
+    from foundpose_amd import corresp_util, feature_util, projector_util, repre_util
+    g = load_golden("hot_section_tiny")
+    S = int(g["image_size"])
+    ex = _extractor(TINY, "dinov2_version=tiny-reg_stride=14_facet=token_layer=2_logbin=0_norm=1", int(g["weights_seed"]), "fp32")
+    q_img = torch.from_numpy(g["q_img"]).unsqueeze(0).cuda()
+    fmap = ex(q_img)["feature_maps"][0]
+    scale = np.abs(g["fmap"]).max()
+    np.testing.assert_allclose(fmap.cpu().numpy(), g["fmap"], rtol=0, atol=1e-4 * scale)
+    grid = feature_util.generate_grid_points((S, S), 14.0).cuda()
+    qp = feature_util.filter_points_by_mask(grid, torch.from_numpy(g["tpl_masks"][4]).cuda())
+    assert np.array_equal(qp.cpu().numpy(), g["query_points"])
+    qf = feature_util.sample_feature_map_at_points(fmap, qp, (S, S)).contiguous()
+    np.testing.assert_allclose(qf.cpu().numpy(), g["query_features"], rtol=0, atol=1e-4 * scale)
+    proj = projector_util.projector_from_tensordict({"pca_projector": {
+        "components": torch.from_numpy(g["pca_components"]), "mean": torch.from_numpy(g["pca_mean"]), "whiten": torch.tensor(False)}})
+    qfp = projector_util.project_features(qf, [proj])
+    np.testing.assert_allclose(qfp.cpu().numpy(), g["query_features_proj"], rtol=0, atol=2e-4 * np.abs(g["query_features_proj"]).max())
+    repre = repre_util.FeatureBasedObjectRepre(
+        vertices=torch.from_numpy(g["vertices"]), feat_vectors=torch.from_numpy(g["bank_feats"]),
+        feat_to_template_ids=torch.from_numpy(g["f2t"]), feat_cluster_centroids=torch.from_numpy(g["centroids"]),
+        feat_cluster_idfs=torch.from_numpy(g["idfs"]), template_descs=torch.from_numpy(g["template_descs"]),
+        template_desc_opts=repre_util.TemplateDescOpts(), feat_raw_projectors=[proj])
+    corresp = corresp_util.establish_correspondences(qp, qfp, repre, "tfidf", "cyclic_buddies", 5, 300)
+    assert [int(c["template_id"]) for c in corresp] == list(g["template_ids"])
+    np.testing.assert_allclose([float(c["template_score"]) for c in corresp], g["template_scores"], rtol=0, atol=1e-4)
+    # with the fixture's own projected features the correspondence sets are identical (k == Q: no boundary ties)
+    corresp2 = corresp_util.establish_correspondences(
+        torch.from_numpy(g["query_points"]).cuda(), torch.from_numpy(g["query_features_proj"]).cuda(), repre, "tfidf", "cyclic_buddies", 5, 300)
+    for i, c in enumerate(corresp2):
+        a = dict(zip(c["coord_2d_ids"].cpu().tolist(), c["nn_vertex_ids"].cpu().tolist()))
+        b = dict(zip(g[f"coord_2d_ids_{i}"].tolist(), g[f"nn_vertex_ids_{i}"].tolist()))
+        assert a == b
