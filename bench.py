@@ -1,0 +1,213 @@
+#!/usr/bin/env python
+"""Headline benchmark: detections/sec (ViT + descriptor matching) on 518x518 crops against a 10k-template
+bank, one process per GPU.  Contract: see the task prompt / DESIGN.md "Measurement".
+
+  python bench.py                       # 1 GPU, finishes in a few minutes
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md chip table)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+
+
+def vit_flops_per_crop(arch, size, layer):
+    np_ = (size // arch.patch) ** 2
+    n = 1 + arch.registers + np_
+    blk = 24 * n * arch.dim ** 2 + 4 * n * n * arch.dim
+    return np_ * 3 * arch.patch ** 2 * arch.dim * 2 + (layer + 1) * blk
+
+
+def build_synthetic_bank(num_templates, feat_dim, raw_dim, num_words, seed, device):
+    """Planted-structure bank built with the device bank builder: P_t ~ U{300..450}."""
+    from foundpose_amd import bank_builder, projector_util, repre_util
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    counts = torch.randint(300, 451, (num_templates,), generator=g)
+    n_f = int(counts.sum())
+    gd = torch.Generator(device=device).manual_seed(seed)
+    sigma = torch.arange(1, feat_dim + 1, dtype=torch.float32, device=device) ** -0.5
+    feats = torch.randn(n_f, feat_dim, generator=gd, device=device) * sigma
+    verts = torch.randn(n_f, 3, generator=gd, device=device) * 50.0
+    f2t = torch.repeat_interleave(torch.arange(num_templates, dtype=torch.int32), counts).to(device)
+    words = feats[torch.randperm(n_f, generator=g)[:num_words].to(device)].clone()
+    opts = repre_util.TemplateDescOpts()
+    descs, idfs, f2c = bank_builder.calc_tfidf_descriptors(feats, f2t, words, num_templates, opts)
+    comps = torch.linalg.qr(torch.randn(raw_dim, feat_dim, generator=g))[0].T.contiguous()  # [feat_dim, raw_dim] orthonormal rows
+    proj = projector_util.projector_from_tensordict({"pca_projector": {
+        "components": comps, "mean": torch.randn(raw_dim, generator=g) * 0.1, "whiten": torch.tensor(False)}})
+    return repre_util.FeatureBasedObjectRepre(
+        vertices=verts, feat_vectors=feats, feat_to_template_ids=f2t, feat_to_cluster_ids=f2c,
+        feat_to_vertex_ids=torch.arange(n_f, dtype=torch.int32, device=device), feat_cluster_centroids=words,
+        feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj])
+
+
+def time_kernel(fn, iters=20):
+    """Average launch duration (ms) with HIP events on the stream the kernel runs on (torch's current stream)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=32, help="crops per GPU per step")
+    ap.add_argument("--templates", type=int, default=10000)
+    ap.add_argument("--version", default="vitl14-reg")
+    ap.add_argument("--layer", type=int, default=18)
+    ap.add_argument("--size", type=int, default=518)
+    ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-detections", type=int, default=3)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from foundpose_amd import engine as fe
+    from foundpose_amd import feature_util, ops, synthetic
+    from foundpose_amd.bank import DeviceBank
+    from foundpose_amd.vit_config import ARCHS
+
+    arch = ARCHS[args.version]
+    name = f"dinov2_version={args.version}_stride=14_facet=token_layer={args.layer}_norm=1"
+    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision).to(dev)
+    repre = build_synthetic_bank(args.templates, 256, arch.dim, 2048, seed=7, device=dev)
+    bank = DeviceBank([repre], device=dev)
+    eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300)
+
+    B = args.batch
+    images = synthetic.make_crops(B, args.size, seed=rank).to(dev)       # inputs resident in HBM before timing
+    masks = synthetic.make_disc_mask(args.size).unsqueeze(0).repeat(B, 1, 1).to(dev)
+
+    def step():
+        res = eng.infer_batch(images, masks)
+        rec = fe.pack_result(res)
+        return fe.gather_records(rec, world)   # the one exchange step (RCCL all-gather over xGMI)
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    det_per_s = world * B * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+
+    if rank == 0:
+        # ---- roofline of the dominant kernel: the fc1 GEMM (+bias+GELU) of a ViT block, M = B*tokens
+        n_tok = 1 + arch.registers + (args.size // 14) ** 2
+        M = (B * n_tok + 127) // 128 * 128
+        a = torch.randn(M, arch.dim, device=dev).to(torch.bfloat16)
+        w = (torch.randn(arch.hidden, arch.dim, device=dev) * 0.02).to(torch.bfloat16)
+        bias = torch.zeros(arch.hidden, device=dev)
+        h = torch.empty(M, arch.hidden, dtype=torch.bfloat16, device=dev)
+        ms = time_kernel(lambda: ops.gemm_bf16(a, w, bias, out=h, epilogue=1, m_valid=B * n_tok))
+        gemm_flops = 2.0 * B * n_tok * arch.dim * arch.hidden   # algorithmic: valid rows only
+        ach = gemm_flops / (ms * 1e-3) / 1e12
+        vit_tf = vit_flops_per_crop(arch, args.size, args.layer) * det_per_s / world / 1e12
+        # ---- HBM roofline of the bank-streaming retrieval kernel (template descriptors read once per batch)
+        from foundpose_amd._lib import call, ptr, stream
+        desc_n = ops.normalize_rows(torch.rand(B, 2048, device=dev))
+        seg = torch.tensor([0, B], dtype=torch.int32, device=dev)
+        nt = torch.full((B,), args.templates, dtype=torch.int32, device=dev)
+        sims = torch.empty(B, args.templates, device=dev)
+        sc, ids = torch.empty(B, 5, device=dev), torch.empty(B, 5, dtype=torch.int32, device=dev)
+        ms_knn = time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, B, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
+                                          1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), stream()))
+        knn_bytes = args.templates * 2048 * 4 + B * 2048 * 4 + B * args.templates * 4 * 2
+        result = {
+            "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",
+            "value": round(det_per_s, 2), "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic (seeded crops/masks, random-init ViT weights, planted-structure bank)",
+            "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block), "
+                                   f"{args.size}x{args.size} crops, batch {B}/GPU, 1 object x {args.templates} templates "
+                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}",
+                       "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step"},
+            "roofline": {"kernel": "gemm_bf16_kernel<GELU> (fc1 of one ViT block)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+                         "flops_per_launch": gemm_flops},
+            "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                                        "frac": round(vit_tf / PEAK_BF16_TFLOPS, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
+            "roofline_knn": {"kernel": "fp_cosine_topk (template-descriptor streaming + top-5)", "bound": "hbm", "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1),
+                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
+                             "bytes_per_launch": knn_bytes},
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(arch, args, repre, images, masks)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(arch, args, repre, images, masks):
+    """The oracle's reference-equivalent CPU path on the host cores, bounded sample of the same workload."""
+    from foundpose_amd import synthetic
+    from oracle import baseline
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    proj = repre.feat_raw_projectors[0]
+    bank = {
+        "feat_vectors": repre.feat_vectors.cpu(), "feat_to_template_ids": repre.feat_to_template_ids.cpu(),
+        "feat_cluster_centroids": repre.feat_cluster_centroids.cpu(), "feat_cluster_idfs": repre.feat_cluster_idfs.cpu(),
+        "template_descs": repre.template_descs.cpu(), "pca_components": proj.components.cpu(), "pca_mean": proj.mean.cpu(),
+    }
+    n = args.cpu_detections
+    imgs, msk = images[:n].cpu(), masks[:n].cpu()
+    baseline.run_detection(sd, arch, args.layer, imgs[0], msk[0], bank)  # warm-up (thread pools, page-in)
+    t0 = time.perf_counter()
+    stages = {}
+    for i in range(n):
+        t, _ = baseline.run_detection(sd, arch, args.layer, imgs[i], msk[i], bank)
+        for k, v in t.items():
+            stages[k] = stages.get(k, 0.0) + v / n
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 4), "unit": "detections/s", "cores": cores, "kind": "port",
+            "sample": f"{n} detections after 1 warm-up, batch of one, fp32 torch-CPU, all {arch.depth} blocks run like the reference",
+            "s_per_stage": {k: round(v, 4) for k, v in stages.items()}}
+
+
+if __name__ == "__main__":
+    main()

@@ -149,6 +149,15 @@ __global__ __launch_bounds__(256) void tfidf_build_kernel(
 }
 
 // ------------------------------------------------------------------ cyclic best buddies: select + gather
+// |u1 - u2|_2 exactly as separate fp32 mul/add + correctly rounded sqrt (no fma contraction), so the
+// heavily tied cycle distances compare bit-for-bit with the CPU.
+FP_DEVICE float point_dist(float x1, float y1, float x2, float y2) {
+#pragma clang fp contract(off)
+  const float dx = x1 - x2, dy = y1 - y2;
+  const float xx = dx * dx, yy = dy * dy;
+  return sqrtf(xx + yy);
+}
+
 __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   __shared__ unsigned long long keys[2048];
   __shared__ int q2o_s[2048];
@@ -170,10 +179,7 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
       const int o = (int)(rb[i] & 0xffffffffu);        // query -> nearest template patch
       const int c = (int)(cb[o] & 0xffffffffu);        // that patch -> nearest query patch
       q2o_s[i] = o;
-      const float dx = __fsub_rn(pts[2 * i], pts[2 * c]);
-      const float dy = __fsub_rn(pts[2 * i + 1], pts[2 * c + 1]);
-      const float d = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));  // no fma contraction
-      key = pack_dist_idx(d, (unsigned)i);
+      key = pack_dist_idx(point_dist(pts[2 * i], pts[2 * i + 1], pts[2 * c], pts[2 * c + 1]), (unsigned)i);
     }
     keys[i] = key;
   }
@@ -221,24 +227,42 @@ __global__ void sample_bilinear_kernel(SampleArgs a) {
   const int img = a.point_img ? a.point_img[p] : 0;
   const float px = a.points[2 * p], py = a.points[2 * p + 1];
   // uv = (2/size) * p - 1   (fp32, no fma: feature_util.py:119)
-  const float u = __fsub_rn(__fmul_rn(__fdiv_rn(2.0f, (float)a.img_w), px), 1.0f);
-  const float v = __fsub_rn(__fmul_rn(__fdiv_rn(2.0f, (float)a.img_h), py), 1.0f);
-  // grid_sample unnormalise, align_corners=False: ((c + 1) * size - 1) / 2
-  const float ix = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(u, 1.f), (float)a.W), 1.f), 2.f);
-  const float iy = __fdiv_rn(__fsub_rn(__fmul_rn(__fadd_rn(v, 1.f), (float)a.H), 1.f), 2.f);
+  // Rounding sequence of torch's CPU grid_sampler (vectorised kernel, fma-contracted), verified
+  // bit-for-bit against torch on the fixtures:  uv = (2/size)*p - 1 (separate mul, sub);
+  // ix = fma(u + 1, W/2, -0.5);  w = ix - floor(ix), e = 1 - w;  out = fma chain over nw, ne, sw, se.
+  float ix, iy;
+  {
+#pragma clang fp contract(off)
+    const float sx = 2.0f / (float)a.img_w, sy = 2.0f / (float)a.img_h;
+    const float ux = sx * px, uy = sy * py;
+    const float u1 = (ux - 1.0f) + 1.0f, v1 = (uy - 1.0f) + 1.0f;
+    ix = fmaf(u1, (float)a.W / 2.f, -0.5f);
+    iy = fmaf(v1, (float)a.H / 2.f, -0.5f);
+  }
   const float fx = floorf(ix), fy = floorf(iy);
   const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
-  const float wx1 = ix - fx, wx0 = (fx + 1.f) - ix, wy1 = iy - fy, wy0 = (fy + 1.f) - iy;
-  const float w_nw = wx0 * wy0, w_ne = wx1 * wy0, w_sw = wx0 * wy1, w_se = wx1 * wy1;
+  float w_nw, w_ne, w_sw, w_se;
+  {
+#pragma clang fp contract(off)
+    const float w = ix - fx, e = 1.f - w, n = iy - fy, s_ = 1.f - n;
+    w_nw = s_ * e; w_ne = s_ * w; w_sw = n * e; w_se = n * w;
+  }
   const bool vx0 = x0 >= 0 && x0 < a.W, vx1 = x1 >= 0 && x1 < a.W, vy0 = y0 >= 0 && y0 < a.H, vy1 = y1 >= 0 && y1 < a.H;
   const float* base = a.fmap + (size_t)img * a.stride_img;
   for (int c = lane; c < a.C; c += 64) {
     const float* bc = base + (size_t)c * a.stride_c;
-    float acc = 0.f;
-    if (vx0 && vy0) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y0 * a.stride_h + (size_t)x0 * a.stride_w], w_nw));
-    if (vx1 && vy0) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y0 * a.stride_h + (size_t)x1 * a.stride_w], w_ne));
-    if (vx0 && vy1) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y1 * a.stride_h + (size_t)x0 * a.stride_w], w_sw));
-    if (vx1 && vy1) acc = __fadd_rn(acc, __fmul_rn(bc[(size_t)y1 * a.stride_h + (size_t)x1 * a.stride_w], w_se));
+    const float v_nw = (vx0 && vy0) ? bc[(size_t)y0 * a.stride_h + (size_t)x0 * a.stride_w] : 0.f;
+    const float v_ne = (vx1 && vy0) ? bc[(size_t)y0 * a.stride_h + (size_t)x1 * a.stride_w] : 0.f;
+    const float v_sw = (vx0 && vy1) ? bc[(size_t)y1 * a.stride_h + (size_t)x0 * a.stride_w] : 0.f;
+    const float v_se = (vx1 && vy1) ? bc[(size_t)y1 * a.stride_h + (size_t)x1 * a.stride_w] : 0.f;
+    float acc;
+    {
+#pragma clang fp contract(off)
+      acc = v_nw * w_nw;
+    }
+    acc = fmaf(v_ne, w_ne, acc);
+    acc = fmaf(v_sw, w_sw, acc);
+    acc = fmaf(v_se, w_se, acc);
     a.out[(size_t)p * a.C + c] = acc;
   }
 }

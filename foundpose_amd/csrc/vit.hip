@@ -69,7 +69,7 @@ __global__ void patchify_kernel(const float* __restrict__ img, int B, int H, int
     const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
     const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
     const float x = img[(((size_t)b * 3 + c) * H + gy * P + py) * W + gx * P + px];
-    v = __fdiv_rn(__fsub_rn(x, mean), stdv);
+    v = (x - mean) / stdv;  // T.Normalize: sub then div (correctly rounded fp32 division)
   }
   out[e] = (T)v;
 }

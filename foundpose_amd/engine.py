@@ -1,0 +1,110 @@
+"""Batched per-detection inference: crops + masks -> 2D-3D correspondences, entirely in HBM.
+
+The batched form of the hot section of the reference driver (/root/reference/scripts/infer.py:468-542),
+which handles one detection at a time: extractor forward -> mask-filtered grid points -> bilinear feature
+sampling -> PCA projection -> establish_correspondences. Detections are independent units, so a node
+shards them across its GPUs (one process per GPU) and gathers fixed-size result records at the end.
+"""
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import feature_util, ops
+from .bank import DeviceBank
+from .dinov2_utils import DinoFeatureExtractor
+from .matching import MatchResult, match_batch
+
+
+class FoundPoseEngine:
+    def __init__(self, extractor: DinoFeatureExtractor, bank: DeviceBank, grid_cell_size: float = 14.0,
+                 top_n_templates: int = 5, top_k_buddies: int = 300) -> None:
+        self.extractor, self.bank = extractor, bank
+        self.cell = grid_cell_size
+        self.top_n, self.top_k = top_n_templates, top_k_buddies
+        self._grids = {}
+
+    def _grid(self, w: int, h: int, device):
+        key = (w, h)
+        if key not in self._grids:
+            pts = feature_util.generate_grid_points((w, h), self.cell).to(device)
+            pix = (pts + 0.5).int()
+            inside = (pix[:, 0] > 0) & (pix[:, 0] < w) & (pix[:, 1] > 0) & (pix[:, 1] < h)
+            self._grids[key] = (pts, pix[:, 0].long(), pix[:, 1].long(), inside)
+        return self._grids[key]
+
+    def query_points(self, masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
+        """filter_points_by_mask for the whole batch -> (points [sumQ,2], point_img [sumQ] i32, counts)."""
+        B, H, W = masks.shape
+        pts, xi, yi, inside = self._grid(W, H, masks.device)
+        on = (masks[:, yi, xi] != 0) & inside[None, :]
+        idx = on.nonzero()  # row-major: grouped by detection, grid order inside (like the reference)
+        counts = on.sum(1).tolist()  # the only host sync of a batch; done before the ViT is enqueued
+        return pts[idx[:, 1]].contiguous(), idx[:, 0].to(torch.int32).contiguous(), counts
+
+    def infer_batch(self, images: torch.Tensor, masks: torch.Tensor, det_obj: Optional[Sequence[int]] = None,
+                    keep_debug: bool = False) -> MatchResult:
+        B, _, H, W = images.shape
+        det_obj = [0] * B if det_obj is None else list(det_obj)
+        q_pts, q_img, counts = self.query_points(masks)
+        fmap, _ = self.extractor.forward_tokens(images)
+        gh, gw = self.extractor.num_patches
+        D = fmap.shape[-1]
+        raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
+        feats = self._project(raw, counts, det_obj)
+        return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug)
+
+    def _project(self, raw: torch.Tensor, counts: Sequence[int], det_obj: Sequence[int]) -> torch.Tensor:
+        if raw.shape[1] == self.bank.feat_dim:
+            return raw
+        out = torch.empty(raw.shape[0], self.bank.feat_dim, dtype=torch.float32, device=raw.device)
+        r0 = 0
+        i = 0
+        while i < len(counts):
+            j = i
+            n = 0
+            while j < len(counts) and det_obj[j] == det_obj[i]:
+                n += counts[j]
+                j += 1
+            x = raw[r0:r0 + n]
+            projs = self.bank.objects[det_obj[i]].projectors
+            if not projs:
+                raise ValueError("feature dims differ from the bank and the object has no projector")
+            for p in projs:
+                x = p.transform(x)
+            out[r0:r0 + n] = x
+            r0 += n
+            i = j
+        return out
+
+
+RECORD_FLOATS_PER_CORRESP = 9  # q_id, feat_id, dist, conf, x, y, X, Y, Z
+
+
+def pack_result(res: MatchResult) -> torch.Tensor:
+    """Fixed-size fp32 record per detection for the final gather: [B, n*(3 + K*9)]
+    (template id, score, count, then K padded correspondences per template). Integer ids < 2^24 are exact in fp32."""
+    B, n, K = res.q_ids.shape
+    head = torch.stack([res.template_ids.float(), res.template_scores, res.counts.float()], -1)  # [B,n,3]
+    body = torch.cat([res.q_ids.float().unsqueeze(-1), res.feat_ids.float().unsqueeze(-1), res.dists.unsqueeze(-1),
+                      res.conf.unsqueeze(-1), res.coord_2d, res.coord_3d], -1)  # [B,n,K,9]
+    return torch.cat([head, body.reshape(B, n, K * RECORD_FLOATS_PER_CORRESP)], -1).reshape(B, -1).contiguous()
+
+
+def shard_detections(num_det: int, world_size: int, rank: int) -> Tuple[int, int]:
+    """Contiguous shard [lo, hi) of the detection list for `rank` (detections are pre-sorted by object, so
+    contiguous chunks keep each rank's bank accesses on few objects)."""
+    base, rem = divmod(num_det, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_records(local: torch.Tensor, world_size: int) -> torch.Tensor:
+    """The one exchange step of the path: all-gather of the per-detection records over RCCL (xGMI).
+    Every rank contributes the same number of rows (the driver pads the tail shard)."""
+    if world_size == 1:
+        return local
+    import torch.distributed as dist
+    out = torch.empty(world_size * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out
