@@ -185,7 +185,9 @@ def cpu_baseline(arch, args, repre, images, masks):
     """The oracle's reference-equivalent CPU path on the host cores, bounded sample of the same workload."""
     from foundpose_amd import synthetic
     from oracle import baseline
-    cores = os.cpu_count() or 1
+    # torch-CPU on ViT-sized matrices stops scaling (and regresses) far below the 256 hardware threads of the
+    # GPU box's host; 32 threads is what the reference's own defaults would be tuned to on such a machine.
+    cores = min(os.cpu_count() or 1, int(os.environ.get("FP_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(cores)
     sd = synthetic.make_vit_state_dict(arch, seed=1234)
     proj = repre.feat_raw_projectors[0]
@@ -196,7 +198,10 @@ def cpu_baseline(arch, args, repre, images, masks):
     }
     n = args.cpu_detections
     imgs, msk = images[:n].cpu(), masks[:n].cpu()
+    tw = time.perf_counter()
     baseline.run_detection(sd, arch, args.layer, imgs[0], msk[0], bank)  # warm-up (thread pools, page-in)
+    if time.perf_counter() - tw > 15.0:
+        n = 1  # keep the default bench run within a few minutes on slow hosts
     t0 = time.perf_counter()
     stages = {}
     for i in range(n):
@@ -205,7 +210,7 @@ def cpu_baseline(arch, args, repre, images, masks):
             stages[k] = stages.get(k, 0.0) + v / n
     dt = time.perf_counter() - t0
     return {"value": round(n / dt, 4), "unit": "detections/s", "cores": cores, "kind": "port",
-            "sample": f"{n} detections after 1 warm-up, batch of one, fp32 torch-CPU, all {arch.depth} blocks run like the reference",
+            "sample": f"{n} detection(s) after 1 warm-up, batch of one, fp32 torch-CPU on {cores} threads, all {arch.depth} blocks run like the reference",
             "s_per_stage": {k: round(v, 4) for k, v in stages.items()}}
 
 
