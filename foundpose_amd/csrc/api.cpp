@@ -3,6 +3,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 
 #include "../../include/foundpose_amd.h"
 #include "common.hpp"
@@ -92,6 +93,14 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
              "fp_cosine_topk: null pointer");
   FP_REQUIRE(num_obj >= 1 && max_templates >= 1 && n_top >= 1, "fp_cosine_topk: bad sizes");
   if (num_det == 0) return FP_OK;
+  if (num_words % 16 == 0 && max_det_per_obj <= 64 && n_top <= 8) {  // bank-streaming path (HBM-bound)
+    CosineArgs c;
+    c.desc_n = desc_n; c.bank_n = bank_n; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
+    c.sims = scratch_sims; c.ld_sims = max_templates;
+    return launch_cosine_topk(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores,
+                              out_ids, ST(stream));
+  }
+  // generic tile path (k-ascending chains): odd descriptor sizes or very large groups
   F32TileArgs a = zero_tile_args();
   a.A = desc_n; a.lda = num_words; a.B = bank_n; a.ldb = num_words; a.K = num_words;
   a.a_seg_off = det_seg_off; a.b_seg_off = obj_tpl_off;
@@ -180,6 +189,10 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_bf16: null pointer");
+  const int tile = (epilogue >> 8) & 0xfff;  // tuning bits: force the 128 or 256 block tile
+  const int pipe = (epilogue >> 20) & 0xf;   // tuning bits: 1 = double-buffered BK=64 main loop
+  epilogue &= 0xff;
+  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384 || tile == 385, "fp_gemm_bf16: bad tile override %d", tile);
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
                  epilogue == GEMM_EPI_BIAS_F32,
              "fp_gemm_bf16: epilogue %d is not available through this entry point", epilogue);
@@ -188,6 +201,9 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
+  a.tile_override = tile;
+  a.pipe_override = pipe;
+  a.dbg = reinterpret_cast<unsigned long long*>(getenv("FP_GEMM_DBG_PTR") ? strtoull(getenv("FP_GEMM_DBG_PTR"), nullptr, 0) : 0ull);
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }
 

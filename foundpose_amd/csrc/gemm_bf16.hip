@@ -16,96 +16,230 @@
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;  // 16 KiB per operand per stage
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 FP_DEVICE int swz(int row) { return (row >> 1) & 7; }
 
-// Issue the DMA of one 128x64 bf16 tile (rows row0.., k0..k0+63) into `lds` (byte offset base).
-FP_DEVICE void stage_tile(const __bf16* __restrict__ g, int ld, int row0, int k0, char* lds, int wave, int lane) {
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int rblk = wave * 4 + i;            // 8-row group handled by this instruction
-    const int row = rblk * 8 + (lane >> 3);
-    const int chunk = (lane & 7) ^ swz(row);  // logical 16-B chunk that must land at physical slot lane&7
-    const __bf16* src = g + (size_t)(row0 + row) * ld + k0 + chunk * 8;
-    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds + rblk * 1024), 16, 0, 0);
-  }
+// One DMA instruction: 8 rows x 64 bf16 (1 KiB) of a tile, row group `rblk`, into the lane-linear LDS image.
+FP_DEVICE void stage_rows(const __bf16* __restrict__ g, int ld, int row0, int k0, char* lds, int rblk, int lane) {
+  const int row = rblk * 8 + (lane >> 3);
+  const int chunk = (lane & 7) ^ swz(row);  // logical 16-B chunk that must land at physical slot lane&7
+  const __bf16* src = g + (size_t)(row0 + row) * ld + k0 + chunk * 8;
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds + rblk * 1024), 16, 0, 0);
 }
 
 FP_DEVICE bf16x8 read_frag(const char* lds, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
 }
 
-FP_DEVICE float gelu_erf(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752440f)); }
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) with erf from Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, far below the
+// bf16 rounding of the output): one v_rcp, one v_exp and a 5-term Horner chain instead of libm's branchy erff.
+FP_DEVICE float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+  const float erf_abs = 1.f - p * t * e;
+  return 0.5f * x * (1.f + copysignf(erf_abs, x));
+}
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+// BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32.
+// 16 rows x 32 bf16 (1 KiB) of a BK=32 sub-tile; swizzle (row>>2)&3 over the 4 chunks of a 64-B row.
+FP_DEVICE void stage_rows32(const __bf16* __restrict__ g, int ld, int row0, int k0, char* lds, int rblk, int lane) {
+  const int row = rblk * 16 + (lane >> 2);
+  const int chunk = (lane & 3) ^ ((row >> 2) & 3);
+  const __bf16* src = g + (size_t)(row0 + row) * ld + k0 + chunk * 8;
+  __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds + rblk * 1024), 16, 0, 0);
+}
+FP_DEVICE bf16x8 read_frag32(const char* lds, int row, int chunk) {
+  return *reinterpret_cast<const bf16x8*>(lds + row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4));
+}
+
+template <int EPI, int BM, int BN, int WM, int WN, int PIPE>
+__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a) {
+  constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile
+  static_assert(A_INSTR % 4 == 0 && B_INSTR % 4 == 0 || (A_INSTR + B_INSTR) % 4 == 0, "staging split");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, kh = lane >> 5;
+  const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, kh = lane >> 5;
 
   const unsigned tiles_n = a.N / BN;
   const unsigned nwg = gridDim.x;
   const unsigned lid = xcd_remap(blockIdx.x, nwg);
   const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
 
-  f32x16 acc[2][2];
+  f32x16 acc[TM][TN];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+  unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
+  if (a.dbg) ts0 = __builtin_readcyclecounter();
+  if constexpr (PIPE == 0) {
+  // DMA piece q (0 .. A_INSTR+B_INSTR-1) of this wave for K-tile k0 into stage buffer `buf`
+  auto stage_piece = [&](int q, int k0, char* buf) {
+    if (q < A_INSTR) stage_rows(a.A, a.lda, m0, k0, buf, wave * A_INSTR + q, lane);
+    else stage_rows(a.W, a.ldw, n0, k0, buf + A_BYTES, wave * B_INSTR + (q - A_INSTR), lane);
+  };
+  constexpr int PIECES = A_INSTR + B_INSTR, PER_KS = PIECES / 4;
+
   const int nk = a.K / BK;
-  stage_tile(a.A, a.lda, m0, 0, smem, wave, lane);
-  stage_tile(a.W, a.ldw, n0, 0, smem + TILE_BYTES, wave, lane);
+#pragma unroll
+  for (int q = 0; q < PIECES; ++q) stage_piece(q, 0, smem);
 
   for (int t = 0; t < nk; ++t) {
     const int cur = t & 1;
     __syncthreads();  // drains the DMA of tile t (vmcnt(0)) and fences the readers of the other stage
-    if (t + 1 < nk) {
-      char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-      stage_tile(a.A, a.lda, m0, (t + 1) * BK, nxt, wave, lane);
-      stage_tile(a.W, a.ldw, n0, (t + 1) * BK, nxt + TILE_BYTES, wave, lane);
-    }
-    const char* As = smem + cur * 2 * TILE_BYTES;
-    const char* Ws = As + TILE_BYTES;
+    if (a.dbg && t == 0) ts1 = __builtin_readcyclecounter();
+    char* nxt = smem + (cur ^ 1) * STAGE;
+    const bool more = t + 1 < nk;
+    const char* As = smem + cur * STAGE;
+    const char* Ws = As + A_BYTES;
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
+      // next tile's DMA is issued in four slices, one ahead of each k-step's MFMAs
+      if (more) {
+#pragma unroll
+        for (int q = 0; q < PER_KS; ++q) stage_piece(ks * PER_KS + q, (t + 1) * BK, nxt);
+      }
       const int chunk = ks * 2 + kh;
-      bf16x8 af0 = read_frag(As, wm * 64 + l31, chunk);
-      bf16x8 af1 = read_frag(As, wm * 64 + 32 + l31, chunk);
-      bf16x8 wf0 = read_frag(Ws, wn * 64 + l31, chunk);
-      bf16x8 wf1 = read_frag(Ws, wn * 64 + 32 + l31, chunk);
+      bf16x8 af[TM], wf[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[j] = read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
       // swapped operands: D[i = n][j = m]
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, af0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, af0, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf0, af1, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf1, af1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
     }
   }
 
+  } else if constexpr (PIPE == 2) {
+    // ---- double-buffered BK=64 with the fragment reads software-pipelined one k-step ahead ACROSS the tile
+    // boundary: the per-tile barrier (and the first LDS reads of the next tile) sit in front of the last
+    // k-step's MFMAs of the current tile, so the barrier bubble is covered by matrix work.
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW;
+    constexpr int STG = (BM + BN) * BK * 2;
+    const int nk = a.K / BK;
+    auto issue_tile = [&](int t) {
+      char* buf = smem + (t & 1) * STG;
+#pragma unroll
+      for (int q = 0; q < A_I; ++q) stage_rows(a.A, a.lda, m0, t * BK, buf, wave * A_I + q, lane);
+#pragma unroll
+      for (int q = 0; q < B_I; ++q) stage_rows(a.W, a.ldw, n0, t * BK, buf + BM * BK * 2, wave * B_I + q, lane);
+    };
+    bf16x8 af[2][TM], wf[2][TN];
+    auto read_frags = [&](int slot, const char* As, int ks) {
+      const char* Ws = As + BM * BK * 2;
+      const int chunk = ks * 2 + kh;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[slot][i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) wf[slot][j] = read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
+    };
+    issue_tile(0);
+    if (nk > 1) issue_tile(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_I + B_I) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, smem, 0);
+    for (int t = 0; t < nk; ++t) {
+      const char* As = smem + (t & 1) * STG;
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cs = ks & 1;
+        if (ks < 3) {
+          read_frags(cs ^ 1, As, ks + 1);
+        } else if (t + 1 < nk) {
+          __syncthreads();  // tile t+1 landed; every wave's reads of tile t have completed
+          if (t + 2 < nk) issue_tile(t + 2);
+          read_frags(cs ^ 1, smem + ((t + 1) & 1) * STG, 0);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[cs][j], af[cs][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
+  } else {
+    constexpr int DEPTH = PIPE == 3 ? 2 : 4, DIST = DEPTH - 1;
+    // ---- DEPTH-deep ring of BK=32 sub-stages, DMA issued 3 sub-stages ahead, counted vmcnt + raw s_barrier:
+    // HBM/L2 latency is covered by ~3 sub-stages of MFMA work instead of one K-tile (guide section 5 T3+T4).
+    constexpr int SA = BM * 64, SB = BN * 64, SUB = SA + SB;          // bytes per sub-stage
+    constexpr int AI = BM / 16 / NW, BI = BN / 16 / NW;               // DMA instructions per wave per sub-stage
+    static_assert(AI >= 1 && BI >= 1, "tile too small for the wave count");
+    const int ns = a.K / 32;
+    auto issue = [&](int sidx) {
+      char* buf = smem + (sidx % DEPTH) * SUB;
+#pragma unroll
+      for (int q = 0; q < AI; ++q) stage_rows32(a.A, a.lda, m0, sidx * 32, buf, wave * AI + q, lane);
+#pragma unroll
+      for (int q = 0; q < BI; ++q) stage_rows32(a.W, a.ldw, n0, sidx * 32, buf + SA, wave * BI + q, lane);
+    };
+#pragma unroll
+    for (int i = 0; i < DIST; ++i)
+      if (i < ns) issue(i);
+    for (int sidx = 0; sidx < ns; ++sidx) {
+      // wait until this wave's pieces of sub-stage `sidx` have landed (younger groups stay in flight)
+      const int younger = min(DIST - 1, ns - 1 - sidx);
+      if (DIST >= 3 && younger == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (AI + BI)) : "memory");
+      else if (DIST >= 2 && younger == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(AI + BI) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // everyone's pieces landed; everyone is done reading slot (sidx-1)&3
+      if (sidx + DIST < ns) issue(sidx + DIST);
+      const char* As = smem + (sidx % DEPTH) * SUB;
+      const char* Ws = As + SA;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int chunk = ks * 2 + kh;
+        bf16x8 af[TM], wf[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = read_frag32(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[j] = read_frag32(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    }
+  }
+
+  if (a.dbg) ts2 = __builtin_readcyclecounter();
   // ---- epilogue: acc[tm][tn][r] = C[m][n],  m = m0 + wm*64 + tm*32 + (lane&31),
   //      n = n0 + wn*64 + tn*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
   // Column-only operands are fetched once, row operands in one batch per tm, so the tail is a
   // few waits instead of one per access.
-  float4 bias[2][4], gam[2][4];
+  float4 bias[TN][4], gam[TN][4];
 #pragma unroll
-  for (int tn = 0; tn < 2; ++tn)
+  for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int n = n0 + wn * 64 + tn * 32 + 8 * g + 4 * kh;
+      const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
       bias[tn][g] = *reinterpret_cast<const float4*>(a.bias + n);
       if constexpr (EPI == GEMM_EPI_LS_RESID_F32) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
     }
 #pragma unroll
-  for (int tm = 0; tm < 2; ++tm) {
-    const int m = m0 + wm * 64 + tm * 32 + l31;
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
     if (m >= a.M_valid) continue;
     size_t out_row = m;
     int vb = 0, vt = 0, pidx = 0;
@@ -118,13 +252,13 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
       vb = m / a.tok_n;
       vt = m - vb * a.tok_n;
     }
-    float4 extra[2][4];  // residual row (LS_RESID) or pos-embed row (TOKENS)
+    float4 extra[TN][4];  // residual row (LS_RESID) or pos-embed row (TOKENS)
     if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32) {
 #pragma unroll
-      for (int tn = 0; tn < 2; ++tn)
+      for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const int n = n0 + wn * 64 + tn * 32 + 8 * g + 4 * kh;
+          const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
           if constexpr (EPI == GEMM_EPI_LS_RESID_F32)
             extra[tn][g] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + out_row * a.ldo + n);
           else
@@ -132,10 +266,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
         }
     }
 #pragma unroll
-    for (int tn = 0; tn < 2; ++tn)
+    for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int n = n0 + wn * 64 + tn * 32 + 8 * g + 4 * kh;
+        const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
         const float4 bs = bias[tn][g];
         float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
         float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
@@ -171,27 +305,57 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmBf16Args a) {
         }
       }
   }
+  if (a.dbg) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long ts3 = __builtin_readcyclecounter();
+    if (tid == 0) {
+      unsigned long long* d = a.dbg + (size_t)blockIdx.x * 4;
+      d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
+    }
+  }
 }
 
-template <int EPI>
-int launch(const GemmBf16Args& a, hipStream_t st) {
+template <int EPI, int BM, int BN, int WM, int WN, int PIPE>
+int launch_cfg(const GemmBf16Args& a, hipStream_t st) {
   const unsigned grid = (a.M / BM) * (a.N / BN);
-  const size_t lds = 4 * TILE_BYTES;
+  const size_t lds = PIPE == 3 ? (size_t)(BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * 2;  // 2 x BK=64 stages == 4 x BK=32 sub-stages; PIPE 3: 2 sub-stages
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIPE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3(grid), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIPE>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
+}
+
+// Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
+// otherwise 128x128 (4 waves, 2 blocks/CU).
+template <int EPI>
+int launch(const GemmBf16Args& a, hipStream_t st) {
+  const int force = a.tile_override;
+  const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
+  const bool use_big = force == 256 || (force == 0 && big_ok && (a.M / 256) * (a.N / 256) >= 256);
+  // pipe_override: 0 = default (double buffer, measured best), 1 = same, 2 = ring of BK=32 sub-stages, 3 = software-pipelined
+  const int pv = a.pipe_override == 2 ? 1 : (a.pipe_override == 3 ? 2 : 0);
+  if (use_big && big_ok) {
+    if (pv == 0) return launch_cfg<EPI, 256, 256, 2, 4, 0>(a, st);
+    if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);
+    return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, st);
+  }
+  if (force == 384 && a.N % 256 == 0) return launch_cfg<EPI, 128, 256, 2, 2, 3>(a, st);  // 128x256, 4 waves, 48 KiB: 2 blocks/CU
+  if (force == 385 && a.N % 256 == 0 && a.M % 256 == 0) return launch_cfg<EPI, 256, 256, 2, 4, 3>(a, st);  // 256x256 with a 2-deep BK=32 ring (64 KiB): 2 blocks/CU
+  if (pv == 0) return launch_cfg<EPI, 128, 128, 2, 2, 0>(a, st);
+  if (pv == 1) return launch_cfg<EPI, 128, 128, 2, 2, 1>(a, st);
+  return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, st);
 }
 
 }  // namespace
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
-  FP_REQUIRE(a.M > 0 && a.M % BM == 0, "gemm_bf16: M (%d) must be a positive multiple of %d (pad the activation buffer)", a.M, BM);
-  FP_REQUIRE(a.N > 0 && a.N % BN == 0, "gemm_bf16: N (%d) must be a multiple of %d", a.N, BN);
+  FP_REQUIRE(a.M > 0 && a.M % 128 == 0, "gemm_bf16: M (%d) must be a positive multiple of 128 (pad the activation buffer)", a.M);
+  FP_REQUIRE(a.N > 0 && a.N % 128 == 0, "gemm_bf16: N (%d) must be a multiple of 128", a.N);
   FP_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm_bf16: K (%d) must be a multiple of %d", a.K, BK);
   FP_REQUIRE(a.bias != nullptr, "gemm_bf16: bias is required (pass zeros)");
   FP_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldo % 4 == 0, "gemm_bf16: leading dims must keep 16-byte alignment");

@@ -91,6 +91,9 @@ struct GemmBf16Args {
   const float* pos;           // [Np, ldo] fp32 pos-embed rows of the patch tokens
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
   __bf16* vt; int vt_ld; int vit_dim;
+  int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
+  unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
+  int pipe_override;          // 0 = default (ring of BK=32 sub-stages), 1 = double-buffered BK=64
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
@@ -123,3 +126,14 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
 int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
 int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st);
+
+struct CosineArgs {
+  const float* desc_n;  // [num_det, W] normalised query descriptors, grouped by object
+  const float* bank_n;  // [T_total, W] normalised template descriptors
+  const int* det_seg_off;  // [num_obj + 1]
+  const int* obj_tpl_off;  // [num_obj + 1]
+  int W;
+  float* sims; int ld_sims;  // [num_det, ld_sims]
+};
+int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+                       const int* det_num_templates, float* out_scores, int* out_ids, hipStream_t st);

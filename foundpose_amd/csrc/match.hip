@@ -83,6 +83,147 @@ __global__ void topk_rows_kernel(const float* __restrict__ vals, int rows, int n
   }
 }
 
+// ------------------------------------------------------------------ template retrieval: bank-streaming cosine scores
+// sims[det][t] = <bank_n[t,:], q_n[det,:]> for every template t of the detection's object.
+// HBM-bound by design: each wave owns 16 template rows and streams them ONCE, straight from HBM into registers
+// (16 B per lane, no LDS: the rows are not shared between waves), against all <= 64 detections of the object
+// (query rows come from L2).  v_mfma_f32_16x16x4_f32: A = 16 templates x 4 k, B = 4 k x 16 detections.
+// A lane's float4 covers k = 16j + 4g .. +3 (g = lane>>4), so MFMA step u consumes k = 16j + 4g' + u, g' = 0..3:
+// the per-(template, detection) fp32 fma chain visits each 16-block of k in the order
+// [0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15] -- the canonical order of this stage (oracle: orc_dot_rows_perm16).
+template <int NQ, int U>
+FP_DEVICE void cos_load(f32x4 (&av)[U], float4 (&bv)[NQ][U], const float* ap, const float* const (&bp)[NQ], int chunk) {
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    av[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 16 * (chunk * U + u)));  // streamed once
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) bv[q][u] = *reinterpret_cast<const float4*>(bp[q] + 16 * (chunk * U + u));
+  }
+}
+template <int NQ, int U>
+FP_DEVICE void cos_mma(f32x4 (&acc)[NQ], const f32x4 (&av)[U], const float4 (&bv)[NQ][U]) {
+  // accumulators alternate between consecutive MFMAs: the 40-cycle dependent latency of 16x16x4 f32 hides behind
+  // the other detection groups' instructions (32-cycle issue)
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[q][u].x, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[q][u].y, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[q][u].z, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[q][u].w, acc[q], 0, 0, 0);
+  }
+}
+
+template <int NQ>
+__global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int obj = blockIdx.y;
+  const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
+  const int d0 = a.det_seg_off[obj], nd = a.det_seg_off[obj + 1] - d0;
+  const int t0 = (blockIdx.x * 4 + wave) * 16;
+  if (t0 >= T || nd <= 0) return;
+  const int i = lane & 15, g = lane >> 4;
+  const int trow = min(t0 + i, T - 1);
+  const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + 4 * g;
+  const float* bp[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) bp[q] = a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + 4 * g;
+  f32x4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nb = a.W / 16;
+  // Software pipeline: chunks of U 16-blocks; chunk c+1's loads are in flight while chunk c's MFMAs run
+  // (a wave keeps 2 x U KiB of the bank stream outstanding -- what it takes to pull HBM bandwidth without LDS).
+  constexpr int U = 8;
+  f32x4 a0[U], a1[U];
+  float4 b0[NQ][U], b1[NQ][U];
+  const int nch = nb / U;
+  if (nch > 0) cos_load<NQ, U>(a0, b0, ap, bp, 0);
+  for (int c = 0; c < nch; c += 2) {
+    if (c + 1 < nch) cos_load<NQ, U>(a1, b1, ap, bp, c + 1);
+    cos_mma<NQ, U>(acc, a0, b0);
+    if (c + 2 < nch) cos_load<NQ, U>(a0, b0, ap, bp, c + 2);
+    if (c + 1 < nch) cos_mma<NQ, U>(acc, a1, b1);
+  }
+  for (int j = nch * U; j < nb; ++j) {  // remainder blocks (W not a multiple of 128)
+    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const float4 bv = *reinterpret_cast<const float4*>(bp[q] + 16 * j);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv.x, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv.y, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv.z, acc[q], 0, 0, 0);
+      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv.w, acc[q], 0, 0, 0);
+    }
+  }
+  // D[i = template 4g + r][j = detection lane&15]
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int det = q * 16 + i;
+    if (det >= nd) continue;
+    float* o = a.sims + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (t0 + 4 * g + r < T) o[r] = acc[q][r];
+  }
+}
+
+// Canonical top-n of each row (largest first, ties -> lowest index), one 256-thread block per row:
+// per-thread top-n over a strided slice (registers), then n rounds of block-wide arg-best over the candidates.
+template <int NMAX>
+__global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                              int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  __shared__ unsigned long long cand[256 * NMAX];
+  __shared__ unsigned long long wbest[4];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int len = row_len ? row_len[row] : n_default;
+  const float* r = vals + (size_t)row * ld;
+  unsigned long long best[NMAX];
+#pragma unroll
+  for (int s = 0; s < NMAX; ++s) best[s] = ~0ull;
+  for (int j = tid; j < len; j += 256) {
+    unsigned long long key = ((unsigned long long)order_key(r[j], true) << 32) | (unsigned)j;
+#pragma unroll
+    for (int s = 0; s < NMAX; ++s) {  // sorted insertion (ascending keys = best first)
+      const unsigned long long lo = key < best[s] ? key : best[s];
+      key = key < best[s] ? best[s] : key;
+      best[s] = lo;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NMAX; ++s) cand[tid * NMAX + s] = best[s];
+  __syncthreads();
+  unsigned long long prev = 0;
+  for (int s = 0; s < n_top; ++s) {
+    unsigned long long b = ~0ull;
+    for (int c = tid; c < 256 * NMAX; c += 256) {
+      const unsigned long long k = cand[c];
+      if ((s == 0 || k > prev) && k < b) b = k;
+    }
+    b = wave_min_u64(b);
+    if (lane == 0) wbest[wave] = b;
+    __syncthreads();
+    b = wbest[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) b = wbest[w] < b ? wbest[w] : b;
+    if (tid == 0) {
+      if (b != ~0ull) {
+        const int j = (int)(b & 0xffffffffu);
+        out_idx[(size_t)row * n_top + s] = j;
+        out_val[(size_t)row * n_top + s] = r[j];
+      } else {
+        out_idx[(size_t)row * n_top + s] = -1;
+        out_val[(size_t)row * n_top + s] = -INFINITY;
+      }
+    }
+    prev = b;
+    __syncthreads();
+  }
+}
+
 // ------------------------------------------------------------------ tf-idf descriptor per detection
 // One block (256 threads) per segment (a detection's query patches, or a template's patches on the
 // bank-builder side). Thread t owns the bins with (id & 255) == t and walks the (q, j) entries in
@@ -351,5 +492,22 @@ int launch_unpack_best(const unsigned long long* best, long long n, float* d2, i
   if (n == 0) return FP_OK;
   hipLaunchKernelGGL(unpack_best_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, best, n, d2, idx);
   FP_CHECK_LAUNCH("unpack_best");
+  return FP_OK;
+}
+
+int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+                       const int* det_num_templates, float* out_scores, int* out_ids, hipStream_t st) {
+  FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
+  FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
+  FP_REQUIRE(n_top <= 8, "cosine_topk: n_top must be <= 8 on the streaming path");
+  dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj);
+  const int nq = cdiv(max_det_per_obj, 16);
+  if (nq <= 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), 0, st, a);
+  else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), 0, st, a);
+  FP_CHECK_LAUNCH("cosine_sims");
+  hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(num_det), dim3(256), 0, st, a.sims, a.ld_sims, det_num_templates, max_templates,
+                     n_top, out_scores, out_ids);
+  FP_CHECK_LAUNCH("topn_rows_block");
   return FP_OK;
 }

@@ -122,7 +122,7 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma=None, 
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        dt = torch.float32 if epilogue in (3, 5) else torch.bfloat16
+        dt = torch.float32 if (epilogue & 0xff) in (3, 5) else torch.bfloat16
         out = torch.zeros(M, N, dtype=dt, device=a.device)
     call("fp_gemm_bf16", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid,
          ptr(bias), ptr(gamma), ptr(out), out.stride(0), epilogue, stream())

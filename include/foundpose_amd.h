@@ -149,7 +149,8 @@ int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, 
 int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
                  int out_dtype, int dim, int out_rows, int out_rows_per_img, int in_rows_per_img, int in_skip,
                  fp_stream_t stream);
-/* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32 */
+/* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32;
+ * tuning bits: epilogue | (128 << 8) or | (256 << 8) forces that block tile (default: chosen from the shape) */
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual */

@@ -66,10 +66,11 @@ def l2_argmin_cols(q, db):
     return idx, d2
 
 
-def dot_rows(bank, q):
+def dot_rows(bank, q, perm16=False):
     bank, q = _f(bank), _f(q)
     out = np.empty(bank.shape[0], np.float32)
-    lib().orc_dot_rows(_p(bank), _i64(bank.shape[0]), _i64(bank.shape[1]), _p(q), _p(out))
+    fn = lib().orc_dot_rows_perm16 if perm16 else lib().orc_dot_rows
+    fn(_p(bank), _i64(bank.shape[0]), _i64(bank.shape[1]), _p(q), _p(out))
     return out
 
 

@@ -127,6 +127,22 @@ void orc_dot_rows(const float* bank, int64_t t, int64_t w, const float* q, float
   }
 }
 
+// Same, but each 16-block of k is visited in the order [0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15]: the canonical chain
+// order of the MI355X bank-streaming cosine kernel (a lane's 16-byte load feeds four consecutive MFMA k-steps).
+// torch's own cosine_similarity sum order is unspecified (vectorised cascade sum), so any fixed order is a valid
+// restatement; this one is used whenever w % 16 == 0, the ascending one otherwise.
+void orc_dot_rows_perm16(const float* bank, int64_t t, int64_t w, const float* q, float* out) {
+#pragma omp parallel for schedule(static)
+  for (int64_t i = 0; i < t; ++i) {
+    float acc = 0.f;
+    const float* r = bank + i * w;
+    for (int64_t j = 0; j < w; j += 16)
+      for (int u = 0; u < 4; ++u)
+        for (int g = 0; g < 4; ++g) acc = fmaf(r[j + 4 * g + u], q[j + 4 * g + u], acc);
+    out[i] = acc;
+  }
+}
+
 // Sequential scatter-add (torch CPU scatter_add_ walks the index tensor in order).
 void orc_scatter_add(const int64_t* idx, const float* src, int64_t n, float* out) {
   for (int64_t i = 0; i < n; ++i) out[idx[i]] += src[i];

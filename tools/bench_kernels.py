@@ -1,0 +1,70 @@
+#!/usr/bin/env python
+"""Micro-benchmarks of the hot kernels at the benchmark shapes (ViT-L/14-reg, 518^2, batch 32).
+    python tools/bench_kernels.py [gemm] [attn] [ln]
+"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from foundpose_amd import ops  # noqa: E402
+
+
+def timeit(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+def main():
+    what = sys.argv[1:] or ["gemm", "attn", "ln"]
+    B, N, D, H = 32, 1374, 1024, 16
+    M = (B * N + 255) // 256 * 256
+    dev = "cuda"
+    if "gemm" in what:
+        for name, n, k, epi in (("qkv(bias)", 3 * D, D, 0), ("proj(ls)", D, D, 3), ("fc1(gelu)", 4 * D, D, 1), ("fc2(ls)", D, 4 * D, 3)):
+            a = torch.randn(M, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+            bias = torch.randn(n, device=dev)
+            gamma = torch.randn(n, device=dev)
+            out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
+            for tile, pipe in ((256, 0), (128, 0)):
+                if True:
+                    ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8) | (pipe << 20), m_valid=B * N))
+                    print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile} {['dbuf64','dbuf64','ring32','swp64'][pipe]}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+    if "attn" in what:
+        qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
+        vt = torch.zeros(B, D, (N + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
+        vt[:, :, :N] = qkv[:B * N, 2 * D:].reshape(B, N, D).permute(0, 2, 1)
+        ms = timeit(lambda: ops.attention(qkv, B, N, D, H, vt=vt))
+        print(f"attn B={B} N={N} H={H}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
+    if "cos" in what:
+        from foundpose_amd._lib import call, ptr, stream
+        T, W, Bq = 10000, 2048, 32
+        bank_n = ops.normalize_rows(torch.rand(T, W, device=dev))
+        desc_n = ops.normalize_rows(torch.rand(Bq, W, device=dev))
+        seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
+        tpl = torch.tensor([0, T], dtype=torch.int32, device=dev)
+        nt = torch.full((Bq,), T, dtype=torch.int32, device=dev)
+        sims = torch.empty(Bq, T, device=dev)
+        sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5,
+                                 ptr(sims), ptr(sc), ptr(ids), stream()), iters=50)
+        print(f"cosine_topk T={T} W={W} B={Bq}: {ms*1e3:8.1f} us  {(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes only)", flush=True)
+    if "ln" in what:
+        x = torch.randn(M, D, device=dev)
+        w, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
+        ms = timeit(lambda: ops.layernorm(x, w, b, torch.bfloat16))
+        print(f"layernorm rows={M}: {ms*1e3:8.1f} us  {M*D*6/ms/1e6:7.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
