@@ -24,8 +24,7 @@ FP_DEVICE bf16x8 read_frag(const char* lds, int row, int chunk) {
 }
 
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char Ks[64 * 128];
-  __shared__ __attribute__((aligned(16))) char Vs[64 * 128];
+  __shared__ __attribute__((aligned(16))) char KV[2][2][64 * 128];  // [stage][K | V^T][64 rows x 128 B]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int qt = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
@@ -67,22 +66,23 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
     vreg0 = *reinterpret_cast<const uint4*>(vbase0 + (key0_));                                  \
     vreg1 = *reinterpret_cast<const uint4*>(vbase1 + (key0_));                                  \
   }
-#define ATTN_STORE_TILE()                                   \
-  {                                                         \
-    *reinterpret_cast<uint4*>(Ks + soff0) = kreg0;          \
-    *reinterpret_cast<uint4*>(Ks + soff1) = kreg1;          \
-    *reinterpret_cast<uint4*>(Vs + soff0) = vreg0;          \
-    *reinterpret_cast<uint4*>(Vs + soff1) = vreg1;          \
+#define ATTN_STORE_TILE(stage_)                                       \
+  {                                                                   \
+    *reinterpret_cast<uint4*>(KV[stage_][0] + soff0) = kreg0;         \
+    *reinterpret_cast<uint4*>(KV[stage_][0] + soff1) = kreg1;         \
+    *reinterpret_cast<uint4*>(KV[stage_][1] + soff0) = vreg0;         \
+    *reinterpret_cast<uint4*>(KV[stage_][1] + soff1) = vreg1;         \
   }
 
   const int nkt = (N + 63) / 64;
   ATTN_LOAD_TILE(0);
+  ATTN_STORE_TILE(0);
+  __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int key0 = kt * 64;
-    __syncthreads();  // everyone is done reading the previous tile
-    ATTN_STORE_TILE();
-    __syncthreads();
-    if (kt + 1 < nkt) ATTN_LOAD_TILE(key0 + 64);
+    const char* Ks = KV[kt & 1][0];
+    const char* Vs = KV[kt & 1][1];
+    if (kt + 1 < nkt) ATTN_LOAD_TILE(key0 + 64);  // next tile: HBM/L2 -> registers, lands under this tile's MFMAs
 
     // ---- S^T = K Q^T : sacc[ks][r] = score(query = l31, key = key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
     f32x16 sacc[2];
@@ -106,15 +106,18 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
         }
     }
     // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
-    float mx = sacc[0][0];
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[ks][r]);
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);  // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+    // the running max stops moving after the first few tiles: skip the rescale of O and l unless some lane needs it
+    const bool grow = __any(m_new > m_run);
+    float alpha = 1.f;
+    if (grow) alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
     m_run = m_new;
+    // exp2(s*c - m*c): scalar fp32 VALU on purpose -- v_pk_fma/v_pk_add variants measured 25 % SLOWER here
+    // (packed fp32 issues badly beside MFMAs, guide "price of one filler beside MFMAs")
     float psum = 0.f;
     const float mc = m_new * c;
 #pragma unroll
@@ -125,11 +128,14 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
         sacc[ks][r] = p;
         psum += p;
       }
-    l_run = l_run * alpha + psum;
+    if (grow) {
+      l_run *= alpha;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    l_run += psum;
 
     // ---- O^T += V^T P^T over 4 steps of 16 keys
 #pragma unroll
@@ -152,6 +158,8 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
         }
       }
+    if (kt + 1 < nkt) ATTN_STORE_TILE((kt + 1) & 1);  // the other stage was last read one iteration ago
+    __syncthreads();
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);

@@ -224,10 +224,118 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a)
   }
 
   if (a.dbg) ts2 = __builtin_readcyclecounter();
-  // ---- epilogue: acc[tm][tn][r] = C[m][n],  m = m0 + wm*64 + tm*32 + (lane&31),
-  //      n = n0 + wn*64 + tn*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
-  // Column-only operands are fetched once, row operands in one batch per tm, so the tail is a
-  // few waits instead of one per access.
+  // ---- epilogue: acc[tm][tn][r] = C[m][n],  m = m0 + wm*(BM/WM) + tm*32 + (lane&31),
+  //      n = n0 + wn*(BN/WN) + tn*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
+  // A lane owns pieces of 32 different rows, so storing straight from registers makes every store instruction touch
+  // 32 cache lines (the address path, not HBM, then bounds the tail).  Instead each 32-row band of the tile goes
+  // through LDS (free after the main loop) and leaves as whole rows: 16 B per lane, lane-contiguous.
+  // bf16 outputs leave through an LDS slab (whole-row 16-B stores: the tail drops from ~15k to ~8k cycles per tile);
+  // the fp32 read-modify-write epilogues are bound by the residual traffic itself and stay register-direct.
+  constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_QKV_BF16;
+  if constexpr (USE_SLAB) {
+  constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
+  constexpr int ESZ = OUT_F32 ? 4 : 2;
+  constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = BN * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
+  constexpr int CHUNKS_PER_ROW = BN * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
+  static_assert(SLAB_ROWS * SLAB_STRIDE <= 2 * (BM + BN) * BK * 2 / (PIPE == 3 ? 2 : 1), "slab must fit the main-loop LDS");
+  float4 bias[TN][4], gam[TN][4];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
+      bias[tn][g] = *reinterpret_cast<const float4*>(a.bias + n);
+      if constexpr (EPI == GEMM_EPI_LS_RESID_F32) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
+    }
+  bool v_tile = false;  // qkv: tiles inside the V column block scatter V^T straight from registers
+  if constexpr (EPI == GEMM_EPI_QKV_BF16) v_tile = n0 >= 2 * a.vit_dim;
+  __syncthreads();  // every wave is done with the operand tiles in LDS
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
+    if (v_tile) {
+      if constexpr (EPI == GEMM_EPI_QKV_BF16) {
+        if (m < a.M_valid) {
+          const int vb = m / a.tok_n, vt = m - vb * a.tok_n;
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int nn = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh - 2 * a.vit_dim;  // head*64 + d
+              const float4 bs = bias[tn][g];
+              __bf16* vtp = a.vt + ((size_t)vb * a.vit_dim + nn) * a.vt_ld + vt;
+              vtp[0 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 0] + bs.x);
+              vtp[1 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 1] + bs.y);
+              vtp[2 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 2] + bs.z);
+              vtp[3 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 3] + bs.w);
+            }
+        }
+      }
+      continue;
+    }
+    // (a) registers -> slab (final values except for the operand that needs a global read)
+    char* srow = smem + (wm * 32 + l31) * SLAB_STRIDE;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int col = wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
+        const float4 bs = bias[tn][g];
+        float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
+        float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
+        if constexpr (EPI == GEMM_EPI_GELU_BF16) {
+          v0 = gelu_erf(v0); v1 = gelu_erf(v1); v2 = gelu_erf(v2); v3 = gelu_erf(v3);
+        }
+        if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
+          const float4 gm = gam[tn][g];
+          v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
+        }
+        if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
+        else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+      }
+    __syncthreads();
+    // (b) slab -> global, whole rows.  Global reads (residual / pos-embed rows) of all passes are issued first,
+    // so the tail pays one memory round trip per band instead of one per pass.
+    constexpr int PASSES = (SLAB_CHUNKS + NT - 1) / NT;
+    static_assert(SLAB_CHUNKS % NT == 0, "slab chunks must divide evenly over the block");
+    float4 ext[PASSES];
+    size_t orow[PASSES];
+    bool ok[PASSES];
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+      const int id = tid + it * NT;
+      const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
+      const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
+      ok[it] = gm_row < a.M_valid;
+      orow[it] = gm_row;
+      if constexpr (EPI == GEMM_EPI_TOKENS_F32) {
+        const int b = gm_row / a.tok_np, pidx = gm_row - b * a.tok_np;
+        orow[it] = (size_t)b * a.tok_n + a.tok_skip + pidx;
+        if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(a.pos + (size_t)pidx * a.ldo + n0 + c * 4);
+      }
+      if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
+        if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + orow[it] * a.ldo + n0 + c * 4);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+      const int id = tid + it * NT;
+      const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
+      if (!ok[it]) continue;
+      const char* sp = smem + r * SLAB_STRIDE + c * 16;
+      if constexpr (!OUT_F32) {
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + n0 + c * 8) = *reinterpret_cast<const uint4*>(sp);
+      } else {
+        float4 v = *reinterpret_cast<const float4*>(sp);
+        if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32) {
+          v.x += ext[it].x; v.y += ext[it].y; v.z += ext[it].z; v.w += ext[it].w;
+        }
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow[it] * a.ldo + n0 + c * 4) = v;
+      }
+    }
+    if (tm + 1 < TM) __syncthreads();
+  }
+  } else {
   float4 bias[TN][4], gam[TN][4];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
@@ -305,6 +413,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a)
         }
       }
   }
+  }
   if (a.dbg) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned long long ts3 = __builtin_readcyclecounter();
@@ -344,8 +453,6 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
     if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);
     return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, st);
   }
-  if (force == 384 && a.N % 256 == 0) return launch_cfg<EPI, 128, 256, 2, 2, 3>(a, st);  // 128x256, 4 waves, 48 KiB: 2 blocks/CU
-  if (force == 385 && a.N % 256 == 0 && a.M % 256 == 0) return launch_cfg<EPI, 256, 256, 2, 4, 3>(a, st);  // 256x256 with a 2-deep BK=32 ring (64 KiB): 2 blocks/CU
   if (pv == 0) return launch_cfg<EPI, 128, 128, 2, 2, 0>(a, st);
   if (pv == 1) return launch_cfg<EPI, 128, 128, 2, 2, 1>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, st);
