@@ -192,7 +192,7 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   const int tile = (epilogue >> 8) & 0xfff;  // tuning bits: force the 128 or 256 block tile
   const int pipe = (epilogue >> 20) & 0xf;   // tuning bits: 1 = double-buffered BK=64 main loop
   epilogue &= 0xff;
-  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_bf16: bad tile override %d", tile);
+  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384, "fp_gemm_bf16: bad tile override %d", tile);
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
                  epilogue == GEMM_EPI_BIAS_F32,
              "fp_gemm_bf16: epilogue %d is not available through this entry point", epilogue);

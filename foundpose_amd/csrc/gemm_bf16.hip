@@ -62,7 +62,7 @@ FP_DEVICE bf16x8 read_frag32(const char* lds, int row, int chunk) {
 }
 
 template <int EPI, int BM, int BN, int WM, int WN, int PIPE>
-__global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   constexpr int NW = WM * WN, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a)
       }
     }
   } else {
-    constexpr int DEPTH = PIPE == 3 ? 2 : 4, DIST = DEPTH - 1;
+    constexpr int DEPTH = PIPE == 3 ? 2 : (PIPE == 4 ? 3 : 4), DIST = DEPTH - 1;
     // ---- DEPTH-deep ring of BK=32 sub-stages, DMA issued 3 sub-stages ahead, counted vmcnt + raw s_barrier:
     // HBM/L2 latency is covered by ~3 sub-stages of MFMA work instead of one K-tile (guide section 5 T3+T4).
     constexpr int SA = BM * 64, SB = BN * 64, SUB = SA + SB;          // bytes per sub-stage
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a)
   constexpr int ESZ = OUT_F32 ? 4 : 2;
   constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = BN * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
   constexpr int CHUNKS_PER_ROW = BN * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
-  static_assert(SLAB_ROWS * SLAB_STRIDE <= 2 * (BM + BN) * BK * 2 / (PIPE == 3 ? 2 : 1), "slab must fit the main-loop LDS");
+  static_assert(SLAB_ROWS * SLAB_STRIDE <= (BM + BN) * 64 * (PIPE == 3 ? 2 : (PIPE == 4 ? 3 : 4)), "slab must fit the main-loop LDS");
   float4 bias[TN][4], gam[TN][4];
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn)
@@ -427,7 +427,8 @@ __global__ __launch_bounds__(WM * WN * 64) void gemm_bf16_kernel(GemmBf16Args a)
 template <int EPI, int BM, int BN, int WM, int WN, int PIPE>
 int launch_cfg(const GemmBf16Args& a, hipStream_t st) {
   const unsigned grid = (a.M / BM) * (a.N / BN);
-  const size_t lds = PIPE == 3 ? (size_t)(BM + BN) * BK * 2 : (size_t)2 * (BM + BN) * BK * 2;  // 2 x BK=64 stages == 4 x BK=32 sub-stages; PIPE 3: 2 sub-stages
+  // 2 x BK=64 stages == 4 x BK=32 sub-stages; PIPE 3 / 4: ring of 2 / 3 sub-stages
+  const size_t lds = (size_t)(BM + BN) * 64 * (PIPE == 3 ? 2 : (PIPE == 4 ? 3 : 4));
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIPE>),
@@ -453,6 +454,7 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
     if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);
     return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, st);
   }
+  if (force == 384 && a.N % 256 == 0) return launch_cfg<EPI, 128, 256, 2, 2, 4>(a, st);  // 4 waves, 72 KiB ring: 2 workgroups per CU
   if (pv == 0) return launch_cfg<EPI, 128, 128, 2, 2, 0>(a, st);
   if (pv == 1) return launch_cfg<EPI, 128, 128, 2, 2, 1>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, st);
