@@ -153,7 +153,7 @@ def main():
         sims = torch.empty(B, args.templates, device=dev)
         sc, ids = torch.empty(B, 5, device=dev), torch.empty(B, 5, dtype=torch.int32, device=dev)
         ms_knn = time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, B, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
-                                          1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), stream()))
+                                          1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), 0, stream()))
         knn_bytes = args.templates * 2048 * 4 + B * 2048 * 4 + B * args.templates * 4 * 2
         result = {
             "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",

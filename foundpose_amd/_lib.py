@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16 = 0, 1
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -47,9 +47,9 @@ _PROTOS = {
     "fp_normalize_rows": [vp, i64, i32, f32, vp, vp],
     "fp_knn_l2": [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "fp_tfidf_build": [vp, vp, i32, vp, i32, vp, i32, i32, f32, i32, vp, vp, f32, vp],
-    "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, vp],
+    "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp],
     "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32,
-                          vp, vp, vp, vp, vp, vp, vp, vp, vp],
+                          vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "fp_sample_bilinear": [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
     "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],

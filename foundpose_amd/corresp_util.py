@@ -1,6 +1,10 @@
 """2D-3D correspondence establishment with the reference's signatures
 (/root/reference/utils/corresp_util.py:34-169), executed on the MI355X.
 
+Tie order: the drop-in functions default to `tie_order="torch"` -- among equal cycle distances (and equal template
+scores) the selection and order are exactly those of the reference's `torch.topk` on CPU tensors, replayed on the
+device (csrc/stl_order.hpp). The batched engine defaults to the cheaper canonical order (value, then lowest index).
+
 `visual_words_knn_index` / `template_knn_indices` (faiss indices the reference builds per object and per
 template, scripts/infer.py:216-239) are accepted for call compatibility and not needed: the HBM bank is
 CSR-indexed by template, so no per-template index or mask scan exists.
@@ -28,7 +32,7 @@ def cyclic_buddies_matching(query_points: torch.Tensor, query_features: torch.Te
         feat_cluster_centroids=object_features[:1].repeat(4, 1), feat_cluster_idfs=torch.ones(4),
         template_descs=torch.ones(1, 4), template_desc_opts=repre_util.TemplateDescOpts(tfidf_knn_k=1))
     bank = template_util.get_device_bank(repre)
-    res = match_batch(bank, query_features.to("cuda"), query_points.to("cuda"), [query_points.shape[0]], None, 1, top_k)
+    res = match_batch(bank, query_features.to("cuda"), query_points.to("cuda"), [query_points.shape[0]], None, 1, top_k, tie_order="torch")
     c = int(res.counts[0, 0])
     dev = query_points.device
     return (res.q_ids[0, 0, :c].to(torch.int64).to(dev), res.feat_ids[0, 0, :c].to(torch.int64).to(dev),
@@ -46,6 +50,7 @@ def establish_correspondences(
     visual_words_knn_index: Optional[knn_util.KNN] = None,
     template_knn_indices: Optional[List[knn_util.KNN]] = None,
     debug: bool = False,
+    tie_order: str = "torch",
 ) -> List[Dict]:
     if template_matching_type != "tfidf":
         raise ValueError(f"Unknown matching type '{template_matching_type}'.")
@@ -55,5 +60,5 @@ def establish_correspondences(
     assert object_repre.vertices is not None
     bank = template_util.get_device_bank(object_repre)
     res = match_batch(bank, query_features.to("cuda"), query_points.to("cuda"), [query_points.shape[0]], None,
-                      top_n_templates, top_k_buddies, keep_debug=debug)
+                      top_n_templates, top_k_buddies, keep_debug=debug, tie_order=tie_order)
     return res.corresp_list(0, debug=debug)

@@ -88,17 +88,18 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
                    int max_det_per_obj, const float* bank_n, const int32_t* obj_tpl_off, int num_obj,
                    int max_templates, int num_words, int n_top, float* scratch_sims, float* out_scores,
-                   int32_t* out_ids, fp_stream_t stream) {
+                   int32_t* out_ids, int tie_mode, fp_stream_t stream) {
   FP_REQUIRE(desc_n && det_seg_off && det_num_templates && bank_n && obj_tpl_off && scratch_sims && out_scores && out_ids,
              "fp_cosine_topk: null pointer");
   FP_REQUIRE(num_obj >= 1 && max_templates >= 1 && n_top >= 1, "fp_cosine_topk: bad sizes");
   if (num_det == 0) return FP_OK;
-  if (num_words % 16 == 0 && max_det_per_obj <= 64 && n_top <= 8) {  // bank-streaming path (HBM-bound)
+  FP_REQUIRE(tie_mode == 0 || tie_mode == 1, "fp_cosine_topk: tie_mode must be 0 (canonical) or 1 (torch)");
+  if (num_words % 16 == 0 && max_det_per_obj <= 64 && (n_top <= 8 || tie_mode == 1)) {  // bank-streaming path (HBM-bound)
     CosineArgs c;
     c.desc_n = desc_n; c.bank_n = bank_n; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
     c.sims = scratch_sims; c.ld_sims = max_templates;
     return launch_cosine_topk(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores,
-                              out_ids, ST(stream));
+                              out_ids, tie_mode, ST(stream));
   }
   // generic tile path (k-ascending chains): odd descriptor sizes or very large groups
   F32TileArgs a = zero_tile_args();
@@ -106,6 +107,8 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
   a.a_seg_off = det_seg_off; a.b_seg_off = obj_tpl_off;
   a.out = scratch_sims; a.ldo = max_templates; a.out_row_global = 1;
   TRY(f32_tile_launch(F32_EPI_STORE, a, max_det_per_obj, max_templates, num_obj, ST(stream)));
+  if (tie_mode == 1)
+    return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, 1, ST(stream));
   return launch_topk_rows(scratch_sims, num_det, max_templates, max_templates, det_num_templates, n_top, 1,
                           out_scores, out_ids, ST(stream));
 }
@@ -115,7 +118,7 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
                       const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
                       void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
-                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d,
+                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d, int tie_mode,
                       fp_stream_t stream) {
   FP_REQUIRE(query_feats && query_sqnorm && query_points && q_off && bank_feats && bank_sqnorm && tpl_off && vertices &&
                  tpl_ids && feat_base && scratch && out_count && out_q_ids && out_feat_ids && out_dists && out_conf &&
@@ -139,7 +142,7 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_off = tpl_off; c.feat_base = feat_base;
   c.points = query_points; c.vertices = vertices;
   c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max;
-  c.n_slots = n_slots; c.top_k = top_k; c.k_max = k_max; c.q_max = q_max;
+  c.n_slots = n_slots; c.top_k = top_k; c.k_max = k_max; c.q_max = q_max; c.tie_mode = tie_mode;
   c.out_count = out_count; c.out_q_ids = out_q_ids; c.out_feat_ids = out_feat_ids; c.out_dists = out_dists;
   c.out_conf = out_conf; c.out_coord_2d = out_coord_2d; c.out_coord_3d = out_coord_3d;
   return launch_cyclic_select(c, pairs, ST(stream));

@@ -44,6 +44,7 @@ struct CyclicArgs {
   const unsigned long long* row_best; int row_stride;  // [pairs, row_stride] (d2, template patch)
   const unsigned long long* col_best; int col_stride;  // [pairs, col_stride] (d2, query patch)
   int n_slots, top_k, k_max, q_max;
+  int tie_mode;            // 0 canonical (value, index); 1 torch.topk's CPU tie order (stl_order.hpp)
   int* out_count;          // [pairs]
   int* out_q_ids;          // [pairs, k_max]
   int* out_feat_ids;       // [pairs, k_max]
@@ -136,4 +137,6 @@ struct CosineArgs {
   float* sims; int ld_sims;  // [num_det, ld_sims]
 };
 int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
-                       const int* det_num_templates, float* out_scores, int* out_ids, hipStream_t st);
+                       const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
+int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
+                     int* out_ids, int tie_mode, hipStream_t st);

@@ -10,6 +10,7 @@
 //   sample_bilinear .. utils/feature_util.py:100-131 (grid_sample bilinear, zeros, align_corners=False)
 #include "common.hpp"
 #include "kernels.hpp"
+#include "stl_order.hpp"
 
 namespace {
 
@@ -224,6 +225,26 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __res
   }
 }
 
+// Strict-order variant: one block per row, the row staged in LDS as (value, index) pairs, one lane replays
+// torch.topk's CPU algorithm (stl_order.hpp).  Rows of up to 20000 elements (160 KiB of LDS).
+__global__ __launch_bounds__(256) void topn_rows_stl_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                            int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(smem_raw);
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const int len = row_len ? row_len[row] : n_default;
+  const float* r = vals + (size_t)row * ld;
+  for (int j = tid; j < len; j += 256) el[j] = stl_order::Elem{r[j], j};
+  __syncthreads();
+  const int k = min(n_top, len);
+  if (tid == 0) stl_order::topk_torch_largest(el, len, k);
+  __syncthreads();
+  if (tid < n_top) {
+    out_idx[(size_t)row * n_top + tid] = tid < k ? el[tid].idx : -1;
+    out_val[(size_t)row * n_top + tid] = tid < k ? el[tid].v : -INFINITY;
+  }
+}
+
 // ------------------------------------------------------------------ tf-idf descriptor per detection
 // One block (256 threads) per segment (a detection's query patches, or a template's patches on the
 // bank-builder side). Thread t owns the bins with (id & 255) == t and walks the (q, j) entries in
@@ -325,6 +346,23 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
     keys[i] = key;
   }
   __syncthreads();
+  if (a.tie_mode == 1) {
+    // strict mode: the reference's torch.topk(-cycle_dists, k) order, ties included -- one lane replays
+    // libstdc++'s nth_element + sort (or partial_sort) on (value, index) pairs held in LDS
+    stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(keys);
+    for (int i = tid; i < Q; i += 256) {
+      const unsigned long long key = keys[i];  // each thread converts only the slots it reads itself
+      el[i] = stl_order::Elem{-__uint_as_float((unsigned)(key >> 32)), i};
+    }
+    __syncthreads();
+    if (tid == 0) stl_order::topk_torch_largest(el, Q, kk);
+    __syncthreads();
+    for (int i = tid; i < kk; i += 256) {  // back to (distance bits, query id) keys in output order
+      const stl_order::Elem e = el[i];
+      keys[i] = pack_dist_idx(-e.v, (unsigned)e.idx);
+    }
+    __syncthreads();
+  } else {
   // bitonic sort of 2048 keys, ascending: (cycle distance, query index)
   for (int size = 2; size <= 2048; size <<= 1) {
     for (int stride = size >> 1; stride > 0; stride >>= 1) {
@@ -337,6 +375,7 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
       }
       __syncthreads();
     }
+  }
   }
   const float dmax = __uint_as_float((unsigned)(keys[kk - 1] >> 32));
   const size_t ob = (size_t)pair * a.k_max;
@@ -495,19 +534,35 @@ int launch_unpack_best(const unsigned long long* best, long long n, float* d2, i
   return FP_OK;
 }
 
+int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
+                     int* out_ids, int tie_mode, hipStream_t st) {
+  if (rows == 0) return FP_OK;
+  if (tie_mode == 1) {
+    FP_REQUIRE(max_len <= 20000, "strict (torch) tie order supports rows of at most 20000 elements (got %d)", max_len);
+    const size_t lds = (size_t)max_len * 8;
+    static size_t attr = 0;
+    if (lds > attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_rows_stl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
+      attr = 160000;
+    }
+    hipLaunchKernelGGL(topn_rows_stl_kernel, dim3(rows), dim3(256), lds, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+  } else {
+    FP_REQUIRE(n_top <= 8, "top-n: n_top must be <= 8 on the canonical block path");
+    hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+  }
+  FP_CHECK_LAUNCH("topn_rows");
+  return FP_OK;
+}
+
 int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
-                       const int* det_num_templates, float* out_scores, int* out_ids, hipStream_t st) {
+                       const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st) {
   FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
   FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
-  FP_REQUIRE(n_top <= 8, "cosine_topk: n_top must be <= 8 on the streaming path");
   dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj);
   const int nq = cdiv(max_det_per_obj, 16);
   if (nq <= 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), 0, st, a);
   else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("cosine_sims");
-  hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(num_det), dim3(256), 0, st, a.sims, a.ld_sims, det_num_templates, max_templates,
-                     n_top, out_scores, out_ids);
-  FP_CHECK_LAUNCH("topn_rows_block");
-  return FP_OK;
+  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st);
 }

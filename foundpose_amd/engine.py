@@ -18,10 +18,11 @@ from .matching import MatchResult, match_batch
 
 class FoundPoseEngine:
     def __init__(self, extractor: DinoFeatureExtractor, bank: DeviceBank, grid_cell_size: float = 14.0,
-                 top_n_templates: int = 5, top_k_buddies: int = 300) -> None:
+                 top_n_templates: int = 5, top_k_buddies: int = 300, tie_order: str = "canonical") -> None:
         self.extractor, self.bank = extractor, bank
         self.cell = grid_cell_size
         self.top_n, self.top_k = top_n_templates, top_k_buddies
+        self.tie_order = tie_order
         self._grids = {}
 
     def _grid(self, w: int, h: int, device):
@@ -52,7 +53,7 @@ class FoundPoseEngine:
         D = fmap.shape[-1]
         raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
         feats = self._project(raw, counts, det_obj)
-        return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug)
+        return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
 
     def _project(self, raw: torch.Tensor, counts: Sequence[int], det_obj: Sequence[int]) -> torch.Tensor:
         if raw.shape[1] == self.bank.feat_dim:

@@ -65,8 +65,12 @@ def match_batch(
     top_n_templates: int = 5,
     top_k_buddies: int = 300,
     keep_debug: bool = False,
+    tie_order: str = "canonical",  # "canonical": (value, lowest index);  "torch": the reference's torch.topk CPU tie order
 ) -> MatchResult:
     require_cuda(query_features, query_points)
+    if tie_order not in ("canonical", "torch"):
+        raise ValueError(f"unknown tie_order '{tie_order}'")
+    tie_mode = 1 if tie_order == "torch" else 0
     dev = query_features.device
     B = len(q_counts)
     det_obj = [0] * B if det_obj is None else list(det_obj)
@@ -129,7 +133,7 @@ def match_batch(
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
     call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
-         ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), stream())
+         ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
 
     # ---- cyclic best buddies against the retrieved templates + correspondence assembly
     tpl_base = torch.tensor([bank.objects[o].tpl_base for o in det_obj], dtype=torch.int32, device=dev)
@@ -146,7 +150,7 @@ def match_batch(
     c3d = torch.zeros(B, n, K, 3, dtype=torch.float32, device=dev)
     call("fp_cyclic_buddies", ptr(qf), ptr(q_sqn), ptr(qp), ptr(q_off), B, q_max, ptr(bank.feats), ptr(bank.feat_sqn),
          ptr(bank.tpl_off), bank.p_max, ptr(bank.vertices), ptr(t_glob), ptr(feat_base), n, bank.feat_dim, K, K,
-         ptr(scratch), ptr(counts), ptr(q_ids), ptr(feat_ids), ptr(dists), ptr(conf), ptr(c2d), ptr(c3d), stream())
+         ptr(scratch), ptr(counts), ptr(q_ids), ptr(feat_ids), ptr(dists), ptr(conf), ptr(c2d), ptr(c3d), tie_mode, stream())
     return MatchResult(t_ids, t_scores, counts, q_ids, feat_ids, dists, conf, c2d, c3d,
                        query_tfidf=desc if keep_debug else None,
                        word_ids=torch.cat(word_ids_all, 0) if keep_debug and word_ids_all else None)

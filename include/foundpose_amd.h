@@ -25,7 +25,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
 
-#define FP_ABI_VERSION 1
+#define FP_ABI_VERSION 2
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -60,11 +60,12 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
  * its object + top-n (tfidf_matching, utils/template_util.py:167-174).  Detections are grouped by object:
  * det_seg_off [num_obj+1] over rows of desc_n, obj_tpl_off [num_obj+1] over rows of bank_n (both
  * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims [num_det, max_templates].  out_scores/out_ids [num_det, n_top]; ids are
- * object-local template ids. */
+ * object-local template ids.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of torch.topk on
+ * a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows <= 20000 templates). */
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
                    int max_det_per_obj,
                    const float* bank_n, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,
-                   int n_top, float* scratch_sims, float* out_scores, int32_t* out_ids, fp_stream_t stream);
+                   int n_top, float* scratch_sims, float* out_scores, int32_t* out_ids, int tie_mode, fp_stream_t stream);
 
 /* Cyclic best-buddy matching of every detection against its n_slots retrieved templates and assembly of the
  * 2D-3D correspondences (cyclic_buddies_matching + the gather in establish_correspondences,
@@ -75,13 +76,15 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
  *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
  *   scratch: B*n_slots*(q_max + p_max)*8 bytes
  * outputs, padded to k_max >= top_k per (detection, slot): count, query ids, object feature ids (= the
- * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d. */
+ * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d.  tie_mode as in fp_cosine_topk: 1 makes
+ * the order (and the choice among tied distances at the top_k boundary) identical to the reference's
+ * torch.topk(-cycle_dists, k). */
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
                       const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
                       void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
-                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d,
+                      float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d, int tie_mode,
                       fp_stream_t stream);
 
 /* sample_feature_map_at_points (utils/feature_util.py:100-131): bilinear grid_sample, zeros padding,

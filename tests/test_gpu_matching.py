@@ -94,7 +94,7 @@ def test_tfidf_build(soft):
             assert np.array_equal(desc_n[s].cpu().numpy(), om.l2_normalize_rows(ref[None])[0])
 
 
-def _gpu_corresp(repre_np, pts, feats, top_n, top_k):
+def _gpu_corresp(repre_np, pts, feats, top_n, top_k, tie_order="canonical"):
     from foundpose_amd import corresp_util, repre_util
     o = repre_np["template_desc_opts"]
     repre = repre_util.FeatureBasedObjectRepre(
@@ -108,7 +108,51 @@ def _gpu_corresp(repre_np, pts, feats, top_n, top_k):
     return corresp_util.establish_correspondences(
         query_points=torch.from_numpy(pts).cuda(), query_features=torch.from_numpy(feats).cuda(), object_repre=repre,
         template_matching_type="tfidf", feat_matching_type="cyclic_buddies", top_n_templates=top_n,
-        top_k_buddies=top_k, debug=True)
+        top_k_buddies=top_k, debug=True, tie_order=tie_order)
+
+
+@pytest.mark.parametrize("name", sorted(MATCH_CASES))
+def test_establish_correspondences_strict_order_equals_reference(name):
+    """Default drop-in behaviour (tie_order="torch"): identical to the reference's own run, index for index,
+    INCLUDING the order among tied cycle distances and the choice at the top-k boundary."""
+    c, g, repre, pts, feats = match_case_inputs(name)
+    got = _gpu_corresp(repre, pts, feats, c["top_n"], c["top_k"], tie_order="torch")
+    assert [int(a["template_id"]) for a in got] == list(g["template_ids"])
+    np.testing.assert_allclose([float(a["template_score"]) for a in got], g["template_scores"], rtol=0, atol=2e-6)
+    for i, a in enumerate(got):
+        assert np.array_equal(a["coord_2d_ids"].cpu().numpy(), g[f"coord_2d_ids_{i}"]), f"template slot {i}"
+        assert np.array_equal(a["nn_vertex_ids"].cpu().numpy(), g[f"nn_vertex_ids_{i}"])
+        assert np.array_equal(a["coord_2d"].cpu().numpy(), g[f"coord_2d_{i}"])
+        assert np.array_equal(a["coord_3d"].cpu().numpy(), g[f"coord_3d_{i}"])
+        assert np.array_equal(a["nn_dists"].cpu().numpy(), g[f"nn_dists_{i}"])
+        np.testing.assert_allclose(a["coord_conf"].cpu().numpy(), g[f"coord_conf_{i}"], rtol=0, atol=1e-7, equal_nan=True)
+
+
+def test_strict_template_order_with_duplicate_templates():
+    """Exact score ties (duplicated templates): tie_order="torch" reproduces torch.topk's pick, canonical picks the lowest id."""
+    from foundpose_amd import ops
+    from foundpose_amd._lib import call, ptr, stream
+    rng = np.random.default_rng(4)
+    for T in (100, 800):  # nth_element branch (5*64 > 100) and partial_sort branch (5*64 <= 800)
+        W, Bq = 64, 3
+        bank = rng.random((T, W)).astype(np.float32)
+        bank[T // 2:] = bank[: T - T // 2]  # every descriptor appears twice
+        q = rng.random((Bq, W)).astype(np.float32)
+        bank_n, q_n = ops.normalize_rows(cu(bank)), ops.normalize_rows(cu(q))
+        seg, tpl = cu(np.array([0, Bq], np.int32)), cu(np.array([0, T], np.int32))
+        nt = cu(np.full(Bq, T, np.int32))
+        sims = torch.empty(Bq, T, device="cuda")
+        for mode in (0, 1):
+            sc = torch.empty(Bq, 5, device="cuda")
+            ids = torch.empty(Bq, 5, dtype=torch.int32, device="cuda")
+            call("fp_cosine_topk", ptr(q_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream())
+            s_cpu = sims.cpu()
+            for b in range(Bq):
+                if mode == 1:
+                    ref = torch.topk(s_cpu[b], 5, sorted=True)[1]
+                else:
+                    ref = torch.from_numpy(clib.topk_canonical(s_cpu[b].numpy(), 5, True)[1])
+                assert ids[b].cpu().tolist() == ref.tolist(), (T, mode, b)
 
 
 @pytest.mark.parametrize("name", sorted(MATCH_CASES))
@@ -239,7 +283,7 @@ def test_engine_batch_equals_per_detection():
         feat_to_template_ids=torch.from_numpy(g["f2t"]), feat_cluster_centroids=torch.from_numpy(g["centroids"]),
         feat_cluster_idfs=torch.from_numpy(g["idfs"]), template_descs=torch.from_numpy(g["template_descs"]),
         template_desc_opts=repre_util.TemplateDescOpts(), feat_raw_projectors=[proj])
-    eng = engine.FoundPoseEngine(ex, DeviceBank([repre]), 14.0, 5, 300)
+    eng = engine.FoundPoseEngine(ex, DeviceBank([repre]), 14.0, 5, 300, tie_order="torch")
     imgs = torch.from_numpy(g["tpl_imgs"][[4, 7, 1]].astype(np.float32)).cuda()
     imgs[0] = torch.from_numpy(g["q_img"]).cuda()
     masks = torch.from_numpy(g["tpl_masks"][[4, 7, 1]]).cuda()

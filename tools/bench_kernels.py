@@ -57,7 +57,7 @@ def main():
         sims = torch.empty(Bq, T, device=dev)
         sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
         ms = timeit(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5,
-                                 ptr(sims), ptr(sc), ptr(ids), stream()), iters=50)
+                                 ptr(sims), ptr(sc), ptr(ids), 0, stream()), iters=50)
         print(f"cosine_topk T={T} W={W} B={Bq}: {ms*1e3:8.1f} us  {(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes only)", flush=True)
     if "ln" in what:
         x = torch.randn(M, D, device=dev)
