@@ -150,7 +150,7 @@ def main():
         desc_n = ops.normalize_rows(torch.rand(B, 2048, device=dev))
         seg = torch.tensor([0, B], dtype=torch.int32, device=dev)
         nt = torch.full((B,), args.templates, dtype=torch.int32, device=dev)
-        sims = torch.empty(B, args.templates, device=dev)
+        sims = torch.empty(9, B, args.templates, device=dev)
         sc, ids = torch.empty(B, 5, device=dev), torch.empty(B, 5, dtype=torch.int32, device=dev)
         ms_knn = time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, B, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
                                           1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), 0, stream()))

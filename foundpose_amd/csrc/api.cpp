@@ -98,6 +98,8 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
     CosineArgs c;
     c.desc_n = desc_n; c.bank_n = bank_n; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
     c.sims = scratch_sims; c.ld_sims = max_templates;
+    c.k_slices = (num_words % 128 == 0) ? 8 : 1;  // canonical chain split, see include/foundpose_amd.h
+    c.slice_stride = (long long)num_det * max_templates;
     return launch_cosine_topk(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores,
                               out_ids, tie_mode, ST(stream));
   }
@@ -108,7 +110,7 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
   a.out = scratch_sims; a.ldo = max_templates; a.out_row_global = 1;
   TRY(f32_tile_launch(F32_EPI_STORE, a, max_det_per_obj, max_templates, num_obj, ST(stream)));
   if (tie_mode == 1)
-    return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, 1, ST(stream));
+    return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, 1, 1, 0, nullptr, ST(stream));
   return launch_topk_rows(scratch_sims, num_det, max_templates, max_templates, det_num_templates, n_top, 1,
                           out_scores, out_ids, ST(stream));
 }

@@ -128,14 +128,17 @@ __global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
   if (t0 >= T || nd <= 0) return;
   const int i = lane & 15, g = lane >> 4;
   const int trow = min(t0 + i, T - 1);
-  const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + 4 * g;
+  // K is cut into a.k_slices contiguous slices (blockIdx.z): more waves than SIMDs, so the fp32 matrix pipe of
+  // every SIMD works on the stream; the slice chains are summed in slice order by the top-n kernel.
+  const int kslice = blockIdx.z, wslice = a.W / a.k_slices;
+  const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + kslice * wslice + 4 * g;
   const float* bp[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) bp[q] = a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + 4 * g;
+  for (int q = 0; q < NQ; ++q) bp[q] = a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + kslice * wslice + 4 * g;
   f32x4 acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nb = a.W / 16;
+  const int nb = wslice / 16;
   // Software pipeline: chunks of U 16-blocks; chunk c+1's loads are in flight while chunk c's MFMAs run
   // (a wave keeps 2 x U KiB of the bank stream outstanding -- what it takes to pull HBM bandwidth without LDS).
   constexpr int U = 8;
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
   for (int q = 0; q < NQ; ++q) {
     const int det = q * 16 + i;
     if (det >= nd) continue;
-    float* o = a.sims + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
+    float* o = a.sims + (size_t)kslice * a.slice_stride + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (t0 + 4 * g + r < T) o[r] = acc[q][r];
@@ -175,18 +178,26 @@ __global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
 // Canonical top-n of each row (largest first, ties -> lowest index), one 256-thread block per row:
 // per-thread top-n over a strided slice (registers), then n rounds of block-wide arg-best over the candidates.
 template <int NMAX>
-__global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                              int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                              int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                              int k_slices, long long slice_stride, unsigned long long* __restrict__ cand_out) {
   __shared__ unsigned long long cand[256 * NMAX];
   __shared__ unsigned long long wbest[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = row_len ? row_len[row] : n_default;
-  const float* r = vals + (size_t)row * ld;
+  float* r = vals + (size_t)row * ld;
+  // gridDim.y > 1: this block scans one contiguous split of the row and emits its n_top best keys (phase A);
+  // a merge launch (gridDim.y == 1 over the candidate keys) finishes the row.
+  const int nsplit = gridDim.y, split = blockIdx.y;
+  const int per = (len + nsplit - 1) / nsplit;
+  const int j_begin = split * per, j_end = min(len, j_begin + per);
   unsigned long long best[NMAX];
 #pragma unroll
   for (int s = 0; s < NMAX; ++s) best[s] = ~0ull;
-  for (int j = tid; j < len; j += 256) {
-    unsigned long long key = ((unsigned long long)order_key(r[j], true) << 32) | (unsigned)j;
+  for (int j = j_begin + tid; j < j_end; j += 256) {
+    float v = r[j];
+    for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];  // slice chains added in slice order
+    unsigned long long key = ((unsigned long long)order_key(v, true) << 32) | (unsigned)j;
 #pragma unroll
     for (int s = 0; s < NMAX; ++s) {  // sorted insertion (ascending keys = best first)
       const unsigned long long lo = key < best[s] ? key : best[s];
@@ -210,11 +221,15 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __res
     b = wbest[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) b = wbest[w] < b ? wbest[w] : b;
-    if (tid == 0) {
+    if (tid == 0 && cand_out) {
+      cand_out[((size_t)row * nsplit + split) * n_top + s] = b;
+    } else if (tid == 0) {
       if (b != ~0ull) {
         const int j = (int)(b & 0xffffffffu);
+        float v = r[j];
+        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
         out_idx[(size_t)row * n_top + s] = j;
-        out_val[(size_t)row * n_top + s] = r[j];
+        out_val[(size_t)row * n_top + s] = v;
       } else {
         out_idx[(size_t)row * n_top + s] = -1;
         out_val[(size_t)row * n_top + s] = -INFINITY;
@@ -225,16 +240,53 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __res
   }
 }
 
+// Phase B of the split top-n: one wave per row merges nsplit * n_top candidate keys (already unique by index).
+__global__ void topn_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, const float* __restrict__ vals, int ld, int rows,
+                                  int n_top, int k_slices, long long slice_stride, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long* c = cand + (size_t)row * ncand;
+  const float* r = vals + (size_t)row * ld;
+  unsigned long long prev = 0;
+  for (int s = 0; s < n_top; ++s) {
+    unsigned long long b = ~0ull;
+    for (int i = lane; i < ncand; i += 64) {
+      const unsigned long long k = c[i];
+      if ((s == 0 || k > prev) && k < b) b = k;
+    }
+    b = wave_min_u64(b);
+    if (lane == 0) {
+      if (b != ~0ull) {
+        const int j = (int)(b & 0xffffffffu);
+        float v = r[j];
+        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
+        out_idx[(size_t)row * n_top + s] = j;
+        out_val[(size_t)row * n_top + s] = v;
+      } else {
+        out_idx[(size_t)row * n_top + s] = -1;
+        out_val[(size_t)row * n_top + s] = -INFINITY;
+      }
+    }
+    prev = b;
+  }
+}
+
 // Strict-order variant: one block per row, the row staged in LDS as (value, index) pairs, one lane replays
 // torch.topk's CPU algorithm (stl_order.hpp).  Rows of up to 20000 elements (160 KiB of LDS).
-__global__ __launch_bounds__(256) void topn_rows_stl_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                            int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+__global__ __launch_bounds__(256) void topn_rows_stl_kernel(float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                            int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                            int k_slices, long long slice_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(smem_raw);
   const int row = blockIdx.x, tid = threadIdx.x;
   const int len = row_len ? row_len[row] : n_default;
-  const float* r = vals + (size_t)row * ld;
-  for (int j = tid; j < len; j += 256) el[j] = stl_order::Elem{r[j], j};
+  float* r = vals + (size_t)row * ld;
+  for (int j = tid; j < len; j += 256) {
+    float v = r[j];
+    for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
+    el[j] = stl_order::Elem{v, j};
+  }
   __syncthreads();
   const int k = min(n_top, len);
   if (tid == 0) stl_order::topk_torch_largest(el, len, k);
@@ -534,8 +586,8 @@ int launch_unpack_best(const unsigned long long* best, long long n, float* d2, i
   return FP_OK;
 }
 
-int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
-                     int* out_ids, int tie_mode, hipStream_t st) {
+int launch_topn_rows(float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
+                     int* out_ids, int tie_mode, int k_slices, long long slice_stride, unsigned long long* cand_scratch, hipStream_t st) {
   if (rows == 0) return FP_OK;
   if (tie_mode == 1) {
     FP_REQUIRE(max_len <= 20000, "strict (torch) tie order supports rows of at most 20000 elements (got %d)", max_len);
@@ -545,10 +597,19 @@ int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_rows_stl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
       attr = 160000;
     }
-    hipLaunchKernelGGL(topn_rows_stl_kernel, dim3(rows), dim3(256), lds, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+    hipLaunchKernelGGL(topn_rows_stl_kernel, dim3(rows), dim3(256), lds, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids, k_slices, slice_stride);
   } else {
     FP_REQUIRE(n_top <= 8, "top-n: n_top must be <= 8 on the canonical block path");
-    hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+    if (cand_scratch && max_len >= 4096) {
+      constexpr int NSPLIT = 16;
+      hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows, NSPLIT), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores,
+                         out_ids, k_slices, slice_stride, cand_scratch);
+      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, NSPLIT * n_top, sims, ld, rows, n_top,
+                         k_slices, slice_stride, out_scores, out_ids);
+    } else {
+      hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids,
+                         k_slices, slice_stride, (unsigned long long*)nullptr);
+    }
   }
   FP_CHECK_LAUNCH("topn_rows");
   return FP_OK;
@@ -558,11 +619,14 @@ int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_de
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st) {
   FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
   FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
-  dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj);
+  dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj, a.k_slices);
   const int nq = cdiv(max_det_per_obj, 16);
   if (nq <= 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), 0, st, a);
   else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("cosine_sims");
-  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st);
+  // candidate keys of the split top-n live behind the 8 slice buffers (scratch contract: 9 slices)
+  unsigned long long* cand = reinterpret_cast<unsigned long long*>(a.sims + 8 * (size_t)num_det * a.ld_sims);
+  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode,
+                          a.k_slices, a.slice_stride, (16 * n_top * 2 <= a.ld_sims) ? cand : nullptr, st);
 }

@@ -129,7 +129,7 @@ def match_batch(
     det_seg = torch.tensor(det_seg_h, dtype=torch.int32, device=dev)
     det_nt = torch.tensor([bank.objects[o].num_templates for o in det_obj], dtype=torch.int32, device=dev)
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
-    sims = torch.empty(B, bank.max_templates, dtype=torch.float32, device=dev)
+    sims = torch.empty(9, B, bank.max_templates, dtype=torch.float32, device=dev)  # k-slice partials; slice 0 = scores
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
     call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),

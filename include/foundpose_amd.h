@@ -59,7 +59,10 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
 /* Template retrieval: cosine similarity of each detection's descriptor against the template descriptors of
  * its object + top-n (tfidf_matching, utils/template_util.py:167-174).  Detections are grouped by object:
  * det_seg_off [num_obj+1] over rows of desc_n, obj_tpl_off [num_obj+1] over rows of bank_n (both
- * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims [num_det, max_templates].  out_scores/out_ids [num_det, n_top]; ids are
+ * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims
+ * [9, num_det, max_templates] (8 k-slice partial scores + candidate keys of the split top-n).  Canonical fp32 summation order of a score:
+ * num_words % 128 == 0: 8 contiguous k-slices, each an fma chain visiting every 16-block of k as
+ * [0,4,8,12,1,5,...,15], slice sums added in slice order; num_words % 16 == 0: one such chain; else k ascending.  out_scores/out_ids [num_det, n_top]; ids are
  * object-local template ids.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of torch.topk on
  * a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows <= 20000 templates). */
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,

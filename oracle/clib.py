@@ -69,8 +69,11 @@ def l2_argmin_cols(q, db):
 def dot_rows(bank, q, perm16=False):
     bank, q = _f(bank), _f(q)
     out = np.empty(bank.shape[0], np.float32)
-    fn = lib().orc_dot_rows_perm16 if perm16 else lib().orc_dot_rows
-    fn(_p(bank), _i64(bank.shape[0]), _i64(bank.shape[1]), _p(q), _p(out))
+    if perm16:
+        slices = 8 if bank.shape[1] % 128 == 0 else 1
+        lib().orc_dot_rows_perm16(_p(bank), _i64(bank.shape[0]), _i64(bank.shape[1]), _p(q), _i64(slices), _p(out))
+    else:
+        lib().orc_dot_rows(_p(bank), _i64(bank.shape[0]), _i64(bank.shape[1]), _p(q), _p(out))
     return out
 
 

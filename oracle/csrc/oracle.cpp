@@ -131,15 +131,22 @@ void orc_dot_rows(const float* bank, int64_t t, int64_t w, const float* q, float
 // order of the MI355X bank-streaming cosine kernel (a lane's 16-byte load feeds four consecutive MFMA k-steps).
 // torch's own cosine_similarity sum order is unspecified (vectorised cascade sum), so any fixed order is a valid
 // restatement; this one is used whenever w % 16 == 0, the ascending one otherwise.
-void orc_dot_rows_perm16(const float* bank, int64_t t, int64_t w, const float* q, float* out) {
+// `slices` contiguous k-slices, each its own chain; the slice results are added in slice order (device: one wave per
+// slice so that every SIMD's fp32 matrix pipe works on the bank stream; 8 slices when w % 128 == 0, else 1).
+void orc_dot_rows_perm16(const float* bank, int64_t t, int64_t w, const float* q, int64_t slices, float* out) {
+  const int64_t ws = w / slices;
 #pragma omp parallel for schedule(static)
   for (int64_t i = 0; i < t; ++i) {
-    float acc = 0.f;
     const float* r = bank + i * w;
-    for (int64_t j = 0; j < w; j += 16)
-      for (int u = 0; u < 4; ++u)
-        for (int g = 0; g < 4; ++g) acc = fmaf(r[j + 4 * g + u], q[j + 4 * g + u], acc);
-    out[i] = acc;
+    float total = 0.f;
+    for (int64_t s = 0; s < slices; ++s) {
+      float acc = 0.f;
+      for (int64_t j = s * ws; j < (s + 1) * ws; j += 16)
+        for (int u = 0; u < 4; ++u)
+          for (int g = 0; g < 4; ++g) acc = fmaf(r[j + 4 * g + u], q[j + 4 * g + u], acc);
+      total = s == 0 ? acc : total + acc;
+    }
+    out[i] = total;
   }
 }
 

@@ -96,7 +96,8 @@ def cosine_scores(template_descs: np.ndarray, query_tfidf: np.ndarray) -> np.nda
     """cosine_similarity(template_descs, tile(query)): normalise each side, then dot."""
     bank_n = l2_normalize_rows(template_descs)
     q_n = l2_normalize_rows(query_tfidf[None, :])[0]
-    # chain order of the device kernel: 16-block permuted order when W % 16 == 0, ascending otherwise
+    # chain order of the device kernel: 16-block permuted order when W % 16 == 0 (8 k-slices when W % 128 == 0),
+    # k ascending otherwise
     return clib.dot_rows(bank_n, q_n, perm16=(bank_n.shape[1] % 16 == 0))
 
 

@@ -141,12 +141,14 @@ def test_strict_template_order_with_duplicate_templates():
         bank_n, q_n = ops.normalize_rows(cu(bank)), ops.normalize_rows(cu(q))
         seg, tpl = cu(np.array([0, Bq], np.int32)), cu(np.array([0, T], np.int32))
         nt = cu(np.full(Bq, T, np.int32))
-        sims = torch.empty(Bq, T, device="cuda")
+        sims = torch.empty(9, Bq, T, device="cuda")
         for mode in (0, 1):
             sc = torch.empty(Bq, 5, device="cuda")
             ids = torch.empty(Bq, 5, dtype=torch.int32, device="cuda")
             call("fp_cosine_topk", ptr(q_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream())
-            s_cpu = sims.cpu()
+            s_cpu = sims[0].cpu()
+            for sl in range(1, 8 if W % 128 == 0 else 1):
+                s_cpu = s_cpu + sims[sl].cpu()  # slice partials added in slice order
             for b in range(Bq):
                 if mode == 1:
                     ref = torch.topk(s_cpu[b], 5, sorted=True)[1]

@@ -54,7 +54,7 @@ def main():
         seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
         tpl = torch.tensor([0, T], dtype=torch.int32, device=dev)
         nt = torch.full((Bq,), T, dtype=torch.int32, device=dev)
-        sims = torch.empty(Bq, T, device=dev)
+        sims = torch.empty(9, Bq, T, device=dev)
         sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
         ms = timeit(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5,
                                  ptr(sims), ptr(sc), ptr(ids), 0, stream()), iters=50)
