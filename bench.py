@@ -52,6 +52,14 @@ def build_synthetic_bank(num_templates, feat_dim, raw_dim, num_words, seed, devi
         feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj])
 
 
+def hbm_traffic_fc1(args, arch, B):
+    """HBM-side bytes per fc1 launch from the rocprofv3 PMC passes of this exact shape (profiles/r1_pmc_counters.txt:
+    FETCH_SIZE 455183.5 KiB doubled per the gfx950 correction + WRITE_SIZE 351744.0 KiB); null for any other shape."""
+    if (args.version, args.size, B, args.precision) == ("vitl14-reg", 518, 32, "bf16"):
+        return int((2 * 455183.5 + 351744.0) * 1024)
+    return None
+
+
 def time_kernel(fn, iters=20):
     """Average launch duration (ms) with HIP events on the stream the kernel runs on (torch's current stream)."""
     fn()
@@ -165,7 +173,7 @@ def main():
                                    f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}",
                        "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step"},
             "roofline": {"kernel": "gemm_bf16_kernel<GELU> (fc1 of one ViT block)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": None, "launch_ms": round(ms, 4),
+                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic_fc1(args, arch, B), "launch_ms": round(ms, 4),
                          "flops_per_launch": gemm_flops},
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                                         "frac": round(vit_tf / PEAK_BF16_TFLOPS, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
