@@ -92,71 +92,81 @@ __global__ void topk_rows_kernel(const float* __restrict__ vals, int rows, int n
 // A lane's float4 covers k = 16j + 4g .. +3 (g = lane>>4), so MFMA step u consumes k = 16j + 4g' + u, g' = 0..3:
 // the per-(template, detection) fp32 fma chain visits each 16-block of k in the order
 // [0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15] -- the canonical order of this stage (oracle: orc_dot_rows_perm16).
-template <int NQ, int U>
-FP_DEVICE void cos_load(f32x4 (&av)[U], float4 (&bv)[NQ][U], const float* ap, const float* const (&bp)[NQ], int chunk) {
+// A-operand (bank) loads of one chunk of U 16-blocks: 16 B per lane, non-temporal (streamed once).
+template <int U>
+FP_DEVICE void cos_load_a(f32x4 (&av)[U], const float* ap, int chunk) {
 #pragma unroll
-  for (int u = 0; u < U; ++u) {
-    av[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 16 * (chunk * U + u)));  // streamed once
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bv[q][u] = *reinterpret_cast<const float4*>(bp[q] + 16 * (chunk * U + u));
-  }
+  for (int u = 0; u < U; ++u) av[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 16 * (chunk * U + u)));
 }
+// MFMAs of one chunk; the query fragments come from the LDS slice image (ds_read_b128, conflict-free: row pitch 1040 B).
+// Accumulators alternate between consecutive MFMAs (dependent latency of 16x16x4 f32 > its issue interval).
 template <int NQ, int U>
-FP_DEVICE void cos_mma(f32x4 (&acc)[NQ], const f32x4 (&av)[U], const float4 (&bv)[NQ][U]) {
-  // accumulators alternate between consecutive MFMAs: the 40-cycle dependent latency of 16x16x4 f32 hides behind
-  // the other detection groups' instructions (32-cycle issue)
+FP_DEVICE void cos_mma(f32x4 (&acc)[NQ], const f32x4 (&av)[U], const char* qs, int chunk, int pitch) {
 #pragma unroll
   for (int u = 0; u < U; ++u) {
+    float4 bv[NQ];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[q][u].x, acc[q], 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) bv[q] = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + (chunk * U + u) * 64);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[q][u].y, acc[q], 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[q].x, acc[q], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[q][u].z, acc[q], 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[q].y, acc[q], 0, 0, 0);
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[q][u].w, acc[q], 0, 0, 0);
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[q].w, acc[q], 0, 0, 0);
   }
 }
 
 template <int NQ>
 __global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char qlds[];  // [NQ*16 detections][wslice floats + 16 B pad]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int obj = blockIdx.y;
   const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
   const int d0 = a.det_seg_off[obj], nd = a.det_seg_off[obj + 1] - d0;
-  const int t0 = (blockIdx.x * 4 + wave) * 16;
-  if (t0 >= T || nd <= 0) return;
-  const int i = lane & 15, g = lane >> 4;
-  const int trow = min(t0 + i, T - 1);
+  if (blockIdx.x * 64 >= T || nd <= 0) return;  // block-uniform
   // K is cut into a.k_slices contiguous slices (blockIdx.z): more waves than SIMDs, so the fp32 matrix pipe of
   // every SIMD works on the stream; the slice chains are summed in slice order by the top-n kernel.
   const int kslice = blockIdx.z, wslice = a.W / a.k_slices;
+  const int pitch = wslice * 4 + 16;
+  // ---- the object's query descriptors (this k-slice) go to LDS once per block, as whole rows (1 KiB per wave
+  // instruction at wslice = 256): per-wave register loads of them cost 2/3 of the kernel's load instructions and the
+  // address path, not HBM, became the limit (profiles/r1_pmc_counters.txt)
+  for (int r = wave; r < NQ * 16; r += 4) {
+    const float* src = a.desc_n + (size_t)(d0 + min(r, nd - 1)) * a.W + kslice * wslice;
+    for (int c = lane * 4; c < wslice; c += 256)
+      *reinterpret_cast<float4*>(qlds + r * pitch + c * 4) = *reinterpret_cast<const float4*>(src + c);
+  }
+  const int t0 = (blockIdx.x * 4 + wave) * 16;
+  const int i = lane & 15, g = lane >> 4;
+  const int trow = min(t0 + i, T - 1);
   const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + kslice * wslice + 4 * g;
-  const float* bp[NQ];
-#pragma unroll
-  for (int q = 0; q < NQ; ++q) bp[q] = a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + kslice * wslice + 4 * g;
+  const char* qs = qlds + i * pitch + g * 16;
   f32x4 acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int nb = wslice / 16;
-  // Software pipeline: chunks of U 16-blocks; chunk c+1's loads are in flight while chunk c's MFMAs run
+  // Software pipeline: chunks of U 16-blocks; chunk c+1's bank loads are in flight while chunk c's MFMAs run
   // (a wave keeps 2 x U KiB of the bank stream outstanding -- what it takes to pull HBM bandwidth without LDS).
   constexpr int U = 8;
   f32x4 a0[U], a1[U];
-  float4 b0[NQ][U], b1[NQ][U];
   const int nch = nb / U;
-  if (nch > 0) cos_load<NQ, U>(a0, b0, ap, bp, 0);
+  const bool active = t0 < T;
+  if (active && nch > 0) cos_load_a<U>(a0, ap, 0);
+  __syncthreads();  // query slice staged
+  if (!active) return;
   for (int c = 0; c < nch; c += 2) {
-    if (c + 1 < nch) cos_load<NQ, U>(a1, b1, ap, bp, c + 1);
-    cos_mma<NQ, U>(acc, a0, b0);
-    if (c + 2 < nch) cos_load<NQ, U>(a0, b0, ap, bp, c + 2);
-    if (c + 1 < nch) cos_mma<NQ, U>(acc, a1, b1);
+    if (c + 1 < nch) cos_load_a<U>(a1, ap, c + 1);
+    cos_mma<NQ, U>(acc, a0, qs, c, pitch);
+    if (c + 2 < nch) cos_load_a<U>(a0, ap, c + 2);
+    if (c + 1 < nch) cos_mma<NQ, U>(acc, a1, qs, c + 1, pitch);
   }
-  for (int j = nch * U; j < nb; ++j) {  // remainder blocks (W not a multiple of 128)
+  for (int j = nch * U; j < nb; ++j) {  // remainder blocks (slice not a multiple of 128 floats)
     const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * j);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(bp[q] + 16 * j);
+      const float4 bv = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + j * 64);
       acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv.x, acc[q], 0, 0, 0);
       acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv.y, acc[q], 0, 0, 0);
       acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv.z, acc[q], 0, 0, 0);
@@ -221,8 +231,16 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict_
     b = wbest[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) b = wbest[w] < b ? wbest[w] : b;
-    if (tid == 0 && cand_out) {
-      cand_out[((size_t)row * nsplit + split) * n_top + s] = b;
+    if (tid == 0 && cand_out) {  // phase A of the split top-n: key + finished score of this split's s-th best
+      const size_t slot = ((size_t)row * nsplit + split) * n_top + s;
+      cand_out[slot] = b;
+      float v = -INFINITY;
+      if (b != ~0ull) {
+        const int j = (int)(b & 0xffffffffu);
+        v = r[j];
+        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
+      }
+      reinterpret_cast<float*>(cand_out + (size_t)gridDim.x * nsplit * n_top)[slot] = v;
     } else if (tid == 0) {
       if (b != ~0ull) {
         const int j = (int)(b & 0xffffffffu);
@@ -240,35 +258,28 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict_
   }
 }
 
-// Phase B of the split top-n: one wave per row merges nsplit * n_top candidate keys (already unique by index).
-__global__ void topn_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, const float* __restrict__ vals, int ld, int rows,
-                                  int n_top, int k_slices, long long slice_stride, float* __restrict__ out_val, int* __restrict__ out_idx) {
+// Phase B of the split top-n: one wave per row merges the nsplit * n_top (<= 128) candidates held in registers.
+__global__ void topn_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
+                                  float* __restrict__ out_val, int* __restrict__ out_idx) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
   const unsigned long long* c = cand + (size_t)row * ncand;
-  const float* r = vals + (size_t)row * ld;
-  unsigned long long prev = 0;
+  const float* cv = reinterpret_cast<const float*>(cand + (size_t)rows * ncand) + (size_t)row * ncand;
+  unsigned long long k0 = lane < ncand ? c[lane] : ~0ull, k1 = lane + 64 < ncand ? c[lane + 64] : ~0ull;
+  const float v0 = lane < ncand ? cv[lane] : 0.f, v1 = lane + 64 < ncand ? cv[lane + 64] : 0.f;
   for (int s = 0; s < n_top; ++s) {
-    unsigned long long b = ~0ull;
-    for (int i = lane; i < ncand; i += 64) {
-      const unsigned long long k = c[i];
-      if ((s == 0 || k > prev) && k < b) b = k;
+    const unsigned long long mine = k0 < k1 ? k0 : k1;
+    const unsigned long long b = wave_min_u64(mine);
+    if (b != ~0ull && mine == b) {  // exactly one lane owns the winner (keys carry the unique column index)
+      out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
+      out_val[(size_t)row * n_top + s] = (k0 == b) ? v0 : v1;
+      if (k0 == b) k0 = ~0ull; else k1 = ~0ull;
     }
-    b = wave_min_u64(b);
-    if (lane == 0) {
-      if (b != ~0ull) {
-        const int j = (int)(b & 0xffffffffu);
-        float v = r[j];
-        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
-        out_idx[(size_t)row * n_top + s] = j;
-        out_val[(size_t)row * n_top + s] = v;
-      } else {
-        out_idx[(size_t)row * n_top + s] = -1;
-        out_val[(size_t)row * n_top + s] = -INFINITY;
-      }
+    if (b == ~0ull && lane == 0) {
+      out_idx[(size_t)row * n_top + s] = -1;
+      out_val[(size_t)row * n_top + s] = -INFINITY;
     }
-    prev = b;
   }
 }
 
@@ -604,8 +615,7 @@ int launch_topn_rows(float* sims, int ld, int rows, int max_len, const int* row_
       constexpr int NSPLIT = 16;
       hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows, NSPLIT), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores,
                          out_ids, k_slices, slice_stride, cand_scratch);
-      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, NSPLIT * n_top, sims, ld, rows, n_top,
-                         k_slices, slice_stride, out_scores, out_ids);
+      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, NSPLIT * n_top, rows, n_top, out_scores, out_ids);
     } else {
       hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids,
                          k_slices, slice_stride, (unsigned long long*)nullptr);
@@ -620,13 +630,22 @@ int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_de
   FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
   FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
   dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj, a.k_slices);
-  const int nq = cdiv(max_det_per_obj, 16);
-  if (nq <= 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), 0, st, a);
-  else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), 0, st, a);
+  const int nq = cdiv(max_det_per_obj, 16) <= 1 ? 1 : (cdiv(max_det_per_obj, 16) == 2 ? 2 : 4);
+  const size_t lds = (size_t)nq * 16 * ((size_t)a.W / a.k_slices * 4 + 16);
+  FP_REQUIRE(lds <= 160 * 1024, "cosine_topk: query slice does not fit LDS (num_words %d)", a.W);
+  static bool attr = false;
+  if (!attr) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr = true;
+  }
+  if (nq == 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), lds, st, a);
+  else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), lds, st, a);
   FP_CHECK_LAUNCH("cosine_sims");
   // candidate keys of the split top-n live behind the 8 slice buffers (scratch contract: 9 slices)
   unsigned long long* cand = reinterpret_cast<unsigned long long*>(a.sims + 8 * (size_t)num_det * a.ld_sims);
   return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode,
-                          a.k_slices, a.slice_stride, (16 * n_top * 2 <= a.ld_sims) ? cand : nullptr, st);
+                          a.k_slices, a.slice_stride, (16 * n_top * 3 <= a.ld_sims && 16 * n_top <= 128) ? cand : nullptr, st);
 }
