@@ -128,6 +128,51 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     }
   }
 
+  } else if constexpr (PIPE == 5) {
+    // ---- double-buffered BK=64, k-steps fused in pairs: 12 fragment reads, then 16 MFMAs.  With two waves per SIMD
+    // one wave's MFMA burst (16 x ~24 cycles when the pipe alternates waves) is long enough to cover the partner's
+    // LDS read latency, so the two waves settle into anti-phase instead of both idling on lgkmcnt.
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW, PCS = A_I + B_I;
+    constexpr int STG = (BM + BN) * BK * 2;
+    const int nk = a.K / BK;
+    auto piece = [&](int q, int t) {
+      char* buf = smem + (t & 1) * STG;
+      if (q < A_I) stage_rows(a.A, a.lda, m0, t * BK, buf, wave * A_I + q, lane);
+      else stage_rows(a.W, a.ldw, n0, t * BK, buf + BM * BK * 2, wave * B_I + (q - A_I), lane);
+    };
+#pragma unroll
+    for (int q = 0; q < PCS; ++q) piece(q, 0);
+    for (int t = 0; t < nk; ++t) {
+      __syncthreads();
+      const char* As = smem + (t & 1) * STG;
+      const char* Ws = As + BM * BK * 2;
+      const bool more = t + 1 < nk;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (more) {
+#pragma unroll
+          for (int q = 0; q < PCS / 2; ++q) piece(half * (PCS / 2) + q, t + 1);
+        }
+        bf16x8 af[2][TM], wf[2][TN];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int chunk = (half * 2 + s2) * 2 + kh;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[s2][i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) wf[s2][j] = read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+      }
+    }
   } else if constexpr (PIPE == 2) {
     // ---- double-buffered BK=64 with the fragment reads software-pipelined one k-step ahead ACROSS the tile
     // boundary: the per-tile barrier (and the first LDS reads of the next tile) sit in front of the last
@@ -447,16 +492,19 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   const int force = a.tile_override;
   const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
   const bool use_big = force == 256 || (force == 0 && big_ok && (a.M / 256) * (a.N / 256) >= 256);
-  // pipe_override: 0 = default (double buffer, measured best), 1 = same, 2 = ring of BK=32 sub-stages, 3 = software-pipelined
-  const int pv = a.pipe_override == 2 ? 1 : (a.pipe_override == 3 ? 2 : 0);
+  // pipe_override: 0 = default (paired k-steps), 1 = plain double buffer, 2 = ring of BK=32 sub-stages,
+  // 3 = software-pipelined fragment reads, 4 = paired k-steps
+  const int pv = a.pipe_override == 1 ? 0 : (a.pipe_override == 2 ? 1 : (a.pipe_override == 3 ? 2 : 5));
   if (use_big && big_ok) {
     if (pv == 0) return launch_cfg<EPI, 256, 256, 2, 4, 0>(a, st);
     if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);
+    if (pv == 5) return launch_cfg<EPI, 256, 256, 2, 4, 5>(a, st);
     return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, st);
   }
   if (force == 384 && a.N % 256 == 0) return launch_cfg<EPI, 128, 256, 2, 2, 4>(a, st);  // 4 waves, 72 KiB ring: 2 workgroups per CU
   if (pv == 0) return launch_cfg<EPI, 128, 128, 2, 2, 0>(a, st);
   if (pv == 1) return launch_cfg<EPI, 128, 128, 2, 2, 1>(a, st);
+  if (pv == 5) return launch_cfg<EPI, 128, 128, 2, 2, 5>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, st);
 }
 
