@@ -71,10 +71,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, kh = lane >> 5;
 
-  const unsigned tiles_n = a.N / BN;
   const unsigned nwg = gridDim.x;
   const unsigned lid = xcd_remap(blockIdx.x, nwg);
-  const int m0 = (lid / tiles_n) * BM, n0 = (lid % tiles_n) * BN;
+  int m0, n0;
+  if (a.tail_parent_tile == 0) {
+    const unsigned tiles_n = a.N / BN, id = lid + a.tile_id_offset;
+    m0 = (id / tiles_n) * BM;
+    n0 = (id % tiles_n) * BN;
+  } else {
+    // tail launch: this grid covers the parent tiles [tile_id_offset, ...) of a (tail_parent_tile)^2 tiling,
+    // each cut into (tail_parent_tile / BM) x (tail_parent_tile / BN) tiles of this kernel's size
+    const unsigned pt = a.tail_parent_tile, sm = pt / BM, sn = pt / BN, per = sm * sn;
+    const unsigned parent = a.tile_id_offset + lid / per, sub = lid % per;
+    const unsigned ptiles_n = a.N / pt;
+    m0 = (parent / ptiles_n) * pt + (sub / sn) * BM;
+    n0 = (parent % ptiles_n) * pt + (sub % sn) * BN;
+  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -470,8 +482,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 }
 
 template <int EPI, int BM, int BN, int WM, int WN, int PIPE>
-int launch_cfg(const GemmBf16Args& a, hipStream_t st) {
-  const unsigned grid = (a.M / BM) * (a.N / BN);
+int launch_cfg(const GemmBf16Args& a, hipStream_t st, unsigned grid_override = 0) {
+  const unsigned grid = grid_override ? grid_override : (a.M / BM) * (a.N / BN);
   // 2 x BK=64 stages == 4 x BK=32 sub-stages; PIPE 3 / 4: ring of 2 / 3 sub-stages
   const size_t lds = (size_t)(BM + BN) * 64 * (PIPE == 3 ? 2 : (PIPE == 4 ? 3 : 4));
   static bool attr = false;
@@ -495,6 +507,19 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   // pipe_override: 0 = default (paired k-steps), 1 = plain double buffer, 2 = ring of BK=32 sub-stages,
   // 3 = software-pipelined fragment reads, 4 = paired k-steps
   const int pv = a.pipe_override == 1 ? 0 : (a.pipe_override == 2 ? 1 : (a.pipe_override == 3 ? 2 : 5));
+  if (use_big && big_ok && pv == 5 && a.tail_split) {  // measured 2-5 % SLOWER than one launch on the ViT-L shapes: off by default
+    // Tail balancing: 256^2 tiles for whole rounds of 256 CUs, the leftover parent tiles as 128^2 tiles at two
+    // workgroups per CU (a partial last round of big tiles otherwise idles up to 255 CUs for a full tile time).
+    const unsigned tiles = (a.M / 256) * (a.N / 256), full = tiles / 256 * 256, rest = tiles - full;
+    if (full > 0 && rest > 0) {
+      int rc = launch_cfg<EPI, 256, 256, 2, 4, 5>(a, st, full);
+      if (rc != FP_OK) return rc;
+      GemmBf16Args t = a;
+      t.tile_id_offset = full;
+      t.tail_parent_tile = 256;
+      return launch_cfg<EPI, 128, 128, 2, 2, 5>(t, st, rest * 4);
+    }
+  }
   if (use_big && big_ok) {
     if (pv == 0) return launch_cfg<EPI, 256, 256, 2, 4, 0>(a, st);
     if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);

@@ -142,8 +142,8 @@ class DinoFeatureExtractor(torch.nn.Module):
             a, dev = self.arch, self._device
             adt = torch.bfloat16 if self.precision == "bf16" else torch.float32
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
-            m_pad = (B * ntok + 127) // 128 * 128
-            mp_pad = (B * np_ + 127) // 128 * 128
+            m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
+            mp_pad = (B * np_ + 255) // 256 * 256
             vt_ld = (ntok + 63) // 64 * 64
             bufs = [
                 torch.zeros(mp_pad, self._model.patch_k_pad, dtype=adt, device=dev),
