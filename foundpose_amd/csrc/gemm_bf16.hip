@@ -11,6 +11,8 @@
 //   * operands are fed to the MFMA swapped (W as the "A" operand) so each lane ends up with 4 consecutive
 //     output columns of one row: 8-byte bf16 / 16-byte fp32 epilogue accesses
 //   * blockIdx is remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels.
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -140,6 +142,182 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     }
   }
 
+  } else if constexpr (PIPE == 7) {
+    // ---- double-buffered BK=64, paired k-steps, with the next tile's DMA pieces interleaved BETWEEN the MFMAs of the
+    // burst (one piece per two MFMAs): a global_load_lds costs its wave ~100-180 issue cycles, which overlap with the
+    // matrix pipe only while that same wave has MFMAs executing (guide: "MFMA <-> buffer_load interleaved 1:1").
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW, PCS = A_I + B_I;
+    constexpr int STG = (BM + BN) * BK * 2;
+    const int nk = a.K / BK;
+    auto piece = [&](int q, int t) {
+      char* buf = smem + (t & 1) * STG;
+      if (q < A_I) stage_rows(a.A, a.lda, m0, t * BK, buf, wave * A_I + q, lane);
+      else stage_rows(a.W, a.ldw, n0, t * BK, buf + BM * BK * 2, wave * B_I + (q - A_I), lane);
+    };
+#pragma unroll
+    for (int q = 0; q < PCS; ++q) piece(q, 0);
+    for (int t = 0; t < nk; ++t) {
+      __syncthreads();
+      const char* As = smem + (t & 1) * STG;
+      const char* Ws = As + BM * BK * 2;
+      const int tnext = t + 1 < nk ? t + 1 : t;
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        bf16x8 af[2][TM], wf[2][TN];
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const int chunk = (half * 2 + s2) * 2 + kh;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) af[s2][i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) wf[s2][j] = read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
+        }
+        constexpr int NM = 2 * TM * TN;            // MFMAs of this burst
+        constexpr int PER = PCS / 2;               // DMA pieces to place in this burst
+        constexpr int EVERY = NM / PER;            // one piece after every EVERY MFMAs
+#pragma unroll
+        for (int idx = 0; idx < NM; ++idx) {
+          const int s2 = idx / (TM * TN), i = (idx / TN) % TM, j = idx % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+          // (the last tile re-stages itself into the idle buffer: branch-free bursts, 1/nk extra L2 traffic)
+          if ((idx % EVERY) == EVERY - 1 && idx / EVERY < PER) piece(half * PER + idx / EVERY, tnext);
+        }
+#pragma unroll
+        for (int g = 0; g < PER; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, EVERY, 0);  // EVERY MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);      // then one VMEM read (the LDS-DMA piece)
+        }
+      }
+    }
+  } else if constexpr (PIPE == 8) {
+    // ---- as PIPE 7, plus the fragment reads of the second half of a K-tile are issued between the MFMAs of the
+    // first half's burst (one ds_read_b128 per MFMA), so only one of the two LDS read phases per tile is exposed.
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW, PCS = A_I + B_I;
+    constexpr int STG = (BM + BN) * BK * 2;
+    const int nk = a.K / BK;
+    auto piece = [&](int q, int t) {
+      char* buf = smem + (t & 1) * STG;
+      if (q < A_I) stage_rows(a.A, a.lda, m0, t * BK, buf, wave * A_I + q, lane);
+      else stage_rows(a.W, a.ldw, n0, t * BK, buf + BM * BK * 2, wave * B_I + (q - A_I), lane);
+    };
+#pragma unroll
+    for (int q = 0; q < PCS; ++q) piece(q, 0);
+    constexpr int NM = 2 * TM * TN, PER = PCS / 2, EVERY = NM / PER, NF = 2 * (TM + TN);
+    for (int t = 0; t < nk; ++t) {
+      __syncthreads();
+      const char* As = smem + (t & 1) * STG;
+      const char* Ws = As + BM * BK * 2;
+      const int tnext = t + 1 < nk ? t + 1 : t;
+      bf16x8 af[2][2][TM], wf[2][2][TN];  // [half][k-step]
+      auto read_one = [&](int half, int f) {  // f-th fragment (0 .. NF-1) of a half
+        const int s2 = f / (TM + TN), r = f % (TM + TN);
+        const int chunk = (half * 2 + s2) * 2 + kh;
+        if (r < TM) af[half][s2][r] = read_frag(As, wm * (BM / WM) + r * 32 + l31, chunk);
+        else wf[half][s2][r - TM] = read_frag(Ws, wn * (BN / WN) + (r - TM) * 32 + l31, chunk);
+      };
+#pragma unroll
+      for (int f = 0; f < NF; ++f) read_one(0, f);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int idx = 0; idx < NM; ++idx) {
+          const int s2 = idx / (TM * TN), i = (idx / TN) % TM, j = idx % TN;
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[half][s2][j], af[half][s2][i], acc[i][j], 0, 0, 0);
+          if (half == 0 && idx < NF) read_one(1, idx);
+          if ((idx % EVERY) == EVERY - 1 && idx / EVERY < PER) piece(half * PER + idx / EVERY, tnext);
+        }
+        if (half == 0) {
+#pragma unroll
+          for (int g = 0; g < NM; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // 1 MFMA
+            if (g < NF) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);          // 1 DS read
+            if ((g % EVERY) == EVERY - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // 1 VMEM read (DMA piece)
+          }
+        } else {
+#pragma unroll
+          for (int g = 0; g < PER; ++g) {
+            __builtin_amdgcn_sched_group_barrier(0x008, EVERY, 0);
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
+      }
+    }
+  } else if constexpr (PIPE == 6) {
+    // ---- role-split schedule (needs WM == 2: wave w and w + NW/2 share a SIMD).  The two wave rows run one barrier
+    // apart: in every barrier interval ("slot") one row issues its 16 MFMAs of a half K-tile while the other row
+    // does its LDS fragment reads (+ the DMA issue) for the next half, then they swap.  The matrix pipe of each SIMD
+    // always has exactly one wave feeding it and the LDS latency of the other wave is off the critical path
+    // (guide section 5: 8-phase idea, here with 4 slots per K-tile and 32x32x16 MFMAs).
+    //   row 0: slot 4t: L0(t)  4t+1: C0(t)  4t+2: L1(t)  4t+3: C1(t)
+    //   row 1: slot 4t+1: L0(t) ...                                  4t+4: C1(t)
+    //   DMA of tile u is issued by every wave in slot 4u-4 (stage u&1 was last read in slot 4u-5) and waited for
+    //   (vmcnt(0)) right before the barrier that ends slot 4u-1.
+    static_assert(WM == 2, "role-split schedule assumes two wave rows");
+    constexpr int A_I = BM / 8 / NW, B_I = BN / 8 / NW;
+    constexpr int STG = (BM + BN) * BK * 2;
+    const int nk = a.K / BK;
+    const int grp = wm;  // wave row = role group
+    auto issue_tile = [&](int t) {
+      char* buf = smem + (t & 1) * STG;
+#pragma unroll
+      for (int q = 0; q < A_I; ++q) stage_rows(a.A, a.lda, m0, t * BK, buf, wave * A_I + q, lane);
+#pragma unroll
+      for (int q = 0; q < B_I; ++q) stage_rows(a.W, a.ldw, n0, t * BK, buf + BM * BK * 2, wave * B_I + q, lane);
+    };
+    bf16x8 af[2][TM], wf[2][TN];
+    auto load_half = [&](const char* As, int half) {
+      const char* Ws = As + BM * BK * 2;
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int chunk = (half * 2 + s2) * 2 + kh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[s2][i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) wf[s2][j] = read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments in registers before the hand-over barrier
+    };
+    auto compute_half = [&]() {
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[s2][j], af[s2][i], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_s_setprio(0);
+    };
+    // prologue: tile 0 by everyone; row 1 also issues tile 1 now (its regular slot would be "slot 0", which it idles)
+    issue_tile(0);
+    if (grp == 1 && nk > 1) {
+      issue_tile(1);
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_I + B_I) : "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();                 // slot 0 starts: tile 0 is in LDS
+    if (grp == 1) __builtin_amdgcn_s_barrier();   // row 1 runs one slot behind
+    for (int t = 0; t < nk; ++t) {
+      const char* As = smem + (t & 1) * STG;
+      // ---- L0(t)
+      if (grp == 0 && t + 1 < nk) issue_tile(t + 1);          // slot 4t = 4(t+1)-4
+      load_half(As, 0);
+      __builtin_amdgcn_s_barrier();
+      // ---- C0(t)
+      compute_half();
+      __builtin_amdgcn_s_barrier();
+      // ---- L1(t)
+      load_half(As, 1);
+      if (grp == 1 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // row 1 is in slot 4t+3 = 4(t+1)-1
+      __builtin_amdgcn_s_barrier();
+      // ---- C1(t)
+      if (grp == 1 && t + 2 < nk) issue_tile(t + 2);          // row 1's C1(t) is slot 4t+4 = 4(t+2)-4
+      compute_half();
+      if (grp == 0 && t + 1 < nk) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // row 0 is in slot 4t+3 = 4(t+1)-1
+      __builtin_amdgcn_s_barrier();
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();   // balance row 1's extra barrier
   } else if constexpr (PIPE == 5) {
     // ---- double-buffered BK=64, k-steps fused in pairs: 12 fragment reads, then 16 MFMAs.  With two waves per SIMD
     // one wave's MFMA burst (16 x ~24 cycles when the pipe alternates waves) is long enough to cover the partner's
@@ -504,9 +682,15 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   const int force = a.tile_override;
   const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
   const bool use_big = force == 256 || (force == 0 && big_ok && (a.M / 256) * (a.N / 256) >= 256);
-  // pipe_override: 0 = default (paired k-steps), 1 = plain double buffer, 2 = ring of BK=32 sub-stages,
-  // 3 = software-pipelined fragment reads, 4 = paired k-steps
-  const int pv = a.pipe_override == 1 ? 0 : (a.pipe_override == 2 ? 1 : (a.pipe_override == 3 ? 2 : 5));
+  // pipe_override: 0 / 1 = default: plain double buffer (DMA of tile t+1 issued in 4 slices between the k-steps).
+  // Alternatives kept for A/B: 2 = ring of BK=32 sub-stages with counted vmcnt, 3 = software-pipelined fragment reads,
+  // 4 = paired k-steps, 5 = role-split wave rows, 6 = DMA pieces interleaved between the MFMAs, 7 = 6 + fragment reads
+  // interleaved.  In isolation 6 is 5-8 % faster on random operands; inside the ViT pipeline all of them land within
+  // 1.5 % of each other (whole-pipeline A/B on one box: 899 / 888 / 885 detections/s for 1 / 6 / 4).
+  // FP_GEMM_PIPE (read once) overrides the default main loop for whole-pipeline A/B runs
+  static const int env_pipe = getenv("FP_GEMM_PIPE") ? atoi(getenv("FP_GEMM_PIPE")) : 0;
+  const int po = a.pipe_override ? a.pipe_override : env_pipe;
+  const int pv = po == 1 ? 0 : (po == 2 ? 1 : (po == 3 ? 2 : (po == 5 ? 6 : (po == 4 ? 5 : (po == 7 ? 8 : 7)))));
   if (use_big && big_ok && pv == 5 && a.tail_split) {  // measured 2-5 % SLOWER than one launch on the ViT-L shapes: off by default
     // Tail balancing: 256^2 tiles for whole rounds of 256 CUs, the leftover parent tiles as 128^2 tiles at two
     // workgroups per CU (a partial last round of big tiles otherwise idles up to 255 CUs for a full tile time).
@@ -524,12 +708,16 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
     if (pv == 0) return launch_cfg<EPI, 256, 256, 2, 4, 0>(a, st);
     if (pv == 1) return launch_cfg<EPI, 256, 256, 2, 4, 1>(a, st);
     if (pv == 5) return launch_cfg<EPI, 256, 256, 2, 4, 5>(a, st);
+    if (pv == 6) return launch_cfg<EPI, 256, 256, 2, 4, 6>(a, st);
+    if (pv == 7) return launch_cfg<EPI, 256, 256, 2, 4, 7>(a, st);
+    if (pv == 8) return launch_cfg<EPI, 256, 256, 2, 4, 8>(a, st);
     return launch_cfg<EPI, 256, 256, 2, 4, 2>(a, st);
   }
   if (force == 384 && a.N % 256 == 0) return launch_cfg<EPI, 128, 256, 2, 2, 4>(a, st);  // 4 waves, 72 KiB ring: 2 workgroups per CU
   if (pv == 0) return launch_cfg<EPI, 128, 128, 2, 2, 0>(a, st);
   if (pv == 1) return launch_cfg<EPI, 128, 128, 2, 2, 1>(a, st);
-  if (pv == 5) return launch_cfg<EPI, 128, 128, 2, 2, 5>(a, st);
+  if (pv == 7 || pv == 8) return launch_cfg<EPI, 128, 128, 2, 2, 7>(a, st);
+  if (pv == 5 || pv == 6) return launch_cfg<EPI, 128, 128, 2, 2, 5>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, 2>(a, st);
 }
 
