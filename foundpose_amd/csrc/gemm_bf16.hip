@@ -690,7 +690,7 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   // FP_GEMM_PIPE (read once) overrides the default main loop for whole-pipeline A/B runs
   static const int env_pipe = getenv("FP_GEMM_PIPE") ? atoi(getenv("FP_GEMM_PIPE")) : 0;
   const int po = a.pipe_override ? a.pipe_override : env_pipe;
-  const int pv = po == 1 ? 0 : (po == 2 ? 1 : (po == 3 ? 2 : (po == 5 ? 6 : (po == 4 ? 5 : (po == 7 ? 8 : 7)))));
+  const int pv = po == 2 ? 1 : (po == 3 ? 2 : (po == 4 ? 5 : (po == 5 ? 6 : (po == 6 ? 7 : (po == 7 ? 8 : 0)))));
   if (use_big && big_ok && pv == 5 && a.tail_split) {  // measured 2-5 % SLOWER than one launch on the ViT-L shapes: off by default
     // Tail balancing: 256^2 tiles for whole rounds of 256 CUs, the leftover parent tiles as 128^2 tiles at two
     // workgroups per CU (a partial last round of big tiles otherwise idles up to 255 CUs for a full tile time).
