@@ -200,7 +200,7 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   epilogue &= 0xff;
   FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384, "fp_gemm_bf16: bad tile override %d", tile);
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
-                 epilogue == GEMM_EPI_BIAS_F32,
+                 epilogue == GEMM_EPI_BIAS_F32 || epilogue == GEMM_EPI_SWIGLU_BF16,
              "fp_gemm_bf16: epilogue %d is not available through this entry point", epilogue);
   FP_REQUIRE(epilogue != GEMM_EPI_LS_RESID_F32 || gamma, "fp_gemm_bf16: gamma required");
   GemmBf16Args a;
@@ -229,7 +229,7 @@ int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, 
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_f32: null pointer");
   FP_REQUIRE(epilogue == F32_EPI_STORE || epilogue == F32_EPI_BIAS || epilogue == F32_EPI_BIAS_GELU ||
-                 epilogue == F32_EPI_LS_RESID || epilogue == F32_EPI_SUB_VEC,
+                 epilogue == F32_EPI_LS_RESID || epilogue == F32_EPI_SUB_VEC || epilogue == F32_EPI_SWIGLU,
              "fp_gemm_f32: epilogue %d is not available through this entry point", epilogue);
   FP_REQUIRE(epilogue != F32_EPI_LS_RESID || gamma, "fp_gemm_f32: gamma required");
   if (M == 0) return FP_OK;
@@ -258,10 +258,6 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
                    int layer, fp_stream_t stream) {
   FP_REQUIRE(m && ws && images && m->blocks, "fp_vit_forward: null pointer");
   FP_REQUIRE(layer >= 0 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);
-  if (m->ffn_swiglu) {
-    fp_set_error("fp_vit_forward: SwiGLU FFN (ViT-g) is not implemented yet");
-    return FP_ERR_UNSUPPORTED;
-  }
   FP_REQUIRE(H % m->patch == 0 && W % m->patch == 0, "fp_vit_forward: image size must be a multiple of the patch size");
   const int D = m->dim, np = (H / m->patch) * (W / m->patch), ntok = 1 + m->registers + np;
   const int Mtok = B * ntok, Mp = B * np;
@@ -317,10 +313,16 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     ln.weight = b.ln2_w; ln.bias = b.ln2_b;
     TRY(layernorm_launch(ln, st));
     if (bf) {
-      TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
+      if (m->ffn_swiglu)  // fc1_w = w12 with rows interleaved (x1_j, x2_j); h = silu(x1) * x2
+        TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, stream));
+      else
+        TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
       TRY(fp_gemm_bf16(ws->h, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
     } else {
-      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_BIAS_GELU, stream));
+      if (m->ffn_swiglu)
+        TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, 2 * m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_SWIGLU, stream));
+      else
+        TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_BIAS_GELU, stream));
       TRY(fp_gemm_f32((const float*)ws->h, m->hidden, (const float*)b.fc2_w, m->hidden, Mtok, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, F32_EPI_LS_RESID, stream));
     }
   }

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
         if (j >= b_cnt) continue;
         float bnj = 0.f, bias = 0.f, gam = 1.f;
         if constexpr (EPI == F32_EPI_DIST_STORE) bnj = a.b_sqnorm[b_off + j];
-        if constexpr (EPI == F32_EPI_BIAS || EPI == F32_EPI_BIAS_GELU || EPI == F32_EPI_LS_RESID || EPI == F32_EPI_TOKENS)
+        if constexpr (EPI == F32_EPI_BIAS || EPI == F32_EPI_BIAS_GELU || EPI == F32_EPI_LS_RESID || EPI == F32_EPI_TOKENS || EPI == F32_EPI_SWIGLU)
           bias = a.bias ? a.bias[j] : 0.f;
         if constexpr (EPI == F32_EPI_SUB_VEC) bias = a.bias[j];
         if constexpr (EPI == F32_EPI_LS_RESID) gam = a.gamma[j];
@@ -210,6 +210,12 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
             *o = 0.5f * x * (1.f + erff(x * 0.70710678118654752440f));
           } else if constexpr (EPI == F32_EPI_LS_RESID) {
             *o = *o + gam * (v + bias);
+          } else if constexpr (EPI == F32_EPI_SWIGLU) {
+            // adjacent columns (x1_j, x2_j) sit in adjacent lanes: the even lane writes silu(x1) * x2 to column j
+            const float mine = v + bias;
+            const float other = __shfl_xor(mine, 1, 64);
+            if ((j & 1) == 0 && j + 1 < b_cnt)
+              a.out[(size_t)pair * a.out_pair_stride + (size_t)i * a.ldo + (j >> 1)] = mine / (1.f + expf(-mine)) * other;
           } else if constexpr (EPI == F32_EPI_TOKENS) {
             // patch-embed: GEMM row i = b*Np + p  ->  token row b*Ntok + tok_skip + p, plus pos-embed
             const int b = i / a.tok_np, p = i - b * a.tok_np;
@@ -249,6 +255,7 @@ int f32_tile_launch(int epi, const F32TileArgs& a, int max_m, int max_n, int pai
     case F32_EPI_BIAS_GELU: return launch<F32_EPI_BIAS_GELU>(a, max_m, max_n, pairs, st);
     case F32_EPI_LS_RESID: return launch<F32_EPI_LS_RESID>(a, max_m, max_n, pairs, st);
     case F32_EPI_TOKENS: return launch<F32_EPI_TOKENS>(a, max_m, max_n, pairs, st);
+    case F32_EPI_SWIGLU: return launch<F32_EPI_SWIGLU>(a, max_m, max_n, pairs, st);
   }
   fp_set_error("f32_tile: unknown epilogue %d", epi);
   return FP_ERR_INVALID;

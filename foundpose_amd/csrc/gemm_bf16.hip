@@ -466,12 +466,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   // through LDS (free after the main loop) and leaves as whole rows: 16 B per lane, lane-contiguous.
   // bf16 outputs leave through an LDS slab (whole-row 16-B stores: the tail drops from ~15k to ~8k cycles per tile);
   // the fp32 read-modify-write epilogues are bound by the residual traffic itself and stay register-direct.
-  constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_QKV_BF16;
+  constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_QKV_BF16 ||
+                            EPI == GEMM_EPI_SWIGLU_BF16;
   if constexpr (USE_SLAB) {
   constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
   constexpr int ESZ = OUT_F32 ? 4 : 2;
-  constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = BN * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
-  constexpr int CHUNKS_PER_ROW = BN * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
+  constexpr int OUT_COLS = EPI == GEMM_EPI_SWIGLU_BF16 ? BN / 2 : BN;  // SwiGLU folds column pairs
+  constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = OUT_COLS * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
+  constexpr int CHUNKS_PER_ROW = OUT_COLS * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
   static_assert(SLAB_ROWS * SLAB_STRIDE <= (BM + BN) * 64 * (PIPE == 3 ? 2 : (PIPE == 4 ? 3 : 4)), "slab must fit the main-loop LDS");
   float4 bias[TN][4], gam[TN][4];
 #pragma unroll
@@ -525,7 +527,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 gm = gam[tn][g];
           v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
         }
-        if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
+        if constexpr (EPI == GEMM_EPI_SWIGLU_BF16) {
+          const float h0 = v0 / (1.f + __builtin_amdgcn_exp2f(-v0 * 1.44269504088896340736f)) * v1;  // silu(x1) * x2
+          const float h1 = v2 / (1.f + __builtin_amdgcn_exp2f(-v2 * 1.44269504088896340736f)) * v3;
+          *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
+        } else if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
         else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
       }
     __syncthreads();
@@ -559,7 +565,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       if (!ok[it]) continue;
       const char* sp = smem + r * SLAB_STRIDE + c * 16;
       if constexpr (!OUT_F32) {
-        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + n0 + c * 8) = *reinterpret_cast<const uint4*>(sp);
+        const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 8;
+        *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
       } else {
         float4 v = *reinterpret_cast<const float4*>(sp);
         if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32) {
@@ -736,6 +743,7 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
     case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
     case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
     case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);
+    case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16>(a, st);
   }
   fp_set_error("gemm_bf16: unknown epilogue %d", epi);
   return FP_ERR_INVALID;

@@ -13,6 +13,7 @@ enum : int {
   F32_EPI_BIAS_GELU = 5,    // out = gelu_erf(acc + bias[j])
   F32_EPI_LS_RESID = 6,     // out += gamma[j] * (acc + bias[j])
   F32_EPI_TOKENS = 7,       // patch-embed scatter into the token sequence (+ pos-embed)
+  F32_EPI_SWIGLU = 8,       // columns interleaved (x1_j, x2_j): out[:, j] = silu(acc_2j + b_2j) * (acc_2j+1 + b_2j+1)
 };
 
 struct F32TileArgs {
@@ -80,6 +81,7 @@ enum : int {
   GEMM_EPI_LS_RESID_F32 = 3,  // out(f32) += gamma * (acc + bias)      (LayerScale + residual)
   GEMM_EPI_TOKENS_F32 = 4,    // patch-embed rows scattered into the token sequence (+ bias + pos-embed)
   GEMM_EPI_BIAS_F32 = 5,      // out(f32) = acc + bias
+  GEMM_EPI_SWIGLU_BF16 = 6,   // SwiGLU FFN: columns interleaved (x1_j, x2_j) -> out(bf16)[:, j] = silu(x1_j) * x2_j, [M, N/2]
 };
 
 struct GemmBf16Args {

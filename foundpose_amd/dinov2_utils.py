@@ -113,6 +113,16 @@ class DinoFeatureExtractor(torch.nn.Module):
             if a.ffn == "mlp":
                 b.fc1_w, b.fc1_b = ptr(mat(p + "mlp.fc1.weight")), ptr(vec(p + "mlp.fc1.bias"))
                 b.fc2_w, b.fc2_b = ptr(mat(p + "mlp.fc2.weight")), ptr(vec(p + "mlp.fc2.bias"))
+            else:
+                # SwiGLU (ViT-g): interleave the rows of w12 as (x1_j, x2_j) so the gate and the value of a hidden unit
+                # land in adjacent GEMM columns and silu(x1) * x2 is a per-lane epilogue
+                w12 = sd[p + "mlp.w12.weight"].to(dev, torch.float32)
+                b12 = sd[p + "mlp.w12.bias"].to(dev, torch.float32)
+                hdn = w12.shape[0] // 2
+                w[p + "w12i"] = torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1).to(wdt).contiguous()
+                w[p + "b12i"] = torch.stack([b12[:hdn], b12[hdn:]], 1).reshape(-1).contiguous()
+                b.fc1_w, b.fc1_b = ptr(w[p + "w12i"]), ptr(w[p + "b12i"])
+                b.fc2_w, b.fc2_b = ptr(mat(p + "mlp.w3.weight")), ptr(vec(p + "mlp.w3.bias"))
         m = _lib.VitModel()
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")

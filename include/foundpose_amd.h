@@ -115,7 +115,8 @@ typedef struct {
 
 typedef struct {
   int dim, depth, heads, hidden, registers, patch;
-  int ffn_swiglu;          /* 1 for ViT-g (not implemented yet -> FP_ERR_UNSUPPORTED) */
+  int ffn_swiglu;          /* 1 for ViT-g: fc1_w/fc1_b hold mlp.w12 with rows INTERLEAVED (x1_j, x2_j) [2*hidden, D],
+                              fc2_w/fc2_b hold mlp.w3 [D, hidden]; h = silu(x1) * x2 is fused into the first GEMM */
   int weight_dtype;        /* FP_BF16 | FP_F32: dtype of the matrices and of the activation buffers */
   const void* patch_w;     /* [D, patch_k_pad]: conv weight flattened (c,py,px), zero padded */
   int patch_k_pad;         /* multiple of 64 */
@@ -155,11 +156,12 @@ int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, 
 int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
                  int out_dtype, int dim, int out_rows, int out_rows_per_img, int in_rows_per_img, int in_skip,
                  fp_stream_t stream);
-/* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32;
+/* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32,
+ * 6 SwiGLU (interleaved column pairs -> [M, N/2] bf16);
  * tuning bits: epilogue | (128 << 8) or | (256 << 8) forces that block tile (default: chosen from the shape) */
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
-/* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual */
+/* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);
 /* qkv [B*N, 3D] (+ vt for bf16) -> out [B*N, D] */

@@ -204,3 +204,27 @@ def test_hot_section_composite_fp32():
         a = dict(zip(c["coord_2d_ids"].cpu().tolist(), c["nn_vertex_ids"].cpu().tolist()))
         b = dict(zip(g[f"coord_2d_ids_{i}"].tolist(), g[f"nn_vertex_ids_{i}"].tolist()))
         assert a == b
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 2e-2)])
+def test_extractor_swiglu_ffn(precision, tol):
+    """ViT-g style blocks (SwiGLU FFN, fused into the w12 GEMM epilogue) vs the oracle."""
+    from foundpose_amd import feature_util
+    from foundpose_amd.vit_config import VitArch
+    arch = VitArch("tinyg-reg", dim=128, depth=2, heads=2, ffn="swiglu", hidden=256, registers=4, pretrain_grid=4,
+                   interp_antialias=True, interp_offset=0.0)
+    sd = synthetic.make_vit_state_dict(arch, seed=5)
+    imgs = synthetic.make_crops(2, 56, seed=3)
+    ex = feature_util.make_feature_extractor("dinov2_version=tinyg-reg_stride=14_facet=token_layer=1_norm=1", state_dict=sd,
+                                             precision=precision, arch=arch).to("cuda")
+    fm = ex(imgs.cuda())["feature_maps"].cpu()
+    ref = ov.extractor_forward(sd, arch, imgs, 1, True, quant="bf16" if precision == "bf16" else None)["feature_maps"]
+    assert rel_err(fm, ref) < tol
+
+
+def test_vitg_shapes_run():
+    """The real ViT-g/14-reg geometry (D=1536, 24 heads, SwiGLU hidden 4096) runs end to end (2 blocks, 1 crop)."""
+    from foundpose_amd import feature_util
+    ex = feature_util.make_feature_extractor("dinov2_version=vitg14-reg_stride=14_facet=token_layer=1_norm=1", seed=3).to("cuda")
+    fm = ex(synthetic.make_crops(1, 518, seed=0).cuda())["feature_maps"]
+    assert fm.shape == (1, 1536, 37, 37) and bool(torch.isfinite(fm).all())
