@@ -195,10 +195,9 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_bf16: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;  // tuning bits: force the 128 or 256 block tile
-  const int pipe = (epilogue >> 20) & 0x7;   // tuning bits: main-loop variant
-  const int tail = (epilogue >> 23) & 1;     // tuning bit: enable the tail-balancing second launch
   epilogue &= 0xff;
-  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 384, "fp_gemm_bf16: bad tile override %d", tile);
+  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_bf16: bad tile override %d", tile);
+
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
                  epilogue == GEMM_EPI_BIAS_F32 || epilogue == GEMM_EPI_SWIGLU_BF16,
              "fp_gemm_bf16: epilogue %d is not available through this entry point", epilogue);
@@ -208,8 +207,6 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
   a.tile_override = tile;
-  a.pipe_override = pipe;
-  a.tail_split = tail;
   a.dbg = reinterpret_cast<unsigned long long*>(getenv("FP_GEMM_DBG_PTR") ? strtoull(getenv("FP_GEMM_DBG_PTR"), nullptr, 0) : 0ull);
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }

@@ -96,9 +96,6 @@ struct GemmBf16Args {
   __bf16* vt; int vt_ld; int vit_dim;
   int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
-  unsigned tile_id_offset, tail_parent_tile;  // internal: sub-range launches (tail balancing)
-  int tail_split;             // 1 = leftover 256^2 tiles of a partial last round run as 128^2 tiles in a second launch
-  int pipe_override;          // 0 = default (ring of BK=32 sub-stages), 1 = double-buffered BK=64
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);

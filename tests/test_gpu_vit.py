@@ -35,21 +35,18 @@ def test_layernorm():
         assert torch.equal(y16, y32.to(torch.bfloat16)) or rel_err(y16.float(), ref) < 2 ** -8
 
 
-@pytest.mark.parametrize("pipe", [0, 2, 3, 4, 5, 6, 7])
-@pytest.mark.parametrize("tile", [128, 256, 384])
+@pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (1408, 3072, 1024), (384, 1024, 4096), (128, 128, 640),
                                    (512, 256, 128), (1536, 1024, 1024), (256, 256, 192)])
-def test_gemm_bf16_epilogues(M, N, K, tile, pipe):
+def test_gemm_bf16_epilogues(M, N, K, tile):
     from foundpose_amd import ops as _ops
     if tile == 256 and (M % 256 or N % 256):
         pytest.skip("256 tile needs M, N multiples of 256")
-    if tile == 384 and (N % 256 or pipe != 0):
-        pytest.skip("128x256 tile needs N multiple of 256; single pipeline")
 
     class ops:  # force the block tile through the tuning bits of the epilogue argument
         @staticmethod
         def gemm_bf16(a, w, bias, gamma=None, out=None, epilogue=0, m_valid=None):
-            return _ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epilogue | (tile << 8) | (pipe << 20), m_valid=m_valid)
+            return _ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epilogue | (tile << 8), m_valid=m_valid)
 
     g = torch.Generator().manual_seed(M + N + K)
     a = (torch.randn(M, K, generator=g)).to(torch.bfloat16)

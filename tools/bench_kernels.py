@@ -24,7 +24,6 @@ def timeit(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-PIPES = ["pair64", "dbuf64", "ring32", "swp64", "pair64", "rolesplit", "interleave", "interleave+rd"]
 
 
 def main():
@@ -39,11 +38,9 @@ def main():
             bias = torch.randn(n, device=dev)
             gamma = torch.randn(n, device=dev)
             out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
-            for tile, pipe in ((256, 6), (256, 7), (256, 6), (256, 7)):
-                if True:
-                    for nt in (0,):
-                        ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8) | (pipe << 20) | (nt << 23), m_valid=B * N))
-                        print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile} {PIPES[pipe]} tail_split={nt}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+            for tile in (256, 128):
+                ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
+                print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "attn" in what:
         qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
         vt = torch.zeros(B, D, (N + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)

@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundpose_amd import ops
 what = sys.argv[1] if len(sys.argv) > 1 else "fc2"
 tile = int(sys.argv[2]) if len(sys.argv) > 2 else 256
-pipe = int(sys.argv[3]) if len(sys.argv) > 3 else 0
 B, N, D, H = 32, 1374, 1024, 16
 M = (B * N + 255) // 256 * 256
 dev = "cuda"
@@ -21,5 +20,5 @@ else:
     bias, gamma = torch.randn(n, device=dev), torch.randn(n, device=dev)
     out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
     for _ in range(4):
-        ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8) | (pipe << 20), m_valid=B * N)
+        ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N)
 torch.cuda.synchronize()
