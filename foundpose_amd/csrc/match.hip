@@ -8,6 +8,8 @@
 //                      scatter_add_ in flattened order) + the query side of cosine_similarity (:167)
 //   cyclic_select .... utils/corresp_util.py:49-70,135-155
 //   sample_bilinear .. utils/feature_util.py:100-131 (grid_sample bilinear, zeros, align_corners=False)
+#include <cstdlib>
+
 #include "common.hpp"
 #include "kernels.hpp"
 #include "stl_order.hpp"
@@ -185,6 +187,122 @@ __global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
   }
 }
 
+// Same arithmetic, bank rows staged through LDS by DMA.  The register-direct kernel above reads 16 B per lane from 16
+// different template rows per load instruction (the MFMA operand layout): 64 B-per-row accesses cost the address path
+// four times what whole rows cost, and that -- not HBM -- bounded it at ~2.5 TB/s.  Here one persistent 8-wave
+// workgroup per CU serves one (object, k-slice); each wave streams its 16-template blocks as 4-KiB chunks (16 rows x
+// 256 B, fetched as whole 256-B row segments by four global_load_lds) through a private three-slot LDS ring: two
+// chunks (8 KiB per wave, 64 KiB per CU) are always in flight under the MFMAs of the third, waits are counted vmcnt,
+// and no barrier is needed because a wave only reads what it fetched itself.  The 16-B pieces of a row are XOR-placed
+// by the row index (on the DMA source address) so the per-lane fragment reads hit 16 different bank groups.
+// Fragment contents and MFMA order are those of cosine_sims_kernel: bit-identical scores.
+typedef __attribute__((address_space(3))) void cos_lds_void;
+typedef __attribute__((address_space(1))) const void cos_gbl_cvoid;
+
+template <int NQ>
+__global__ __launch_bounds__(1024) void cosine_stream_kernel(CosineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char qlds[];  // [NQ*16 detections][wslice floats + 16 B] | [waves][3][4 KiB]
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int obj = blockIdx.y;
+  const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
+  const int d0 = a.det_seg_off[obj], nd = a.det_seg_off[obj + 1] - d0;
+  if (T <= 0 || nd <= 0) return;  // block-uniform
+  const int kslice = blockIdx.z, wslice = a.W / a.k_slices;
+  const int pitch = wslice * 4 + 16;
+  const int nwave = blockDim.x >> 6;
+  for (int r = wave; r < NQ * 16; r += nwave) {
+    const float* src = a.desc_n + (size_t)(d0 + min(r, nd - 1)) * a.W + kslice * wslice;
+    for (int c = lane * 4; c < wslice; c += 256)
+      *reinterpret_cast<float4*>(qlds + r * pitch + c * 4) = *reinterpret_cast<const float4*>(src + c);
+  }
+  char* ring = qlds + NQ * 16 * pitch + wave * (3 * 4096);
+  const int nblk = (T + 15) >> 4, nch = wslice >> 6;         // 16-template blocks of the object, 64-word chunks per block
+  const int first = blockIdx.x * nwave + wave, stride = gridDim.x * nwave;
+  const int ntask = first < nblk ? (nblk - first + stride - 1) / stride : 0;
+  const int total = ntask * nch;
+  __syncthreads();  // query slice staged (the only barrier)
+  if (total == 0) return;
+
+  const int i = lane & 15, g = lane >> 4;
+  const float* slice_base = a.bank_n + (size_t)tb * a.W + kslice * wslice;
+  // issue side: (task, chunk) cursor of the next chunk to fetch
+  int it_blk = first, it_ch = 0, it_slot = 0;
+  auto issue = [&]() {
+    const int t0 = it_blk * 16;
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int row = 4 * q4 + g;                     // lane -> (row of the block, physical 16-B slot i)
+      const int piece = i ^ row;                      // logical piece that must land in slot i of this row
+      const float* src = slice_base + (size_t)min(t0 + row, T - 1) * a.W + it_ch * 64 + piece * 4;
+      __builtin_amdgcn_global_load_lds((cos_gbl_cvoid*)src, (cos_lds_void*)(ring + it_slot * 4096 + q4 * 1024), 16, 0, 2 /* nt */);
+    }
+    if (++it_ch == nch) { it_ch = 0; it_blk += stride; }
+    it_slot = it_slot == 2 ? 0 : it_slot + 1;
+  };
+  issue();
+  if (total > 1) issue();
+  if (total > 2) issue();
+
+  f32x4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const char* qs = qlds + i * pitch + g * 16;
+  int blk = first, ch = 0, slot = 0;
+  for (int cc = 0; cc < total; ++cc) {
+    // loads return in order: chunk cc has landed once at most the later chunks' DMAs are outstanding
+    if (cc + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    else if (cc + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // the chunk moves to registers at once, so its slot can be refilled now: all three ring slots (12 KiB per wave,
+    // 96 KiB per CU) are in flight while the MFMAs below run
+    const char* cs = ring + slot * 4096 + i * 256;
+    f32x4 av[4];
+    float4 bv[4][NQ];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(cs + (((4 * j + g) ^ i) << 4));
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) bv[j][q] = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + (ch * 4 + j) * 64);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the slot is handed back
+    if (cc + 3 < total) issue();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // 32 (NQ = 2) back-to-back MFMAs, two alternating accumulator chains
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bv[j][q].x, acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bv[j][q].y, acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bv[j][q].z, acc[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bv[j][q].w, acc[q], 0, 0, 0);
+    }
+    slot = slot == 2 ? 0 : slot + 1;
+    if (++ch == nch) {
+      // D[i = template 4g + r][j = detection lane&15]
+      const int t0 = blk * 16;
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int det = q * 16 + i;
+        if (det < nd) {
+          // a lane holds 4 consecutive templates of one detection: one 16-B store when the row pitch allows it
+          float* o = a.sims + (size_t)kslice * a.slice_stride + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
+          if (t0 + 16 <= T && (a.ld_sims & 3) == 0) {
+            *reinterpret_cast<f32x4*>(o) = acc[q];
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (t0 + 4 * g + r < T) o[r] = acc[q][r];
+          }
+        }
+        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      ch = 0;
+      blk += stride;
+    }
+  }
+}
+
 // Canonical top-n of each row (largest first, ties -> lowest index), one 256-thread block per row:
 // per-thread top-n over a strided slice (registers), then n rounds of block-wide arg-best over the candidates.
 template <int NMAX>
@@ -255,6 +373,63 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict_
     }
     prev = b;
     __syncthreads();
+  }
+}
+
+// Phase A of the split top-n, one WAVE per (row, split): per-lane sorted top-n over a contiguous split (slice chains
+// summed in slice order), then n rounds of wave-wide arg-best over the lanes' heads -- registers and lane shuffles only
+// (the block-wide version above spent its time in 5 x (LDS scan + barrier) rounds).
+template <int NMAX>
+__global__ __launch_bounds__(256) void topn_rows_wave_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                             int n_default, int n_top, int k_slices, long long slice_stride, int nsplit,
+                                                             int rows, unsigned long long* __restrict__ cand_out) {
+  const int row = blockIdx.x, lane = threadIdx.x & 63, split = blockIdx.y * 4 + (threadIdx.x >> 6);
+  if (split >= nsplit) return;
+  const int len = row_len ? row_len[row] : n_default;
+  const float* r = vals + (size_t)row * ld;
+  const int per = (len + nsplit - 1) / nsplit;
+  const int j_begin = split * per, j_end = min(len, j_begin + per);
+  unsigned long long best[NMAX];
+#pragma unroll
+  for (int s = 0; s < NMAX; ++s) best[s] = ~0ull;
+  // the partial scores were written by other XCDs, so every load here is an Infinity-Cache round trip (~1 us): batches
+  // of 4 elements per lane put 4 x k_slices independent loads in flight before the first add
+  for (int j0 = j_begin + lane; j0 < j_end; j0 += 256) {
+    float v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = j0 + 64 * e < j_end ? r[j0 + 64 * e] : 0.f;
+    for (int sl = 1; sl < k_slices; ++sl) {  // slice chains added in slice order
+      float w[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) w[e] = j0 + 64 * e < j_end ? r[(size_t)sl * slice_stride + j0 + 64 * e] : 0.f;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] += w[e];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned long long key = j0 + 64 * e < j_end ? ((unsigned long long)order_key(v[e], true) << 32) | (unsigned)(j0 + 64 * e) : ~0ull;
+#pragma unroll
+      for (int s = 0; s < NMAX; ++s) {  // sorted insertion (ascending keys = best first)
+        const unsigned long long lo = key < best[s] ? key : best[s];
+        key = key < best[s] ? best[s] : key;
+        best[s] = lo;
+      }
+    }
+  }
+  float* cval = reinterpret_cast<float*>(cand_out + (size_t)rows * nsplit * n_top);
+  for (int s = 0; s < n_top; ++s) {
+    const unsigned long long b = wave_min_u64(best[0]);
+    const size_t slot = ((size_t)row * nsplit + split) * n_top + s;
+    if (b == ~0ull) {
+      if (lane == 0) { cand_out[slot] = b; cval[slot] = -INFINITY; }
+    } else if (best[0] == b) {  // exactly one lane owns the winner (keys carry the unique column index)
+      const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits, no reload
+      cand_out[slot] = b;
+      cval[slot] = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+#pragma unroll
+      for (int t = 0; t + 1 < NMAX; ++t) best[t] = best[t + 1];
+      best[NMAX - 1] = ~0ull;
+    }
   }
 }
 
@@ -612,10 +787,10 @@ int launch_topn_rows(float* sims, int ld, int rows, int max_len, const int* row_
   } else {
     FP_REQUIRE(n_top <= 8, "top-n: n_top must be <= 8 on the canonical block path");
     if (cand_scratch && max_len >= 4096) {
-      constexpr int NSPLIT = 16;
-      hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows, NSPLIT), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores,
-                         out_ids, k_slices, slice_stride, cand_scratch);
-      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, NSPLIT * n_top, rows, n_top, out_scores, out_ids);
+      const int nsplit = 128 / n_top < 24 ? 128 / n_top : 24;  // the merge wave holds nsplit * n_top <= 128 candidates
+      hipLaunchKernelGGL(topn_rows_wave_kernel<8>, dim3(rows, cdiv(nsplit, 4)), dim3(256), 0, st, sims, ld, row_len, max_len, n_top,
+                         k_slices, slice_stride, nsplit, rows, cand_scratch);
+      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, nsplit * n_top, rows, n_top, out_scores, out_ids);
     } else {
       hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids,
                          k_slices, slice_stride, (unsigned long long*)nullptr);
@@ -629,23 +804,52 @@ int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_de
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st) {
   FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
   FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
-  dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj, a.k_slices);
   const int nq = cdiv(max_det_per_obj, 16) <= 1 ? 1 : (cdiv(max_det_per_obj, 16) == 2 ? 2 : 4);
-  const size_t lds = (size_t)nq * 16 * ((size_t)a.W / a.k_slices * 4 + 16);
+  const int wslice = a.W / a.k_slices;
+  const size_t lds = (size_t)nq * 16 * ((size_t)wslice * 4 + 16);
   FP_REQUIRE(lds <= 160 * 1024, "cosine_topk: query slice does not fit LDS (num_words %d)", a.W);
   static bool attr = false;
+  static int num_cus = 256;
   if (!attr) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) num_cus = n;
     attr = true;
   }
-  if (nq == 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), lds, st, a);
-  else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), lds, st, a);
+  // FP_COSINE_STREAM=0 (read once): A/B switch back to the register-direct kernel
+  static const int env_stream = getenv("FP_COSINE_STREAM") ? atoi(getenv("FP_COSINE_STREAM")) : 1;
+  if (env_stream && nq <= 2 && wslice % 64 == 0 && lds + 8 * 3 * 4096 <= 160 * 1024) {
+    // one persistent workgroup per CU: the (object, slice) pairs share the CUs evenly.  8..12 waves per workgroup,
+    // whichever splits the 16-template blocks most evenly over the waves (the kernel is close to MFMA-bound, so a
+    // wave with 3 blocks next to waves with 2 costs what the slowest wave costs)
+    const int nblk = cdiv(max_templates, 16);
+    const int per = num_cus / (num_obj * a.k_slices);
+    const int gx = per < 1 ? 1 : (per > cdiv(nblk, 8) ? cdiv(nblk, 8) : per);
+    int nw = 8;
+    double best = 0.0;
+    for (int w = 8; w <= 12; ++w) {
+      if (lds + (size_t)w * 3 * 4096 > 160 * 1024) break;
+      const int slots = gx * w, mx = cdiv(nblk, slots);
+      const double eff = (double)nblk / slots / mx;
+      if (eff >= best) { best = eff; nw = w; }
+    }
+    const size_t lds_stream = lds + (size_t)nw * 3 * 4096;
+    dim3 sgrid(gx, num_obj, a.k_slices);
+    if (nq == 1) hipLaunchKernelGGL(cosine_stream_kernel<1>, sgrid, dim3(nw * 64), lds_stream, st, a);
+    else hipLaunchKernelGGL(cosine_stream_kernel<2>, sgrid, dim3(nw * 64), lds_stream, st, a);
+  } else {
+    dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj, a.k_slices);
+    if (nq == 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), lds, st, a);
+    else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), lds, st, a);
+  }
   FP_CHECK_LAUNCH("cosine_sims");
   // candidate keys of the split top-n live behind the 8 slice buffers (scratch contract: 9 slices)
   unsigned long long* cand = reinterpret_cast<unsigned long long*>(a.sims + 8 * (size_t)num_det * a.ld_sims);
   return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode,
-                          a.k_slices, a.slice_stride, (16 * n_top * 3 <= a.ld_sims && 16 * n_top <= 128) ? cand : nullptr, st);
+                          a.k_slices, a.slice_stride, (24 * n_top * 3 <= a.ld_sims) ? cand : nullptr, st);
 }

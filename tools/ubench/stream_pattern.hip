@@ -20,6 +20,15 @@ __global__ __launch_bounds__(256) void k(const float* __restrict__ a, int T, flo
       f32x4 v = NT ? __builtin_nontemporal_load((const f32x4*)(p + 16 * j)) : *(const f32x4*)(p + 16 * j);
       acc += v;
     }
+  } else if (PAT == 2) {
+    // fully linear: the wave's 16 KiB are one contiguous run (what a [block][slice][16][256] re-layout of the bank gives)
+    const size_t wid = ((size_t)blockIdx.z * gridDim.x + blockIdx.x) * 4 + wave;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float* p = a + wid * 4096 + r * 256 + 4 * lane;
+      f32x4 v = NT ? __builtin_nontemporal_load((const f32x4*)p) : *(const f32x4*)p;
+      acc += v;
+    }
   } else {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -60,5 +69,8 @@ int main() {
   run<0, 1>(b, T2, out, "T=50k: 16 rows x 64 B, nt");
   run<1, 0>(b, T2, out, "T=50k: 1 row x 1 KiB");
   run<1, 1>(b, T2, out, "T=50k: 1 row x 1 KiB, nt");
+  run<2, 0>(b, T2, out, "T=50k: linear 16 KiB per wave");
+  run<2, 1>(b, T2, out, "T=50k: linear 16 KiB per wave, nt");
+  run<2, 0>(a, T, out, "T=10k: linear 16 KiB per wave");
   return 0;
 }
