@@ -9,45 +9,76 @@
 
 namespace {
 
-// One wave per row; the row lives in registers (D/128 float2 per lane, D <= 2048), two-pass mean/var.
-template <int MAXI>
+// One wave per row at a time; the row lives in registers, two-pass mean/var.  Waves are persistent (grid-stride over
+// the rows) and fetch their next row before reducing the current one, so the 12 dependent shuffle steps of the two
+// reductions overlap with HBM latency instead of following it.
+// VEC = floats per lane and access: 4 (16-B loads, 8-B bf16 stores; needs D % 256 == 0: ViT-B/L/g) or 2 (ViT-S).
+template <int VEC>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.out_rows) return;
+  constexpr int MAXI = 2048 / (64 * VEC);
+  typedef __attribute__((ext_vector_type(VEC))) float vec_t;
   const int lane = threadIdx.x & 63;
-  const int img = row / a.out_rows_per_img, p = row - img * a.out_rows_per_img;
-  const float* x = a.x + ((size_t)img * a.in_rows_per_img + a.in_skip + p) * a.ld_x;
-  const int n2 = a.dim >> 7;  // float2 per lane
-  float2 v[MAXI];
-  float s = 0.f;
+  const int wstride = gridDim.x * 4;
+  int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.out_rows) return;
+  const int nv = a.dim / (64 * VEC);  // vectors per lane
+  auto row_ptr = [&](int r) {
+    const int img = r / a.out_rows_per_img, p = r - img * a.out_rows_per_img;
+    return a.x + ((size_t)img * a.in_rows_per_img + a.in_skip + p) * a.ld_x;
+  };
+  vec_t v[MAXI], nx[MAXI];
+  {
+    const float* x = row_ptr(row);
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
-    if (i < n2) {
-      v[i] = *reinterpret_cast<const float2*>(x + (i * 64 + lane) * 2);
-      s += v[i].x + v[i].y;
-    }
-  const float mean = wave_sum(s) / (float)a.dim;
-  float ss = 0.f;
+    for (int i = 0; i < MAXI; ++i)
+      if (i < nv) nx[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
+  }
+  for (; row < a.out_rows; row += wstride) {
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
-    if (i < n2) {
-      const float dx = v[i].x - mean, dy = v[i].y - mean;
-      ss += dx * dx + dy * dy;
-    }
-  const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
+    for (int i = 0; i < MAXI; ++i) v[i] = nx[i];
+    if (row + wstride < a.out_rows) {
+      const float* x = row_ptr(row + wstride);
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
-    if (i < n2) {
-      const int c = (i * 64 + lane) * 2;
-      const float2 w = *reinterpret_cast<const float2*>(a.weight + c);
-      const float2 b = *reinterpret_cast<const float2*>(a.bias + c);
-      const float y0 = (v[i].x - mean) * rstd * w.x + b.x;
-      const float y1 = (v[i].y - mean) * rstd * w.y + b.y;
-      if (a.out_dtype == FP_DTYPE_BF16)
-        *reinterpret_cast<unsigned*>(reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c) = pack_bf16x2(y0, y1);
-      else
-        *reinterpret_cast<float2*>(reinterpret_cast<float*>(a.out) + (size_t)row * a.ld_out + c) = make_float2(y0, y1);
+      for (int i = 0; i < MAXI; ++i)
+        if (i < nv) nx[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
     }
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < nv) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s += v[i][e];
+      }
+    const float mean = wave_sum(s) / (float)a.dim;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < nv) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float d = v[i][e] - mean;
+          ss += d * d;
+        }
+      }
+    const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < nv) {
+        const int c = (i * 64 + lane) * VEC;
+        const vec_t w = *reinterpret_cast<const vec_t*>(a.weight + c);
+        const vec_t b = *reinterpret_cast<const vec_t*>(a.bias + c);
+        vec_t y;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) y[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
+        if (a.out_dtype == FP_DTYPE_BF16) {
+          __bf16* o = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c;
+          if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
+          else *reinterpret_cast<unsigned*>(o) = pack_bf16x2(y[0], y[1]);
+        } else {
+          *reinterpret_cast<vec_t*>(reinterpret_cast<float*>(a.out) + (size_t)row * a.ld_out + c) = y;
+        }
+      }
+  }
 }
 
 // images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
@@ -99,7 +130,12 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   FP_REQUIRE(a.dim % 128 == 0 && a.dim <= 2048, "layernorm: dim must be a multiple of 128 and <= 2048 (got %d)", a.dim);
   FP_REQUIRE(a.ld_x % 2 == 0 && a.ld_out % 2 == 0, "layernorm: leading dims must be even");
   if (a.out_rows == 0) return FP_OK;
-  hipLaunchKernelGGL(layernorm_kernel<16>, dim3(cdiv(a.out_rows, 4)), dim3(256), 0, st, a);
+  const int wgs = cdiv(a.out_rows, 4);
+  const int grid = wgs < 2048 ? wgs : 2048;  // 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
+  if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0)
+    hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, st, a);
+  else
+    hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("layernorm");
   return FP_OK;
 }

@@ -15,10 +15,10 @@ for what in sys.argv[1:] or ["proj", "qkv", "fc2"]:
     grid = (M // 256) * (n // 256)
     dbg = torch.zeros(grid, 4, dtype=torch.int64, device=dev)
     for _ in range(2):
-        ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (256 << 8) | (1 << 20), m_valid=B * N)
+        ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (256 << 8), m_valid=B * N)
     torch.cuda.synchronize()
     os.environ["FP_GEMM_DBG_PTR"] = str(dbg.data_ptr())
-    ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (256 << 8) | (1 << 20), m_valid=B * N)
+    ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (256 << 8), m_valid=B * N)
     torch.cuda.synchronize()
     del os.environ["FP_GEMM_DBG_PTR"]
     t = dbg.cpu().numpy().astype(np.float64)
