@@ -85,6 +85,7 @@ def main():
     ap.add_argument("--layer", type=int, default=18)
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--graph", action="store_true", help="replay the ViT forward as one hipGraph (measured: no gain, the step is GPU-bound: 34.51 vs 34.44 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-detections", type=int, default=3)
     args = ap.parse_args()
@@ -109,7 +110,7 @@ def main():
 
     arch = ARCHS[args.version]
     name = f"dinov2_version={args.version}_stride=14_facet=token_layer={args.layer}_norm=1"
-    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision).to(dev)
+    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
     repres = [build_synthetic_bank(args.templates, 256, arch.dim, 2048, seed=7 + o, device=dev) for o in range(args.objects)]
     repre = repres[0]
     bank = DeviceBank(repres, device=dev)

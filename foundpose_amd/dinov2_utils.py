@@ -41,8 +41,9 @@ def _interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: 
 
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
-                 precision: str = "bf16", arch: Optional[VitArch] = None) -> None:
+                 precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False) -> None:
         super().__init__()
+        self.use_graph = use_graph  # replay the forward's launch sequence as one hipGraph (static buffers per batch shape)
         if arch is not None:  # non-hub architecture (unit tests use a tiny one)
             ARCHS[arch.name] = arch
         spec: ExtractorSpec = parse_extractor_name(model_name)
@@ -67,6 +68,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._blocks = None
         self._grids: Dict[Tuple[int, int], Tuple[torch.Tensor, torch.Tensor]] = {}
         self._ws: Dict[Tuple[int, int, int], Tuple[_lib.VitWorkspace, list]] = {}
+        self._graphs: Dict[Tuple[int, int, int], tuple] = {}
         self.num_patches: Optional[Tuple[int, int]] = None
 
     # ---- device placement (same call pattern as the reference: extractor.to(device))
@@ -133,6 +135,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._w, self._model, self._blocks, self._device = w, m, blocks, dev
         self._grids.clear()
         self._ws.clear()
+        self._graphs.clear()
 
     def _grid_tables(self, gh: int, gw: int):
         key = (gh, gw)
@@ -185,11 +188,41 @@ class DinoFeatureExtractor(torch.nn.Module):
         pos_patch, prefix = self._grid_tables(gh, gw)
         self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
         ws, _ = self._workspace(B, gh, gw)
-        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
-        fmap = torch.empty(B, gh * gw, self.arch.dim, dtype=torch.float32, device=images.device)
-        cls = torch.empty(B, self.arch.dim, dtype=torch.float32, device=images.device)
-        call("fp_vit_features", C.byref(self._model), C.byref(ws), B, gh * gw, int(self.apply_norm), ptr(fmap), ptr(cls), stream())
+        if self.use_graph:
+            fmap, cls = self._forward_graph(images, ws, B, H, W, gh, gw)
+        else:
+            fmap = torch.empty(B, gh * gw, self.arch.dim, dtype=torch.float32, device=images.device)
+            cls = torch.empty(B, self.arch.dim, dtype=torch.float32, device=images.device)
+            self._launch(images, ws, B, H, W, gh, gw, fmap, cls)
         self.num_patches = (gh, gw)
+        return fmap, cls
+
+    def _launch(self, images, ws, B, H, W, gh, gw, fmap, cls) -> None:
+        """The ~125 kernel launches of one forward (C++ launch sequence) on the current stream."""
+        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        call("fp_vit_features", C.byref(self._model), C.byref(ws), B, gh * gw, int(self.apply_norm), ptr(fmap), ptr(cls), stream())
+
+    def _forward_graph(self, images, ws, B, H, W, gh, gw):
+        """hipGraph replay of the launch sequence: one graph launch per batch instead of ~125 kernel launches.
+        Captured once per (B, grid) workspace over static input / output buffers; the returned tensors are those
+        static buffers and are overwritten by the next call with the same batch shape."""
+        key = (B, gh, gw)
+        entry = self._graphs.get(key)
+        if entry is None:
+            dev = images.device
+            img_s = torch.empty_like(images)
+            fmap = torch.empty(B, gh * gw, self.arch.dim, dtype=torch.float32, device=dev)
+            cls = torch.empty(B, self.arch.dim, dtype=torch.float32, device=dev)
+            img_s.copy_(images)
+            self._launch(img_s, ws, B, H, W, gh, gw, fmap, cls)  # warm-up outside capture (function attributes, lazy module load)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._launch(img_s, ws, B, H, W, gh, gw, fmap, cls)
+            entry = self._graphs[key] = (g, img_s, fmap, cls)
+        g, img_s, fmap, cls = entry
+        img_s.copy_(images)
+        g.replay()
         return fmap, cls
 
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:

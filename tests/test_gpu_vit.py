@@ -225,3 +225,16 @@ def test_vitg_shapes_run():
     ex = feature_util.make_feature_extractor("dinov2_version=vitg14-reg_stride=14_facet=token_layer=1_norm=1", seed=3).to("cuda")
     fm = ex(synthetic.make_crops(1, 518, seed=0).cuda())["feature_maps"]
     assert fm.shape == (1, 1536, 37, 37) and bool(torch.isfinite(fm).all())
+
+
+def test_extractor_hipgraph_replay_is_bit_identical():
+    """use_graph=True replays the same launch sequence as one hipGraph: outputs equal the eager launches bit for bit,
+    also on the second replay with new pixels in the static input buffer."""
+    from foundpose_amd import feature_util
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1"
+    eager = feature_util.make_feature_extractor(name, seed=11).to("cuda")
+    graph = feature_util.make_feature_extractor(name, seed=11, use_graph=True).to("cuda")
+    for seed in (0, 1, 2):
+        imgs = synthetic.make_crops(3, 224, seed=seed).cuda()
+        a, b = eager(imgs), graph(imgs)
+        assert torch.equal(a["feature_maps"], b["feature_maps"]) and torch.equal(a["cls_tokens"], b["cls_tokens"])
