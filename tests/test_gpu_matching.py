@@ -306,3 +306,114 @@ def test_engine_batch_equals_per_detection():
             assert torch.equal(s_["coord_3d"], b_["coord_3d"]) and torch.equal(s_["coord_2d"], b_["coord_2d"])
     rec = engine.pack_result(res)
     assert rec.shape == (3, 5 * (3 + 300 * 9))
+
+
+# ------------------------------------------------------------------ full-size properties (BASELINE sizes: T = 10 000, W = 2048)
+def _full_size_bank(T=10000, W=2048, seed=3):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    from foundpose_amd import ops
+    bank = torch.rand(T, W, generator=g, device="cuda") * (torch.rand(T, W, generator=g, device="cuda") < 0.02)  # sparse, like tf-idf
+    bank[:, 0] += 1e-3  # no all-zero rows
+    return ops.normalize_rows(bank)
+
+
+def _cosine_topk(desc_n, bank_n, n_top, tie_mode=0):
+    from foundpose_amd._lib import call, ptr, stream
+    B, W = desc_n.shape
+    T = bank_n.shape[0]
+    seg = torch.tensor([0, B], dtype=torch.int32, device="cuda")
+    off = torch.tensor([0, T], dtype=torch.int32, device="cuda")
+    nt = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    sims = torch.zeros(9, B, T, device="cuda")
+    sc, ids = torch.empty(B, n_top, device="cuda"), torch.empty(B, n_top, dtype=torch.int32, device="cuda")
+    call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, B, ptr(bank_n), ptr(off), 1, T, W, n_top, ptr(sims), ptr(sc), ptr(ids),
+         tie_mode, stream())
+    return sc, ids, sims
+
+
+def test_full_size_retrieval_planted_and_kernel_agreement():
+    """T = 10 000 templates x 2048 words, 32 detections:
+    * a query that IS a bank row comes back first with score 1 (size-independent planted property),
+    * the LDS-streaming kernel (<= 32 detections per object) and the register-direct kernel (taken for 33..64
+      detections) produce bit-identical scores and ids for the same queries,
+    * the top-5 equals a sort of the oracle's canonical chain scores on a sample of rows."""
+    bank_n = _full_size_bank()
+    T, W = bank_n.shape
+    g = torch.Generator().manual_seed(5)
+    planted = torch.randint(0, T, (32,), generator=g)
+    desc_n = bank_n[planted.cuda()].clone()
+    desc_n[16:] = torch.nn.functional.normalize(desc_n[16:] + 0.02 * torch.rand(16, W, device="cuda"), dim=1)  # half of them perturbed
+    from foundpose_amd import ops
+    desc_n = ops.normalize_rows(desc_n)
+    sc, ids, _ = _cosine_topk(desc_n, bank_n, 5)
+    assert torch.equal(ids[:, 0].cpu(), planted.to(torch.int32))
+    assert float((sc[:16, 0] - 1).abs().max()) < 1e-6
+    # same 32 queries inside a 64-detection call -> the other kernel
+    sc2, ids2, _ = _cosine_topk(torch.cat([desc_n, desc_n.flip(0)]), bank_n, 5)
+    assert torch.equal(ids2[:32], ids) and torch.equal(sc2[:32], sc)
+    assert torch.equal(ids2[32:], ids.flip(0)) and torch.equal(sc2[32:], sc.flip(0))
+    # oracle chain (8 k-slices x permuted 16-blocks) on 3 detections
+    bn = bank_n.cpu().numpy()
+    for b in (0, 17, 31):
+        ref = clib.dot_rows(bn, desc_n[b].cpu().numpy(), perm16=True)
+        vals, idx = clib.topk_canonical(ref, 5, True)
+        assert np.array_equal(idx.astype(np.int32), ids[b].cpu().numpy())
+        assert np.array_equal(vals, sc[b].cpu().numpy())
+
+
+def test_full_size_strict_and_canonical_agree_without_ties():
+    """On tie-free scores the reference's torch.topk order and the canonical order are the same list."""
+    bank_n = _full_size_bank(T=10000, seed=9)
+    from foundpose_amd import ops
+    desc_n = ops.normalize_rows(torch.rand(8, bank_n.shape[1], generator=torch.Generator(device="cuda").manual_seed(1), device="cuda"))
+    sc0, ids0, _ = _cosine_topk(desc_n, bank_n, 5, tie_mode=0)
+    sc1, ids1, _ = _cosine_topk(desc_n, bank_n, 5, tie_mode=1)
+    assert torch.equal(ids0, ids1) and torch.equal(sc0, sc1)
+
+
+@pytest.mark.parametrize("T,W,B", [(1, 128, 1), (3, 128, 2), (17, 256, 5), (800, 2048, 33), (129, 192, 7), (16, 2048, 32)])
+def test_retrieval_ragged_shapes_vs_oracle(T, W, B):
+    """Fewer templates than top-n (ids -1 / score -inf past the end), template counts that are not multiples of the
+    16-row block, word counts that take the 1-slice chain, and a detection count that takes the fallback kernel."""
+    g = torch.Generator().manual_seed(T * 7 + W + B)
+    from foundpose_amd import ops
+    bank_n = ops.normalize_rows(torch.rand(T, W, generator=g).cuda())
+    desc_n = ops.normalize_rows(torch.rand(B, W, generator=g).cuda())
+    sc, ids, _ = _cosine_topk(desc_n, bank_n, 5)
+    bn = bank_n.cpu().numpy()
+    for b in range(B):
+        ref = clib.dot_rows(bn, desc_n[b].cpu().numpy(), perm16=(W % 16 == 0))
+        k = min(5, T)
+        vals, idx = clib.topk_canonical(ref, k, True)
+        assert np.array_equal(idx.astype(np.int32), ids[b, :k].cpu().numpy())
+        assert np.array_equal(vals, sc[b, :k].cpu().numpy())
+        assert bool((ids[b, k:] == -1).all()) and bool(torch.isinf(sc[b, k:]).all())
+
+
+def test_match_batch_degenerate_detections():
+    """A detection with a single query patch and one with fewer patches than top-k buddies, next to a normal one:
+    each equals the oracle run alone (the reference would process them one by one, corresp_util.py:73-169)."""
+    from foundpose_amd import repre_util
+    from foundpose_amd.bank import DeviceBank
+    from foundpose_amd.matching import match_batch
+    c, g, r, pts, feats = match_case_inputs("match_planted")
+    repre = repre_util.FeatureBasedObjectRepre(
+        vertices=torch.from_numpy(r["vertices"]), feat_vectors=torch.from_numpy(r["feat_vectors"]),
+        feat_to_template_ids=torch.from_numpy(r["feat_to_template_ids"]),
+        feat_cluster_centroids=torch.from_numpy(r["feat_cluster_centroids"]),
+        feat_cluster_idfs=torch.from_numpy(r["feat_cluster_idfs"]), template_descs=torch.from_numpy(r["template_descs"]),
+        template_desc_opts=repre_util.TemplateDescOpts())
+    bank = DeviceBank([repre])
+    dets = [(pts[:1], feats[:1]), (pts, feats), (pts[5:12], feats[5:12])]
+    qf = torch.from_numpy(np.concatenate([d[1] for d in dets])).cuda()
+    qp = torch.from_numpy(np.concatenate([d[0] for d in dets])).cuda()
+    res = match_batch(bank, qf, qp, [len(d[0]) for d in dets], None, 5, 300)
+    for b, (p, f) in enumerate(dets):
+        ora = om.establish_correspondences(p, f, r, 5, 300, topk_mode="canonical")
+        got = res.corresp_list(b, debug=True)
+        assert [int(x["template_id"]) for x in got] == [o["template_id"] for o in ora]
+        for a, o in zip(got, ora):
+            assert np.array_equal(a["coord_2d_ids"].cpu().numpy(), o["coord_2d_ids"])
+            assert np.array_equal(a["nn_vertex_ids"].cpu().numpy(), o["nn_vertex_ids"])
+            # all cycle distances of a 1-patch detection are 0 -> conf = 1 - 0/0 = NaN, like the reference (corresp_util.py:64)
+            assert np.array_equal(a["coord_conf"].cpu().numpy(), o["coord_conf"], equal_nan=True)

@@ -238,3 +238,25 @@ def test_extractor_hipgraph_replay_is_bit_identical():
         imgs = synthetic.make_crops(3, 224, seed=seed).cuda()
         a, b = eager(imgs), graph(imgs)
         assert torch.equal(a["feature_maps"], b["feature_maps"]) and torch.equal(a["cls_tokens"], b["cls_tokens"])
+
+
+def test_extractor_vitl14reg_518_metric_config_vs_oracle():
+    """The bench configuration (ViT-L/14-reg, layer 18, 518x518): fp32 parity mode and the bf16 path against the CPU
+    oracle on one crop, plus batch invariance of the bf16 path at the metric's batch of 32 (crop 5 of the batch ==
+    that crop run alone, bit for bit)."""
+    arch = ARCHS["vitl14-reg"]
+    name = "dinov2_version=vitl14-reg_stride=14_facet=token_layer=18_norm=1"
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    imgs = synthetic.make_crops(32, 518, seed=0)
+    ref = ov.extractor_forward(sd, arch, imgs[5:6], 18, True)["feature_maps"]
+    from foundpose_amd import feature_util
+    ex32 = feature_util.make_feature_extractor(name, state_dict=sd, precision="fp32").to("cuda")
+    f32 = ex32(imgs[5:6].cuda())["feature_maps"].cpu()
+    assert f32.shape == (1, 1024, 37, 37)
+    assert rel_err(f32, ref) < 5e-5
+    del ex32
+    ex16 = feature_util.make_feature_extractor(name, state_dict=sd, precision="bf16").to("cuda")
+    one = ex16(imgs[5:6].cuda())["feature_maps"].clone()
+    assert rel_err(one.cpu(), ref) < 3e-2
+    batch = ex16(imgs.cuda())["feature_maps"]
+    assert torch.equal(batch[5], one[0])
