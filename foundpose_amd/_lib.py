@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16 = 0, 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -36,8 +36,8 @@ class VitModel(C.Structure):
 
 class VitWorkspace(C.Structure):
     _fields_ = [
-        ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("vt", vp), ("h", vp),
-        ("m_pad", i32), ("m_patch_pad", i32), ("vt_ld", i32),
+        ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp),
+        ("m_pad", i32), ("m_patch_pad", i32),
     ]
 
 
@@ -58,8 +58,7 @@ _PROTOS = {
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "fp_gemm_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
-    "fp_attention": [vp, i32, vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
-    "fp_gemm_qkv_bf16": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "fp_convert_f32_to_bf16": [vp, vp, i64, vp],
 }
 

@@ -211,17 +211,6 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }
 
-int fp_gemm_qkv_bf16(const void* A, int lda, const void* W, int ldw, int M, int M_valid, int dim, const float* bias,
-                     void* qkv, void* vt, int vt_ld, int n_tok, fp_stream_t stream) {
-  FP_REQUIRE(A && W && qkv && vt && bias, "fp_gemm_qkv_bf16: null pointer");
-  GemmBf16Args a;
-  memset(&a, 0, sizeof(a));
-  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
-  a.M = M; a.N = 3 * dim; a.K = dim; a.M_valid = M_valid; a.bias = bias; a.out = qkv; a.ldo = 3 * dim;
-  a.vt = reinterpret_cast<__bf16*>(vt); a.vt_ld = vt_ld; a.vit_dim = dim; a.tok_n = n_tok;
-  return gemm_bf16_launch(GEMM_EPI_QKV_BF16, a, ST(stream));
-}
-
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_f32: null pointer");
@@ -236,11 +225,11 @@ int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, 
   return f32_tile_launch(epilogue, a, M, N, 1, ST(stream));
 }
 
-int fp_attention(const void* qkv, int ld_qkv, const void* vt, int vt_ld, void* out, int ld_out, int B, int n_tok,
+int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok,
                  int dim, int heads, int dtype, fp_stream_t stream) {
   FP_REQUIRE(qkv && out, "fp_attention: null pointer");
   AttnArgs a;
-  a.qkv = qkv; a.ld_qkv = ld_qkv; a.vt = vt; a.vt_ld = vt_ld; a.out = out; a.ld_out = ld_out;
+  a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
   a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads;
   return attn_launch(a, dtype, ST(stream));
 }
@@ -263,7 +252,6 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   FP_REQUIRE(ws->patches && ws->x && ws->y && ws->qkv && ws->h, "fp_vit_forward: workspace buffer missing");
   hipStream_t st = ST(stream);
   const bool bf = m->weight_dtype == FP_DTYPE_BF16;
-  if (bf) FP_REQUIRE(ws->vt && ws->vt_ld % 64 == 0 && ws->vt_ld >= ntok, "fp_vit_forward: V^T workspace missing / too small");
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
   TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, m->weight_dtype, st));
@@ -289,7 +277,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = m->weight_dtype;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
-  at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.vt = ws->vt; at.vt_ld = ws->vt_ld; at.out = ws->y; at.ld_out = D;
+  at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.out = ws->y; at.ld_out = D;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
 
   for (int i = 0; i <= layer; ++i) {
@@ -298,7 +286,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     ln.weight = b.ln1_w; ln.bias = b.ln1_b;
     TRY(layernorm_launch(ln, st));
     if (bf) {
-      TRY(fp_gemm_qkv_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, Mtok, D, b.qkv_b, ws->qkv, ws->vt, ws->vt_ld, ntok, stream));
+      TRY(fp_gemm_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, nullptr, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
       TRY(attn_launch(at, FP_DTYPE_BF16, st));
       TRY(fp_gemm_bf16(ws->y, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
     } else {

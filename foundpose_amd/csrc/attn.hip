@@ -4,13 +4,15 @@
 // through self.model(batch), /root/reference/utils/dinov2_utils.py:257; optional xformers path upstream).
 //
 // bf16 kernel (flash-style, one pass over the keys, fp32 online softmax):
-//   * block = (128 queries, head, image), 4 waves x 32 queries; K tile [64 keys][64 d] and V^T tile
-//     [64 d][64 keys] staged through registers into XOR-swizzled LDS, next tile's loads in flight under the MFMAs
+//   * block = (128 queries, head, image), 4 waves x 32 queries; K tile and V tile (64 keys x 64 d each, rows of the
+//     qkv buffer) staged through registers into LDS, next tile's loads in flight under the MFMAs, one barrier per tile
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (operands swapped so a lane owns ONE query's scores:
 //     row max / row sum need a single cross-lane exchange with lane^32)
 //   * P -> bf16 in registers: v_cvt_pk_bf16_f32 + v_permlane32_swap builds the B operand of O^T = V^T P^T
-//   * V arrives pre-transposed from the qkv GEMM epilogue (keys contiguous), so the A operand is a plain
-//     ds_read_b128 -- no transposing LDS reads on the hot loop.
+//   * V stays row-major ([key][d], exactly as the qkv GEMM wrote it); the A operand V^T of the P*V MFMA is produced by
+//     gfx950's hardware transpose read ds_read_b64_tr_b16 (two per fragment: lane (d = l&31, kh) receives keys
+//     kh*8 + 4r + j of column d) from an LDS image cut into 16-column blocks.  No pre-transposed V^T copy in HBM
+//     (92 MB per layer at the bench batch) and no transposing epilogue in the qkv GEMM.
 // fp32 kernel (parity mode): one thread per query, K/V rows broadcast from LDS, exact expf.
 #include "common.hpp"
 #include "kernels.hpp"
@@ -23,14 +25,20 @@ FP_DEVICE bf16x8 read_frag(const char* lds, int row, int chunk) {
   return *reinterpret_cast<const bf16x8*>(lds + row * 128 + ((chunk ^ swz(row)) << 4));
 }
 
+// V image for the transpose reads: [4 blocks of 16 d][64 keys][16 d = 32 B]; block offsets 0 / 2176 / 4416 / 6592 so
+// that (a) the two blocks a ds_read_b64_tr_b16 touches are 128 B apart mod 256 (lanes 0-31 cover all 64 banks once) and
+// (b) the four blocks start in different bank quarters for the 16-B staging writes.
+constexpr int VTR_DT = 4416, VTR_B = 2176, VTR_BYTES = 8704;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
 __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
-  __shared__ __attribute__((aligned(16))) char KV[2][2][64 * 128];  // [stage][K | V^T][64 rows x 128 B]
+  __shared__ __attribute__((aligned(16))) char KV[2][2][VTR_BYTES];  // [stage][K: 64 rows x 128 B swizzled | V: block image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
   const int qt = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
   const int N = a.n_tok, D = a.dim;
   const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
-  const __bf16* vt = reinterpret_cast<const __bf16*>(a.vt) + ((size_t)img * D + head * 64) * a.vt_ld;
 
   // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d]
   const int q = qt * 128 + wave * 32 + l31;
@@ -53,8 +61,11 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
   const int soff0 = srow0 * 128 + ((sch ^ swz(srow0)) << 4);
   const int soff1 = (srow0 + 32) * 128 + ((sch ^ swz(srow0 + 32)) << 4);
   const __bf16* kbase = qkv + D + head * 64 + sch * 8;
-  const __bf16* vbase0 = vt + (size_t)srow0 * a.vt_ld + sch * 8;
-  const __bf16* vbase1 = vt + (size_t)(srow0 + 32) * a.vt_ld + sch * 8;
+  const __bf16* vbase = kbase + D;
+  // V staging offsets: this thread's 8 d's (chunk sch) of key srow0 / srow0 + 32 inside the block image
+  const int voff0 = (sch >> 2) * VTR_DT + ((sch >> 1) & 1) * VTR_B + srow0 * 32 + (sch & 1) * 16, voff1 = voff0 + 32 * 32;
+  // transpose-read base: source chunk of this lane inside a [4 keys][16 d] block + its block (b = bit 4 of the lane) + key half
+  const int vrd = ((lane >> 4) & 1) * VTR_B + (kh * 8 + ((lane & 15) >> 2)) * 32 + (lane & 3) * 8;
   uint4 kreg0, kreg1, vreg0, vreg1;
 #define ATTN_LOAD_TILE(key0_)                                                                   \
   {                                                                                             \
@@ -63,15 +74,15 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
     k1_ = k1_ < N ? k1_ : N - 1;                                                                \
     kreg0 = *reinterpret_cast<const uint4*>(kbase + (size_t)k0_ * a.ld_qkv);                    \
     kreg1 = *reinterpret_cast<const uint4*>(kbase + (size_t)k1_ * a.ld_qkv);                    \
-    vreg0 = *reinterpret_cast<const uint4*>(vbase0 + (key0_));                                  \
-    vreg1 = *reinterpret_cast<const uint4*>(vbase1 + (key0_));                                  \
+    vreg0 = *reinterpret_cast<const uint4*>(vbase + (size_t)k0_ * a.ld_qkv);                    \
+    vreg1 = *reinterpret_cast<const uint4*>(vbase + (size_t)k1_ * a.ld_qkv);                    \
   }
 #define ATTN_STORE_TILE(stage_)                                       \
   {                                                                   \
     *reinterpret_cast<uint4*>(KV[stage_][0] + soff0) = kreg0;         \
     *reinterpret_cast<uint4*>(KV[stage_][0] + soff1) = kreg1;         \
-    *reinterpret_cast<uint4*>(KV[stage_][1] + soff0) = vreg0;         \
-    *reinterpret_cast<uint4*>(KV[stage_][1] + soff1) = vreg1;         \
+    *reinterpret_cast<uint4*>(KV[stage_][1] + voff0) = vreg0;         \
+    *reinterpret_cast<uint4*>(KV[stage_][1] + voff1) = vreg1;         \
   }
 
   const int nkt = (N + 63) / 64;
@@ -154,7 +165,10 @@ __global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
         const int kstep = ks * 2 + kk;  // keys kstep*16 .. +15 of the tile
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-          bf16x8 vf = read_frag(Vs, dt * 32 + l31, kstep * 2 + kh);
+          const char* vp = Vs + vrd + dt * VTR_DT + kstep * 512;  // 16 keys x 32 B per k-step; + 128 B = 4 keys on
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 128));
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
           oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[dt], 0, 0, 0);
         }
       }
@@ -234,8 +248,6 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.dim % 64 == 0 && a.heads * 64 == a.dim, "attention: head_dim must be 64 (dim %d heads %d)", a.dim, a.heads);
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
-    FP_REQUIRE(a.vt != nullptr && a.vt_ld % 64 == 0 && a.vt_ld >= ((a.n_tok + 63) / 64) * 64,
-               "attention(bf16): V^T buffer must have a key stride padded to a multiple of 64 (got %d for %d tokens)", a.vt_ld, a.n_tok);
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
     dim3 grid(cdiv(a.n_tok, 128), a.heads, a.batch);
     hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, a);

@@ -141,7 +141,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     // bf16 outputs leave through an LDS slab (whole-row 16-B stores: the tail drops from ~15k to ~8k cycles per tile);
     // so does the fp32 LayerScale + residual read-modify-write (residual rows read and written as whole rows:
     // proj 152 -> 141 us, fc2 386 -> 374 us).  Only the small fp32 bias / patch-embed outputs stay register-direct.
-    constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_QKV_BF16 ||
+    constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 ||
                               EPI == GEMM_EPI_SWIGLU_BF16 || EPI == GEMM_EPI_LS_RESID_F32;
     if constexpr (USE_SLAB) {
     constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
@@ -159,32 +159,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         bias[tn][g] = *reinterpret_cast<const float4*>(a.bias + n);
         if constexpr (EPI == GEMM_EPI_LS_RESID_F32) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
       }
-    bool v_tile = false;  // qkv: tiles inside the V column block scatter V^T straight from registers
-    if constexpr (EPI == GEMM_EPI_QKV_BF16) v_tile = n0 >= 2 * a.vit_dim;
     __syncthreads();  // every wave is done with the operand tiles in LDS
   #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
-      if (v_tile) {
-        if constexpr (EPI == GEMM_EPI_QKV_BF16) {
-          if (m < a.M_valid) {
-            const int vb = m / a.tok_n, vt = m - vb * a.tok_n;
-  #pragma unroll
-            for (int tn = 0; tn < TN; ++tn)
-  #pragma unroll
-              for (int g = 0; g < 4; ++g) {
-                const int nn = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh - 2 * a.vit_dim;  // head*64 + d
-                const float4 bs = bias[tn][g];
-                __bf16* vtp = a.vt + ((size_t)vb * a.vit_dim + nn) * a.vt_ld + vt;
-                vtp[0 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 0] + bs.x);
-                vtp[1 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 1] + bs.y);
-                vtp[2 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 2] + bs.z);
-                vtp[3 * (size_t)a.vt_ld] = (__bf16)(acc[tm][tn][4 * g + 3] + bs.w);
-              }
-          }
-        }
-        continue;
-      }
       // (a) registers -> slab (final values except for the operand that needs a global read)
       char* srow = smem + (wm * 32 + l31) * SLAB_STRIDE;
   #pragma unroll
@@ -268,15 +246,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
       if (m >= a.M_valid) continue;
       size_t out_row = m;
-      int vb = 0, vt = 0, pidx = 0;
+      int pidx = 0;
       if constexpr (EPI == GEMM_EPI_TOKENS_F32) {
         const int b = m / a.tok_np;
         pidx = m - b * a.tok_np;
         out_row = (size_t)b * a.tok_n + a.tok_skip + pidx;
-      }
-      if constexpr (EPI == GEMM_EPI_QKV_BF16) {
-        vb = m / a.tok_n;
-        vt = m - vb * a.tok_n;
       }
       float4 extra[TN][4];  // residual row (LS_RESID) or pos-embed row (TOKENS)
       if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32) {
@@ -299,25 +273,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
-          if constexpr (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_QKV_BF16) {
+          if constexpr (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16) {
             if constexpr (EPI == GEMM_EPI_GELU_BF16) {
               const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
-            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+              v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
             }
-            bool transposed_v = false;
-            if constexpr (EPI == GEMM_EPI_QKV_BF16) transposed_v = n >= 2 * a.vit_dim;
-            if (!transposed_v) {
-              uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
-              *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + out_row * a.ldo + n) = pk;
-            } else {
-              // V goes out transposed, Vt[b][head][d][t] (keys contiguous), for the attention P*V operand
-              const int nn = n - 2 * a.vit_dim;  // head*64 + d
-              __bf16* vtp = a.vt + ((size_t)vb * a.vit_dim + nn) * a.vt_ld + vt;
-              vtp[0 * (size_t)a.vt_ld] = (__bf16)v0;
-              vtp[1 * (size_t)a.vt_ld] = (__bf16)v1;
-              vtp[2 * (size_t)a.vt_ld] = (__bf16)v2;
-              vtp[3 * (size_t)a.vt_ld] = (__bf16)v3;
-            }
+            uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + out_row * a.ldo + n) = pk;
           } else if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
             const float4 gm = gam[tn][g];
             float4 x = extra[tn][g];
@@ -381,7 +343,6 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
   switch (epi) {
     case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16>(a, st);
     case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16>(a, st);
-    case GEMM_EPI_QKV_BF16: return launch<GEMM_EPI_QKV_BF16>(a, st);
     case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
     case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
     case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);

@@ -77,7 +77,6 @@ int launch_sqrt_inplace(float* x, long long n, hipStream_t st);
 enum : int {
   GEMM_EPI_BIAS_BF16 = 0,     // out(bf16) = acc + bias
   GEMM_EPI_GELU_BF16 = 1,     // out(bf16) = gelu_erf(acc + bias)
-  GEMM_EPI_QKV_BF16 = 2,      // q,k -> out(bf16) [M,3D];  v -> vt[b][h][d][t] (keys contiguous)
   GEMM_EPI_LS_RESID_F32 = 3,  // out(f32) += gamma * (acc + bias)      (LayerScale + residual)
   GEMM_EPI_TOKENS_F32 = 4,    // patch-embed rows scattered into the token sequence (+ bias + pos-embed)
   GEMM_EPI_BIAS_F32 = 5,      // out(f32) = acc + bias
@@ -93,7 +92,6 @@ struct GemmBf16Args {
   void* out; int ldo;
   const float* pos;           // [Np, ldo] fp32 pos-embed rows of the patch tokens
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
-  __bf16* vt; int vt_ld; int vit_dim;
   int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
 };
@@ -106,7 +104,6 @@ enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1 };
 // ---------------------------------------------------------------- attn.hip
 struct AttnArgs {
   const void* qkv; int ld_qkv;   // [B*N, 3D] (bf16 or f32): q | k | v column blocks, head-major inside
-  const void* vt; int vt_ld;     // bf16 only: V^T [B][D][vt_ld] (keys contiguous, zero padded)
   void* out; int ld_out;         // [B*N, D]
   int batch, n_tok, dim, heads;
 };

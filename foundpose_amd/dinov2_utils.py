@@ -157,18 +157,16 @@ class DinoFeatureExtractor(torch.nn.Module):
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
             m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
             mp_pad = (B * np_ + 255) // 256 * 256
-            vt_ld = (ntok + 63) // 64 * 64
             bufs = [
                 torch.zeros(mp_pad, self._model.patch_k_pad, dtype=adt, device=dev),
                 torch.zeros(m_pad, a.dim, dtype=torch.float32, device=dev),
                 torch.zeros(m_pad, a.dim, dtype=adt, device=dev),
                 torch.zeros(m_pad, 3 * a.dim, dtype=adt, device=dev),
-                torch.zeros(B, a.dim, vt_ld, dtype=torch.bfloat16, device=dev),
                 torch.zeros(m_pad, a.hidden, dtype=adt, device=dev),
             ]
             ws = _lib.VitWorkspace()
-            ws.patches, ws.x, ws.y, ws.qkv, ws.vt, ws.h = (ptr(t) for t in bufs)
-            ws.m_pad, ws.m_patch_pad, ws.vt_ld = m_pad, mp_pad, vt_ld
+            ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs)
+            ws.m_pad, ws.m_patch_pad = m_pad, mp_pad
             self._ws[key] = (ws, bufs)
         return self._ws[key]
 

@@ -138,10 +138,10 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_dty
     return out
 
 
-def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, vt: Optional[torch.Tensor] = None):
+def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int):
     require_cuda(qkv)
     bf = qkv.dtype == torch.bfloat16
     out = torch.zeros(qkv.shape[0], dim, dtype=qkv.dtype, device=qkv.device)
-    call("fp_attention", ptr(qkv), qkv.stride(0), ptr(vt), 0 if vt is None else vt.shape[-1], ptr(out), dim,
+    call("fp_attention", ptr(qkv), qkv.stride(0), ptr(out), dim,
          batch, n_tok, dim, heads, _lib.FP_BF16 if bf else _lib.FP_F32, stream())
     return out

@@ -25,7 +25,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
 
-#define FP_ABI_VERSION 2
+#define FP_ABI_VERSION 3
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -132,11 +132,9 @@ typedef struct {
   float* x;      /* [m_pad, D] fp32 residual stream */
   void* y;       /* [m_pad, D] activation dtype (LN output / attention output) */
   void* qkv;     /* [m_pad, 3D] */
-  void* vt;      /* bf16 only: [B, D, vt_ld] zero-initialised once by the caller */
   void* h;       /* [m_pad, hidden] */
   int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
   int m_patch_pad; /* multiple of 128, >= B*Np */
-  int vt_ld;     /* multiple of 64, >= tokens per image */
 } fp_vit_workspace;
 
 /* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token
@@ -164,12 +162,9 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);
-/* qkv [B*N, 3D] (+ vt for bf16) -> out [B*N, D] */
-int fp_attention(const void* qkv, int ld_qkv, const void* vt, int vt_ld, void* out, int ld_out, int B, int n_tok,
+/* qkv [B*N, 3D] (q | k | v column blocks, head-major inside) -> out [B*N, D] */
+int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok,
                  int dim, int heads, int dtype, fp_stream_t stream);
-/* qkv projection with the bf16 epilogue that also writes V^T (used by fp_vit_forward) */
-int fp_gemm_qkv_bf16(const void* A, int lda, const void* W, int ldw, int M, int M_valid, int dim, const float* bias,
-                     void* qkv, void* vt, int vt_ld, int n_tok, fp_stream_t stream);
 int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream);
 
 #ifdef __cplusplus

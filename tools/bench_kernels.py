@@ -43,9 +43,7 @@ def main():
                 print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "attn" in what:
         qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
-        vt = torch.zeros(B, D, (N + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
-        vt[:, :, :N] = qkv[:B * N, 2 * D:].reshape(B, N, D).permute(0, 2, 1)
-        ms = timeit(lambda: ops.attention(qkv, B, N, D, H, vt=vt))
+        ms = timeit(lambda: ops.attention(qkv, B, N, D, H))
         print(f"attn B={B} N={N} H={H}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
     if "cos" in what:
         from foundpose_amd._lib import call, ptr, stream

@@ -9,10 +9,8 @@ M = (B * N + 255) // 256 * 256
 dev = "cuda"
 if what == "attn":
     qkv = torch.randn(M, 3 * D, device=dev).to(torch.bfloat16)
-    vt = torch.zeros(B, D, (N + 63) // 64 * 64, dtype=torch.bfloat16, device=dev)
-    vt[:, :, :N] = qkv[:B * N, 2 * D:].reshape(B, N, D).permute(0, 2, 1)
     for _ in range(4):
-        ops.attention(qkv, B, N, D, H, vt=vt)
+        ops.attention(qkv, B, N, D, H)
 else:
     n, k, epi = {"qkv": (3 * D, D, 0), "proj": (D, D, 3), "fc1": (4 * D, D, 1), "fc2": (D, 4 * D, 3)}[what]
     a = torch.randn(M, k, device=dev).to(torch.bfloat16)
