@@ -93,6 +93,7 @@ struct GemmBf16Args {
   const float* pos;           // [Np, ldo] fp32 pos-embed rows of the patch tokens
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
   int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
+  unsigned rast_r, rast_gn;
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
 };
 
