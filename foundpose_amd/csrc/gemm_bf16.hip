@@ -73,7 +73,12 @@ template <int EPI, int BM, int BN, int WM, int WN>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
-  constexpr int A_INSTR = BM / 8 / NW, B_INSTR = BN / 8 / NW;  // DMA instructions per wave per K-tile
+  // DMA issue is asymmetric on the 8-wave tile: only the waves of row wm == 0 fetch (every SIMD hosts one wave of each
+  // row).  A global/buffer_load..lds blocks its wave for ~60-180 issue cycles; when all eight waves issue their pieces
+  // in lock step the matrix pipes idle meanwhile, when one wave per SIMD does it the other keeps its SIMD's pipe fed.
+  constexpr bool ASYM = NW == 8;
+  constexpr int NISSUE = ASYM ? NW / 2 : NW;
+  constexpr int A_INSTR = BM / 8 / NISSUE, B_INSTR = BN / 8 / NISSUE;  // DMA instructions per issuing wave per K-tile
   constexpr int PIECES = A_INSTR + B_INSTR;
   static_assert(PIECES % 4 == 0, "staging split");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
@@ -117,9 +122,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)a.N * a.ldw * 2u, 0x00020000);
     const unsigned voff_a[2] = {stage_lane_offset(a.lda, lane, 0), stage_lane_offset(a.lda, lane, 1)};
     const unsigned voff_w[2] = {stage_lane_offset(a.ldw, lane, 0), stage_lane_offset(a.ldw, lane, 1)};
+    const bool issuer = !ASYM || wm == 0;  // wave-uniform
+    const int iw = ASYM ? wave % NISSUE : wave;
     auto stage_piece = [&](int q, int t, char* buf) {
-      if (q < A_INSTR) stage_rows(rsrc_a, voff_a[q & 1], a.lda, m0, t * BK, buf, wave * A_INSTR + q);
-      else stage_rows(rsrc_w, voff_w[(q - A_INSTR) & 1], a.ldw, n0, t * BK, buf + A_BYTES, wave * B_INSTR + (q - A_INSTR));
+      if (!issuer) return;
+      if (q < A_INSTR) stage_rows(rsrc_a, voff_a[q & 1], a.lda, m0, t * BK, buf, iw * A_INSTR + q);
+      else stage_rows(rsrc_w, voff_w[(q - A_INSTR) & 1], a.ldw, n0, t * BK, buf + A_BYTES, iw * B_INSTR + (q - A_INSTR));
     };
 #pragma unroll
     for (int q = 0; q < PIECES; ++q) stage_piece(q, kb, smem);
