@@ -54,9 +54,10 @@ def build_synthetic_bank(num_templates, feat_dim, raw_dim, num_words, seed, devi
 
 def hbm_traffic_fc1(args, arch, B):
     """HBM-side bytes per fc1 launch from the rocprofv3 PMC passes of this exact shape (profiles/r1_pmc_counters.txt:
-    FETCH_SIZE 455183.5 KiB doubled per the gfx950 correction + WRITE_SIZE 351744.0 KiB); null for any other shape."""
+    FETCH_SIZE 266533.5 KiB doubled per the gfx950 correction + WRITE_SIZE 351744.0 KiB, super-tile raster;
+    455183.5 KiB fetched with the plain tile order); null for any other shape."""
     if (args.version, args.size, B, args.precision) == ("vitl14-reg", 518, 32, "bf16"):
-        return int((2 * 455183.5 + 351744.0) * 1024)
+        return int((2 * 266533.5 + 351744.0) * 1024)
     return None
 
 
