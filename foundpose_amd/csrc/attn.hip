@@ -32,7 +32,7 @@ constexpr int VTR_DT = 4416, VTR_B = 2176, VTR_BYTES = 8704;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
 
-__global__ __launch_bounds__(256) void attn_bf16_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][VTR_BYTES];  // [stage][K: 64 rows x 128 B swizzled | V: block image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
