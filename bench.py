@@ -188,7 +188,7 @@ def main():
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
                              "bytes_per_launch": knn_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             result["cpu_baseline"] = cpu_baseline(arch, args, repre, images, masks)
         print(json.dumps(result), flush=True)
     if world > 1:
