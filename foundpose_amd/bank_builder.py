@@ -47,3 +47,59 @@ def calc_tfidf_descriptors(
     descs, _ = ops.tfidf_build(wid, d2, seg, idfs.contiguous(), opts.tfidf_soft_assign, opts.tfidf_soft_sigma_squared,
                                sqrt_dists=False)
     return descs, idfs, feat_to_cluster_ids
+
+
+def extract_template_features(extractor, templates: torch.Tensor, masks: torch.Tensor, grid_cell: float = 14.0,
+                              batch_size: int = 32) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Patch features of the rendered templates inside their masks (scripts/gen_repre.py:136-214 in the reference:
+    extractor on each template, grid points filtered by the mask, bilinear samples of the feature map), batched.
+
+    templates [T, 3, S, S] f32 in [0, 1], masks [T, S, S] -> (features [N_f, D] f32, feat_to_template_ids [N_f] i32,
+    points [N_f, 2] f32 pixel coordinates), contiguous runs per template in template order."""
+    from . import feature_util
+    T, _, H, W = templates.shape
+    grid = feature_util.generate_grid_points((W, H), grid_cell).cuda()
+    feats, ids, pts = [], [], []
+    for t0 in range(0, T, batch_size):
+        imgs = templates[t0:t0 + batch_size].cuda()
+        msk = masks[t0:t0 + batch_size].cuda()
+        fmap, _ = extractor.forward_tokens(imgs)
+        gh, gw = extractor.num_patches
+        D = fmap.shape[-1]
+        q_pts, q_img = [], []
+        for b in range(imgs.shape[0]):
+            p = feature_util.filter_points_by_mask(grid, msk[b])
+            q_pts.append(p)
+            q_img.append(torch.full((p.shape[0],), b, dtype=torch.int32, device=p.device))
+            ids.append(torch.full((p.shape[0],), t0 + b, dtype=torch.int32, device=p.device))
+        q_pts, q_img = torch.cat(q_pts).contiguous(), torch.cat(q_img).contiguous()
+        feats.append(ops.sample_bilinear(fmap.reshape(imgs.shape[0], gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H)))
+        pts.append(q_pts)
+    return torch.cat(feats), torch.cat(ids), torch.cat(pts)
+
+
+def build_object_repre(raw_features: torch.Tensor, feat_to_template_ids: torch.Tensor, vertices: torch.Tensor,
+                       num_templates: int, pca_components: int = 256, pca_max_samples: int = 100000,
+                       cluster_num: int = 2048, cluster_iters: int = 50,
+                       desc_opts: TemplateDescOpts = TemplateDescOpts(), verbose: bool = False):
+    """PCA -> k-means visual words -> tf-idf template descriptors, all on the MI355X
+    (scripts/gen_repre.py:271-345 in the reference), returned as the bank object the inference path loads.
+
+    raw_features [N_f, D] (template order), vertices [N_f, 3] = the 3D point of every feature (their registration
+    from rendered depth is upstream of this function)."""
+    from . import cluster_util, projector_util, repre_util
+    feats = raw_features.float().cuda()
+    projectors = []
+    if pca_components and pca_components < feats.shape[1]:
+        proj = projector_util.PCAProjector(n_components=pca_components)
+        proj.fit(feats, max_samples=pca_max_samples)
+        feats = proj.transform(feats)
+        projectors.append(proj)
+    centroids, cluster_ids, _ = cluster_util.kmeans(feats, cluster_num, num_iter=cluster_iters, verbose=verbose)
+    f2t = feat_to_template_ids.to(torch.int32).cuda()
+    descs, idfs, f2c = calc_tfidf_descriptors(feats, f2t, centroids, num_templates, desc_opts)
+    return repre_util.FeatureBasedObjectRepre(
+        vertices=vertices.float().cuda(), feat_vectors=feats, feat_to_template_ids=f2t, feat_to_cluster_ids=f2c,
+        feat_to_vertex_ids=torch.arange(feats.shape[0], dtype=torch.int32, device=feats.device),
+        feat_cluster_centroids=centroids, feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=desc_opts,
+        feat_raw_projectors=projectors)

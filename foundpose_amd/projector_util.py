@@ -30,9 +30,42 @@ class PCAProjector(Projector):
         self._dev: Dict[Any, Any] = {}
 
     def fit(self, data_x: torch.Tensor, data_y: Optional[torch.Tensor] = None, **kwargs: Any) -> None:
-        raise NotImplementedError(
-            "PCA fitting belongs to the offline bank builder (scripts/gen_repre.py in the reference); "
-            "load a fitted projector with projector_from_tensordict")
+        """Fits the PCA on the MI355X (bank-builder tier; reference: projector_util.py:51-64 -> sklearn PCA.fit).
+
+        Same estimator as sklearn's full solver: mean, covariance (X-mu)^T (X-mu) / (n-1) -- the [D, D] Gram matrix is
+        one exact-fp32 MFMA GEMM over the samples -- eigen-decomposition (fp64, D x D: host-sized), components = leading
+        eigenvectors with sklearn's sign convention (svd_flip on V: the largest-magnitude entry of every component is
+        positive).  `max_samples` caps the fitting set with a random permutation like the reference.  sklearn picks a
+        RANDOMIZED solver for 256 of 1024 dims, so its own output is seed-dependent; the subspace and variances agree
+        to solver tolerance (tests/test_gpu_bank_builder.py checks against the full solver).
+        """
+        x = data_x
+        if "max_samples" in kwargs and x.shape[0] > kwargs["max_samples"]:
+            x = x[torch.randperm(x.shape[0])[: kwargs["max_samples"]].to(x.device)]
+        x = x.float().cuda().contiguous() if not x.is_cuda else x.float().contiguous()
+        n, D = x.shape
+        if n < 2 or self.n_components > min(n, D):
+            raise ValueError(f"cannot fit {self.n_components} components on {n} samples of {D} dims")
+        mean = x.mean(dim=0)
+        xc_t = (x - mean).t().contiguous()                      # [D, n]: rows = dims, the GEMM's K runs over samples
+        cov = ops.gemm_f32(xc_t, xc_t) / float(n - 1)           # exact-fp32 MFMA chains, k ascending
+        evals, evecs = torch.linalg.eigh(cov.double().cpu())    # ascending
+        evals = evals.flip(0).clamp_min(0.0)
+        comps = evecs.flip(1).t().contiguous()                  # [D, D] rows = components, variance descending
+        sign = torch.sign(comps.gather(1, comps.abs().argmax(dim=1, keepdim=True)))
+        sign[sign == 0] = 1.0
+        comps = comps * sign
+        k = self.n_components
+        total = float(evals.sum())
+        self.components = comps[:k].float()
+        self.mean = mean.cpu()
+        self.extra = {
+            "explained_variance": evals[:k].float(),
+            "explained_variance_ratio": (evals[:k] / total).float(),
+            "singular_values": torch.sqrt(evals[:k] * (n - 1)).float(),
+            "noise_variance": (evals[k:].mean() if k < min(n, D) else torch.tensor(0.0, dtype=torch.float64)).float(),
+        }
+        self._dev = {}
 
     def _device_state(self, device):
         key = str(device)
