@@ -26,6 +26,7 @@ def calc_tfidf_descriptors(
     feat_words: torch.Tensor,            # [W, d] cuda
     num_templates: int,
     opts: TemplateDescOpts = TemplateDescOpts(),
+    feat_to_word_ids: torch.Tensor = None,  # [N_f] word of every feature if already known (k-means assignment)
 ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
     """-> (template_descs [T, W], word_idfs [W], feat_to_cluster_ids [N_f] i32)."""
     fv = feat_vectors.float().contiguous()
@@ -35,8 +36,11 @@ def calc_tfidf_descriptors(
     words_sqn = ops.sqnorm_rows(words)
     fv_sqn = ops.sqnorm_rows(fv)
     # 1-NN word of every feature (the k-means assignment of cluster_util.py:59)
-    _, wid1 = ops.knn_l2(fv, words, 1, fv_sqn, words_sqn)
-    feat_to_cluster_ids = wid1[:, 0].contiguous()
+    if feat_to_word_ids is None:
+        _, wid1 = ops.knn_l2(fv, words, 1, fv_sqn, words_sqn)
+        feat_to_cluster_ids = wid1[:, 0].contiguous()
+    else:
+        feat_to_cluster_ids = feat_to_word_ids.to(device=fv.device, dtype=torch.int32).contiguous()
     # idf: number of templates in which each word occurs (template_util.py:94-102)
     pairs = torch.unique(f2t * W + feat_to_cluster_ids.to(torch.int64))
     occ = torch.bincount(pairs % W, minlength=W)

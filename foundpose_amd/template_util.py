@@ -34,6 +34,27 @@ def calc_tfidf(feature_word_ids: torch.Tensor, feature_word_dists: torch.Tensor,
     return desc[0].to(feature_word_ids.device)
 
 
+def calc_tfidf_descriptors(
+    feat_vectors: torch.Tensor,
+    feat_to_word_ids: torch.Tensor,
+    feat_to_template_ids: torch.Tensor,
+    feat_words: torch.Tensor,
+    num_templates: int,
+    tfidf_knn_k: int,
+    tfidf_soft_assign: bool,
+    tfidf_soft_sigma_squared: float,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Bank side of the descriptors (reference: template_util.py:74-123), all templates in one pass on the device:
+    -> (template_descs [T, W], word_idfs [W]).  Features must be grouped by template (ascending ids), as gen_repre
+    produces them."""
+    from . import bank_builder
+    opts = repre_util.TemplateDescOpts(tfidf_knn_k=tfidf_knn_k, tfidf_soft_assign=tfidf_soft_assign,
+                                       tfidf_soft_sigma_squared=tfidf_soft_sigma_squared)
+    descs, idfs, _ = bank_builder.calc_tfidf_descriptors(feat_vectors.cuda(), feat_to_template_ids.cuda(), feat_words.cuda(),
+                                                         num_templates, opts, feat_to_word_ids=feat_to_word_ids)
+    return descs, idfs
+
+
 def tfidf_matching(query_features: torch.Tensor, object_repre: repre_util.FeatureBasedObjectRepre, top_n_templates: int,
                    visual_words_knn_index: Optional[knn_util.KNN] = None, debug: bool = False) -> Tuple[torch.Tensor, torch.Tensor]:
     if object_repre.template_desc_opts is None or object_repre.template_desc_opts.desc_type != "tfidf":

@@ -267,6 +267,12 @@ def test_bank_builder_vs_reference_fixture(name):
     assert np.array_equal(f2c.cpu().numpy(), g["feat_to_cluster_ids"])
     np.testing.assert_allclose(idfs.cpu().numpy(), g["word_idfs"], rtol=3e-7, atol=0)
     np.testing.assert_allclose(descs.cpu().numpy(), g["template_descs"], rtol=5e-5, atol=1e-8)
+    # the drop-in with the reference's signature (template_util.py:74-83) gives the same tensors
+    from foundpose_amd import template_util
+    d2, i2 = template_util.calc_tfidf_descriptors(
+        cu(repre["feat_vectors"]), cu(g["feat_to_cluster_ids"]), cu(repre["feat_to_template_ids"]), cu(repre["feat_cluster_centroids"]),
+        int(c["T"]), 3, bool(c["soft"]), 10.0)
+    assert torch.equal(d2, descs) and torch.equal(i2, idfs)
 
 
 def test_engine_batch_equals_per_detection():
