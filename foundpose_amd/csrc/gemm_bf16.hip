@@ -118,16 +118,21 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 
     // DMA piece q (0 .. PIECES-1) of this wave for K-tile t into stage buffer `buf`
     static_assert(A_INSTR % 2 == 0 && B_INSTR % 2 == 0, "row-group parity of a piece must be a compile-time property");
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)a.A, 0, (unsigned)a.M * a.lda * 2u, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)a.W, 0, (unsigned)a.N * a.ldw * 2u, 0x00020000);
+    // the resources start at this tile's first row (32-bit offsets then never exceed one tile's extent, whatever the
+    // size of the matrix) and end at the end of the matrix, clipped to the 4-GiB range of a buffer resource
+    auto tile_rsrc = [](const __bf16* base, int row0, int rows, int ld) {
+      const unsigned long long bytes = (unsigned long long)(rows - row0) * ld * 2ull;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(base + (size_t)row0 * ld), 0, bytes > 0xffffffffull ? 0xffffffffu : (unsigned)bytes, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t rsrc_a = tile_rsrc(a.A, m0, a.M, a.lda), rsrc_w = tile_rsrc(a.W, n0, a.N, a.ldw);
     const unsigned voff_a[2] = {stage_lane_offset(a.lda, lane, 0), stage_lane_offset(a.lda, lane, 1)};
     const unsigned voff_w[2] = {stage_lane_offset(a.ldw, lane, 0), stage_lane_offset(a.ldw, lane, 1)};
     const bool issuer = !ASYM || wm == 0;  // wave-uniform
     const int iw = ASYM ? wave % NISSUE : wave;
     auto stage_piece = [&](int q, int t, char* buf) {
       if (!issuer) return;
-      if (q < A_INSTR) stage_rows(rsrc_a, voff_a[q & 1], a.lda, m0, t * BK, buf, iw * A_INSTR + q);
-      else stage_rows(rsrc_w, voff_w[(q - A_INSTR) & 1], a.ldw, n0, t * BK, buf + A_BYTES, iw * B_INSTR + (q - A_INSTR));
+      if (q < A_INSTR) stage_rows(rsrc_a, voff_a[q & 1], a.lda, 0, t * BK, buf, iw * A_INSTR + q);
+      else stage_rows(rsrc_w, voff_w[(q - A_INSTR) & 1], a.ldw, 0, t * BK, buf + A_BYTES, iw * B_INSTR + (q - A_INSTR));
     };
 #pragma unroll
     for (int q = 0; q < PIECES; ++q) stage_piece(q, kb, smem);

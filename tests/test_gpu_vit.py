@@ -257,3 +257,20 @@ def test_extractor_vitl14reg_518_metric_config_vs_oracle():
     assert rel_err(one.cpu(), ref) < 3e-2
     batch = ex16(imgs.cuda())["feature_maps"]
     assert torch.equal(batch[5], one[0])
+
+
+def test_gemm_bf16_operands_beyond_4gib():
+    """A > 4 GiB (the buffer-resource range): tiles deep inside the matrix still read the right rows."""
+    from foundpose_amd import ops
+    M, K, N = 1179648, 2048, 256  # A = 4.5 GiB of bf16
+    a = torch.zeros(M, K, dtype=torch.bfloat16, device="cuda")
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rows = [0, 255, 1048576 + 3, M - 1]  # first tile, and rows past the 4-GiB mark
+    for r in rows:
+        a[r] = torch.randn(K, generator=g, device="cuda").to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device="cuda") * 0.05).to(torch.bfloat16)
+    out = ops.gemm_bf16(a, w, torch.zeros(N, device="cuda"), epilogue=5)
+    for r in rows:
+        ref = a[r].double() @ w.double().T
+        assert float((out[r].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max()), r
+    assert float(out[300000].abs().max()) == 0.0
