@@ -4,14 +4,18 @@
 // (call site /root/reference/utils/dinov2_utils.py:257).  MI355X design:
 //   * block tile 256x256x64, 512 threads = 2x4 waves, each wave 128x64 = 4x2 v_mfma_f32_32x32x16_bf16
 //     (128x128, 4 waves for small shapes)
-//   * A and W tiles go HBM/L2 -> LDS with global_load_lds (16 B/lane, no VGPR round trip), double buffered,
-//     one barrier per K-tile, next tile's DMA in flight under the MFMAs
+//   * A and W tiles go HBM/L2 -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 16 B/lane, no VGPR round trip), double
+//     buffered, one barrier per K-tile, next tile's DMA in flight under the MFMAs; on the 8-wave tile only ONE wave
+//     row issues the DMA (each SIMD hosts a wave of either row: the partner keeps the matrix pipe fed while the
+//     issuing wave is blocked in its ~100-cycle DMA issues)
 //   * LDS image is row-major [row][64 bf16]; bank conflicts of the ds_read_b128 fragment reads are
 //     removed by XOR-swizzling the 16-B chunk index with (row>>1)&7 -- applied on the *source* address
 //     (the DMA destination is lane-linear) and again on the read (guide section 5.4 rule 21)
 //   * operands are fed to the MFMA swapped (W as the "A" operand) so each lane ends up with 4 consecutive
-//     output columns of one row: 8-byte bf16 / 16-byte fp32 epilogue accesses
-//   * logical workgroup ids are remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels.
+//     output columns of one row; every epilogue but the small fp32 ones leaves through an LDS slab as whole rows
+//   * logical workgroup ids are remapped so that each XCD's L2 sees a contiguous run of tiles sharing A panels; wide
+//     outputs use an 8 x 4 super-tile raster per XCD that keeps a group of W panels resident in its L2.
+// What bounds it, and what was tried and did not help: DESIGN.md section 5 "GEMM analysis".
 #include <cstdlib>
 
 #include "common.hpp"
