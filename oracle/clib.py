@@ -87,6 +87,8 @@ def scatter_add(idx, src, size):
 
 def topk_torch(values, k, largest=True, sorted_=True):
     values = _f(values)
+    if not 0 <= k <= values.shape[0]:
+        raise ValueError(f"k={k} out of range for {values.shape[0]} values (torch.topk raises too)")
     val = np.empty(k, np.float32)
     idx = np.empty(k, np.int64)
     lib().orc_topk_torch(_p(values), _i64(values.shape[0]), _i64(k), int(largest), int(sorted_), _p(val), _p(idx))
@@ -95,6 +97,8 @@ def topk_torch(values, k, largest=True, sorted_=True):
 
 def topk_canonical(values, k, largest=True):
     values = _f(values)
+    if not 0 <= k <= values.shape[0]:
+        raise ValueError(f"k={k} out of range for {values.shape[0]} values")
     val = np.empty(k, np.float32)
     idx = np.empty(k, np.int64)
     lib().orc_topk_canonical(_p(values), _i64(values.shape[0]), _i64(k), int(largest), _p(val), _p(idx))

@@ -106,7 +106,9 @@ def tfidf_matching(query_features, repre: Dict, top_n: int, topk_mode: str = "to
     ids, dists = nearest_words(query_features, repre["feat_cluster_centroids"], opts["tfidf_knn_k"])
     q_tfidf = calc_tfidf(ids, dists, repre["feat_cluster_idfs"], opts["tfidf_soft_assign"], opts["tfidf_soft_sigma_squared"])
     sims = cosine_scores(repre["template_descs"], q_tfidf)
-    scores, tids = _topk(sims, top_n, True, topk_mode)
+    # (torch.topk raises when there are fewer templates than top_n, template_util.py:172; the device path returns the
+    #  templates there are, padded with -1 -- the oracle follows the device here so the case stays comparable)
+    scores, tids = _topk(sims, min(top_n, sims.shape[0]), True, topk_mode)
     return tids, scores, {"word_ids": ids, "word_dists": dists, "query_tfidf": q_tfidf, "sims": sims}
 
 

@@ -423,3 +423,56 @@ def test_match_batch_degenerate_detections():
             assert np.array_equal(a["nn_vertex_ids"].cpu().numpy(), o["nn_vertex_ids"])
             # all cycle distances of a 1-patch detection are 0 -> conf = 1 - 0/0 = NaN, like the reference (corresp_util.py:64)
             assert np.array_equal(a["coord_conf"].cpu().numpy(), o["coord_conf"], equal_nan=True)
+
+
+# ------------------------------------------------------------------ randomized sweep: GPU == oracle on many seeded configurations
+def _random_case(seed):
+    rng = np.random.RandomState(seed)
+    T = int(rng.choice([1, 2, 5, 6, 17, 40, 130]))
+    pmin = int(rng.choice([1, 4, 20, 60]))
+    pmax = pmin + int(rng.choice([0, 3, 25, 80]))
+    W = int(rng.choice([16, 48, 128, 256]))
+    noise = float(rng.choice([0.0, 0.0, 0.05, 0.5]))  # 0.0: exact copies of bank rows -> zero distances, heavy ties
+    dup = min(int(rng.choice([0, 0, 3, 9])), pmin)  # duplicated query patches (exact ties); a template has >= pmin patches
+    return dict(T=T, pmin=pmin, pmax=pmax, W=W, tpl=int(rng.randint(T)), noise=noise, top_n=int(rng.choice([1, 3, 5])),
+                top_k=int(rng.choice([1, 7, 50, 300])), soft=bool(rng.rand() < 0.3), bank_seed=1000 + seed, q_seed=2000 + seed, dup=dup)
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_sweep_vs_oracle_both_tie_orders(seed):
+    """Seeded random banks / queries (tiny to medium, ties, soft and hard assignment, fewer templates than top-n, fewer
+    patches than top-k): the device result equals the oracle index for index in BOTH tie orders -- the canonical one and
+    the reference's torch.topk CPU order."""
+    from oracle.make_golden import build_match_inputs
+    from foundpose_amd import corresp_util, repre_util
+    c = _random_case(seed)
+    bank, centroids, pts, feats = build_match_inputs(c)
+    W = min(c["W"], bank["feat_vectors"].shape[0] // 4 * 4)  # the device path wants num_words % 4 == 0 (checked below)
+    centroids = centroids[:W]
+    opts = {"desc_type": "tfidf", "tfidf_knn_metric": "l2", "tfidf_knn_k": min(3, W), "tfidf_soft_assign": c["soft"],
+            "tfidf_soft_sigma_squared": 10.0}
+    r = om.build_synthetic_repre({k: v.numpy() for k, v in bank.items()}, centroids.numpy(), opts)
+    repre = repre_util.FeatureBasedObjectRepre(
+        vertices=torch.from_numpy(r["vertices"]), feat_vectors=torch.from_numpy(r["feat_vectors"]),
+        feat_to_template_ids=torch.from_numpy(r["feat_to_template_ids"]),
+        feat_cluster_centroids=torch.from_numpy(r["feat_cluster_centroids"]), feat_cluster_idfs=torch.from_numpy(r["feat_cluster_idfs"]),
+        template_descs=torch.from_numpy(r["template_descs"]),
+        template_desc_opts=repre_util.TemplateDescOpts(tfidf_knn_k=opts["tfidf_knn_k"], tfidf_soft_assign=c["soft"]))
+    for order in ("canonical", "torch"):
+        got = corresp_util.establish_correspondences(pts.cuda(), feats.cuda(), repre, "tfidf", "cyclic_buddies", c["top_n"], c["top_k"],
+                                                     debug=True, tie_order=order)
+        ora = om.establish_correspondences(pts.numpy(), feats.numpy(), r, c["top_n"], c["top_k"], topk_mode=order)
+        assert [int(x["template_id"]) for x in got] == [o["template_id"] for o in ora], (order, c)
+        for a, o in zip(got, ora):
+            assert np.array_equal(a["coord_2d_ids"].cpu().numpy(), o["coord_2d_ids"]), (order, c)
+            assert np.array_equal(a["nn_vertex_ids"].cpu().numpy(), o["nn_vertex_ids"]), (order, c)
+            assert np.array_equal(a["nn_dists"].cpu().numpy(), o["nn_dists"]), (order, c)
+            assert np.array_equal(a["coord_conf"].cpu().numpy(), o["coord_conf"], equal_nan=True), (order, c)
+            # scores: the idf terms go through logf on the device and numpy's log in the oracle (1 ulp apart at times)
+            assert abs(float(a["template_score"]) - float(o["template_score"])) <= 2e-6, (order, c)
+
+
+def test_num_words_not_multiple_of_4_fails_loudly():
+    from foundpose_amd._lib import FoundPoseNativeError
+    with pytest.raises(FoundPoseNativeError, match="multiples of 4"):
+        _cosine_topk(torch.rand(2, 14).cuda(), torch.rand(5, 14).cuda(), 3)
