@@ -53,7 +53,10 @@ class DinoFeatureExtractor(torch.nn.Module):
         self.model_base_name = f"dinov2_{self.version}".replace("-", "_")
         self.patch_size = self.arch.patch
         if self.stride != self.patch_size:
-            raise NotImplementedError("stride != patch size (pos-embed re-striding) is not implemented on the MI355X path")
+            raise NotImplementedError(
+                "stride != patch size is not implemented on the MI355X path.  (The reference's own code for it cannot run "
+                "either: _fix_pos_enc returns a function without a `self` parameter and binds it with types.MethodType "
+                "(dinov2_utils.py:326,386-388), so its first forward raises TypeError; there is no behaviour to match.)")
         if self.facet != "token":
             raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path (shipped configs use 'token')")
         if not 0 <= self.layer < self.arch.depth:
