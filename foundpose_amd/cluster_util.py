@@ -6,8 +6,8 @@ empty-cluster handling are not pinned by any reference test ("parity unpinned"),
 published faiss behaviour restated: centroids initialised from a seeded random subset, assignment by exact squared-L2
 arg-min (the same exact-fp32 MFMA distance tile as the inference k-NN, ties -> lowest centroid index), centroid = mean of
 its samples, an empty cluster re-seeded by splitting the currently largest cluster (faiss: `split_clusters`, centroid
-times 1 +- 1/1024 on alternating dims).  Deterministic for a given seed: sums are taken in sample order (sorted
-segmented reduction), not with atomics.
+times 1 +- 1/1024 on alternating dims).  Deterministic for a given seed: the centroid sums are sample-ordered fp32 fma
+chains (a one-hot GEMM on the exact-fp32 MFMA tile), not atomics.
 """
 
 from typing import Tuple
@@ -24,15 +24,16 @@ def _assign(samples: torch.Tensor, s_sqn: torch.Tensor, centroids: torch.Tensor)
     return d2[:, 0], ids[:, 0]
 
 
-def _update(samples: torch.Tensor, ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
-    """Per-cluster means with a deterministic summation order: stable sort by cluster, fp64 prefix sums."""
-    order = torch.argsort(ids.to(torch.int64), stable=True)
+def _update(samples_t: torch.Tensor, ids: torch.Tensor, k: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-cluster means with a deterministic summation order: the sums are ONE exact-fp32 MFMA GEMM of the one-hot
+    assignment matrix [k, n] with the transposed samples [d, n] -- every (cluster, dim) sum is a sample-ascending fp32
+    fma chain -- instead of atomics (order-dependent) or a sort + prefix-sum pass (9x slower at 3e5 x 256)."""
+    n = ids.shape[0]
+    onehot = torch.zeros(k, samples_t.shape[1], dtype=torch.float32, device=ids.device)  # (columns padded to 4: zeros)
+    onehot[ids.to(torch.int64), torch.arange(n, device=ids.device)] = 1.0
     counts = torch.bincount(ids.to(torch.int64), minlength=k)
-    ends = torch.cumsum(counts, 0)
-    csum = torch.cumsum(samples[order].double(), dim=0)
-    csum = torch.cat([torch.zeros(1, samples.shape[1], dtype=torch.float64, device=samples.device), csum])
-    sums = csum[ends] - csum[ends - counts]
-    return (sums / counts.clamp_min(1).unsqueeze(1)).float(), counts
+    sums = ops.gemm_f32(onehot, samples_t)  # [k, d]
+    return sums / counts.clamp_min(1).unsqueeze(1).float(), counts
 
 
 def kmeans(samples: torch.Tensor, num_centroids: int, num_iter: int = 50, verbose: bool = True,
@@ -48,9 +49,11 @@ def kmeans(samples: torch.Tensor, num_centroids: int, num_iter: int = 50, verbos
     g = torch.Generator(device="cpu").manual_seed(seed)
     centroids = x[torch.randperm(n, generator=g)[:k].to(x.device)].clone()
     x_sqn = ops.sqnorm_rows(x)
+    x_t = torch.zeros(d, (n + 3) // 4 * 4, dtype=torch.float32, device=x.device)  # [d, n (+pad)]: the update GEMM's K
+    x_t[:, :n] = x.t()                                                             # dimension runs over the samples
     for it in range(num_iter):
         d2, ids = _assign(x, x_sqn, centroids)
-        new_c, counts = _update(x, ids, k)
+        new_c, counts = _update(x_t, ids, k)
         empty = torch.nonzero(counts == 0).flatten().tolist()
         if empty:  # split the largest clusters, one per empty slot (faiss split_clusters)
             sizes = counts.clone()
