@@ -36,3 +36,33 @@ def test_cpu_tensor_is_rejected_loudly():
     from foundpose_amd import _lib, ops
     with pytest.raises(_lib.FoundPoseNativeError):
         ops.sqnorm_rows(torch.zeros(4, 8))
+
+
+def test_bank_builder_entry_points_refuse_cpu_tensors_and_bad_names():
+    """Host logic that needs no GPU: loud failures instead of silent CPU work."""
+    import torch
+    from foundpose_amd import cluster_util, feature_util, knn_util
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cluster_util.kmeans(torch.zeros(64, 8), 4, verbose=False)
+    with pytest.raises(NotImplementedError):
+        feature_util.make_feature_extractor("resnet50")                      # feature_util.py:18-23 in the reference
+    with pytest.raises(NotImplementedError, match="no behaviour to match"):
+        feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=7_facet=token_layer=9_norm=1")
+    with pytest.raises(NotImplementedError):
+        feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=key_layer=9_norm=1")
+    with pytest.raises(ValueError):
+        knn_util.KNN(k=1, metric="manhattan").fit(torch.zeros(4, 4))         # knn_util.py:61-63 in the reference
+
+
+def test_oracle_topn_is_clamped_to_the_template_count():
+    """torch.topk raises when there are fewer templates than top_n; the oracle (like the device path) returns what exists."""
+    import numpy as np
+    from oracle import clib, match as om
+    from oracle.make_golden import build_match_inputs
+    c = dict(T=2, pmin=20, pmax=20, W=16, tpl=1, noise=0.05, top_n=5, top_k=10, soft=False, bank_seed=5, q_seed=6, dup=0)
+    bank, centroids, pts, feats = build_match_inputs(c)
+    r = om.build_synthetic_repre({k: v.numpy() for k, v in bank.items()}, centroids.numpy())
+    out = om.establish_correspondences(pts.numpy(), feats.numpy(), r, 5, 10)
+    assert [o["template_id"] for o in out][0] == 1 and len(out) == 2
+    with pytest.raises(ValueError):
+        clib.topk_torch(np.zeros(3, np.float32), 5)
