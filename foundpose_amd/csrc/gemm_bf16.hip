@@ -193,6 +193,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = OUT_COLS * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
     constexpr int CHUNKS_PER_ROW = OUT_COLS * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
     static_assert(SLAB_ROWS * SLAB_STRIDE <= 2 * STAGE, "slab must fit the main-loop LDS");
+    // two slabs, used alternately, when they fit: band tm+1 is written while band tm is still being stored, and the
+    // barrier that publishes band tm+1 also retires the readers of band tm-1's slab -> one barrier per band, not two
+    constexpr bool TWO_SLABS = 2 * SLAB_ROWS * SLAB_STRIDE <= 2 * STAGE;
+    constexpr int SLAB_BYTES = SLAB_ROWS * SLAB_STRIDE;
     float4 bias[TN][4], gam[TN][4];
   #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -207,7 +211,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
       // (a) registers -> slab (final values except for the operand that needs a global read)
-      char* srow = smem + (wm * 32 + l31) * SLAB_STRIDE;
+      char* slab = smem + (TWO_SLABS ? (tm & 1) * SLAB_BYTES : 0);
+      char* srow = slab + (wm * 32 + l31) * SLAB_STRIDE;
   #pragma unroll
       for (int tn = 0; tn < TN; ++tn)
   #pragma unroll
@@ -260,7 +265,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         const int id = tid + it * NT;
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
         if (!ok[it]) continue;
-        const char* sp = smem + r * SLAB_STRIDE + c * 16;
+        const char* sp = slab + r * SLAB_STRIDE + c * 16;
         if constexpr (!OUT_F32) {
           const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 8;
           *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
@@ -272,7 +277,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow[it] * a.ldo + n0 + c * 4) = v;
         }
       }
-      if (tm + 1 < TM) __syncthreads();
+      if (!TWO_SLABS && tm + 1 < TM) __syncthreads();
     }
     } else {
     float4 bias[TN][4], gam[TN][4];
