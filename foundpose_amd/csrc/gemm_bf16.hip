@@ -210,6 +210,30 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
+      // Global reads of this band (residual / pos-embed rows, whole rows, all passes) are issued FIRST, ahead of the
+      // register -> slab pass and its barrier, so their latency hides under that pass (proj -4 %, fc2 -1.5 %).
+      // Issuing them one band ahead, interleaved with the previous band's stores, measured 5 % SLOWER.
+      constexpr int PASSES = (SLAB_CHUNKS + NT - 1) / NT;
+      static_assert(SLAB_CHUNKS % NT == 0, "slab chunks must divide evenly over the block");
+      float4 ext[PASSES];
+      size_t orow[PASSES];
+      bool ok[PASSES];
+  #pragma unroll
+      for (int it = 0; it < PASSES; ++it) {
+        const int id = tid + it * NT;
+        const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
+        const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
+        ok[it] = gm_row < a.M_valid;
+        orow[it] = gm_row;
+        if constexpr (EPI == GEMM_EPI_TOKENS_F32) {
+          const int b = gm_row / a.tok_np, pidx = gm_row - b * a.tok_np;
+          orow[it] = (size_t)b * a.tok_n + a.tok_skip + pidx;
+          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(a.pos + (size_t)pidx * a.ldo + n0 + c * 4);
+        }
+        if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
+          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + orow[it] * a.ldo + n0 + c * 4);
+        }
+      }
       // (a) registers -> slab (final values except for the operand that needs a global read)
       char* slab = smem + (TWO_SLABS ? (tm & 1) * SLAB_BYTES : 0);
       char* srow = slab + (wm * 32 + l31) * SLAB_STRIDE;
@@ -237,29 +261,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       __syncthreads();
-      // (b) slab -> global, whole rows.  Global reads (residual / pos-embed rows) of all passes are issued first,
-      // so the tail pays one memory round trip per band instead of one per pass.
-      constexpr int PASSES = (SLAB_CHUNKS + NT - 1) / NT;
-      static_assert(SLAB_CHUNKS % NT == 0, "slab chunks must divide evenly over the block");
-      float4 ext[PASSES];
-      size_t orow[PASSES];
-      bool ok[PASSES];
-  #pragma unroll
-      for (int it = 0; it < PASSES; ++it) {
-        const int id = tid + it * NT;
-        const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
-        const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
-        ok[it] = gm_row < a.M_valid;
-        orow[it] = gm_row;
-        if constexpr (EPI == GEMM_EPI_TOKENS_F32) {
-          const int b = gm_row / a.tok_np, pidx = gm_row - b * a.tok_np;
-          orow[it] = (size_t)b * a.tok_n + a.tok_skip + pidx;
-          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(a.pos + (size_t)pidx * a.ldo + n0 + c * 4);
-        }
-        if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
-          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + orow[it] * a.ldo + n0 + c * 4);
-        }
-      }
+      // (b) slab -> global, whole rows
   #pragma unroll
       for (int it = 0; it < PASSES; ++it) {
         const int id = tid + it * NT;
