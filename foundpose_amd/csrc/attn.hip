@@ -3,7 +3,9 @@
 // Replaces softmax(q k^T / sqrt(64)) v inside the backbone's Attention.forward (the reference reaches it
 // through self.model(batch), /root/reference/utils/dinov2_utils.py:257; optional xformers path upstream).
 //
-// bf16 kernel (flash-style, one pass over the keys, fp32 online softmax):
+// bf16 kernels (flash-style, one pass over the keys, fp32 online softmax).  attn_bf16_w64_kernel (default: 64 queries
+// per wave, K/V tiles by LDS-DMA, see its header) and attn_bf16_kernel (32 queries per wave, register staging; kept as
+// the cross-check, FP_ATTN_W64=0) produce bit-identical results.  Common to both:
 //   * block = (128 queries, head, image), 4 waves x 32 queries; K tile and V tile (64 keys x 64 d each, rows of the
 //     qkv buffer) staged through registers into LDS, next tile's loads in flight under the MFMAs, one barrier per tile
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (operands swapped so a lane owns ONE query's scores:
@@ -14,6 +16,8 @@
 //     kh*8 + 4r + j of column d) from an LDS image cut into 16-column blocks.  No pre-transposed V^T copy in HBM
 //     (92 MB per layer at the bench batch) and no transposing epilogue in the qkv GEMM.
 // fp32 kernel (parity mode): one thread per query, K/V rows broadcast from LDS, exact expf.
+#include <cstdlib>
+#include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -36,7 +40,24 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][VTR_BYTES];  // [stage][K: 64 rows x 128 B swizzled | V: block image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
-  const int qt = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+  // Workgroup -> (query tile, head, image).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its
+  // own L2: when the (image, head) pairs divide by 8, all query tiles of a pair are given ids of ONE residue mod 8 so
+  // that the pair's K and V (2 x N x 128 B) are fetched into one L2 instead of eight.
+  int qt, head, img;
+  {
+    const int nqt = (a.n_tok + 127) / 128, pairs = a.heads * a.batch, i = blockIdx.x;
+    int pair;
+    if ((pairs & 7) == 0) {
+      const int j = i >> 3;
+      qt = j % nqt;
+      pair = (j / nqt) * 8 + (i & 7);
+    } else {
+      qt = i % nqt;
+      pair = i / nqt;
+    }
+    head = pair % a.heads;
+    img = pair / a.heads;
+  }
   const int N = a.n_tok, D = a.dim;
   const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
 
@@ -192,6 +213,213 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- bf16, 64 queries per wave
+// Same arithmetic as attn_bf16_kernel (identical MFMA operands and order per query => bit-identical output), different
+// work split: block = 256 queries = 4 waves x TWO 32-query blocks.  A K fragment (ds_read_b128) and a V^T fragment
+// (two transpose reads) feed two MFMAs instead of one, and a staged K/V tile serves 256 queries instead of 128, which
+// halves the LDS read, LDS write and L1 fill traffic per flop -- the old split kept the LDS pipe ~80 % busy.  K and V
+// tiles arrive by LDS-DMA (buffer_load_dwordx4 ... lds, whole 128-B rows, no staging registers, no ds_write):
+//   K image  [64 keys][128 B], 16-B chunk p of row r holds chunk p ^ ((r >> 1) & 7)            (b128 fragment reads)
+//   V image  [64 keys][128 B], 64-B half  g of row r holds half  g ^ ((r >> 1) & 1)            (transpose reads: the
+//            four keys x 64 B a half-wave touches then fall into four different bank quarters)
+// Rows past the last token read as zeros (buffer range check) and are masked exactly like before.
+typedef __attribute__((address_space(3))) void lds_void_t;
+
+__global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: DMA offsets
+  const int l31 = lane & 31, kh = lane >> 5;
+  int qt, head, img;
+  {
+    const int nqt = (a.n_tok + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    int pair;
+    if ((pairs & 7) == 0) {  // all query tiles of an (image, head) pair on one XCD (one L2), see attn_bf16_kernel
+      const int j = i >> 3;
+      qt = j % nqt;
+      pair = (j / nqt) * 8 + (i & 7);
+    } else {
+      qt = i % nqt;
+      pair = i / nqt;
+    }
+    head = pair % a.heads;
+    img = pair / a.heads;
+  }
+  const int N = a.n_tok, D = a.dim;
+  const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  const int q0 = qt * 256 + wave * 64;
+  const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
+
+  // ---- staging: wave w issues row groups 2w, 2w+1 (8 keys x 128 B each) of K and of V
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (unsigned)((size_t)N * a.ld_qkv * 2), 0x00020000);
+  const int sr = lane >> 3, sp = lane & 7;
+  const unsigned rowoff = (unsigned)(sr * a.ld_qkv) * 2u;
+  const unsigned voff_k0 = rowoff + ((sp ^ (sr >> 1)) << 4);        // even row group: swizzle (r >> 1) & 7 = sr >> 1
+  const unsigned voff_k1 = rowoff + ((sp ^ ((sr >> 1) + 4)) << 4);  // odd row group: ... + 4
+  const unsigned voff_v = rowoff + ((sp ^ (((sr >> 1) & 1) << 2)) << 4);
+  const unsigned tile_stride = (unsigned)(64 * a.ld_qkv) * 2u, grp_stride = (unsigned)(8 * a.ld_qkv) * 2u;
+  const unsigned soff_k = (unsigned)(D + head * 64) * 2u + 2u * wave * grp_stride, soff_v = soff_k + (unsigned)D * 2u;
+  auto stage_tile = [&](int kt, int stage) {
+    const unsigned t = kt * tile_stride;
+    char* kd = KV[stage][0] + wave * 2048;
+    char* vd = KV[stage][1] + wave * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(vd + 1024), 16, voff_v, soff_v + t + grp_stride, 0, 0);
+  };
+  const int nkt = (N + 63) / 64;
+  stage_tile(0, 0);
+
+  const float c = 0.125f * 1.44269504088896340736f;  // head_dim^-0.5 * log2(e)
+  // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d]
+  bf16x8 qf[2][4];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const int q = q0 + qb * 32 + l31;
+    const int qc = q < N ? q : N - 1;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+      qf[qb][ds] = *reinterpret_cast<const bf16x8*>(qkv + (size_t)qc * a.ld_qkv + head * 64 + (ds * 2 + kh) * 8);
+  }
+  f32x16 oacc[2][2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
+  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  // transpose-read base inside the V image: key = kh*8 + kq, 16-d block b, 8-B piece; the 64-B half flips with kq >> 1
+  const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
+  const int vrd0 = (kh * 8 + kq) * 128 + (((kq >> 1) & 1) << 6) + vb * 32 + (lane & 3) * 8;
+
+  // s_waitcnt as a BUILTIN (vmcnt(0), encoding 0x0f70): the compiler's wait-count pass sees it and knows the Q fragment
+  // loads have landed -- behind an opaque asm it re-waited for them inside the loop, with counts that also drained
+  // the LDS-DMA of the iteration (one full load latency exposed per tile)
+  __builtin_amdgcn_s_waitcnt(0x0f70);
+  __syncthreads();
+  // one key tile; RAGGED (the last tile when N % 64 != 0) is a separate instantiation so that the full tiles carry no
+  // masking code at all (inlined into one loop the compiler if-converts the mask into 120 selects per tile)
+  auto tile = [&](int kt, auto ragged) {
+    constexpr bool RAGGED = decltype(ragged)::value;
+    const int key0 = kt * 64;
+    const char* Ks = KV[kt & 1][0];
+    const char* Vs = KV[kt & 1][1];
+    if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);  // the other stage was last read one iteration ago
+    if (active) {
+      // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
+      f32x16 sacc[2][2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) sacc[qb][ks][r] = 0.f;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
+          sacc[0][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ds], sacc[0][ks], 0, 0, 0);
+          sacc[1][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ds], sacc[1][ks], 0, 0, 0);
+        }
+      }
+      bf16x8 pf[2][4];
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
+          const int lim = N - key0 - 4 * kh;
+#pragma unroll
+          for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[qb][ks][r] = -INFINITY;
+        }
+        // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
+        float mx = fmaxf(sacc[qb][0][0], sacc[qb][1][0]);
+#pragma unroll
+        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[qb][0][r]), sacc[qb][1][r]);  // v_max3_f32
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run[qb], mx);
+        // the running max stops moving after the first few tiles: skip the rescale of O and l unless some lane needs it
+        const bool grow = __any(m_new > m_run[qb]);
+        float alpha = 1.f;
+        if (grow) alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+        m_run[qb] = m_new;
+        float psum = 0.f;
+        const float mc = m_new * c;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][ks][r], c, -mc));
+            sacc[qb][ks][r] = p;
+            psum += p;
+          }
+        if (grow) {
+          l_run[qb] *= alpha;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) oacc[qb][i][r] *= alpha;
+        }
+        l_run[qb] += psum;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int kk = 0; kk < 2; ++kk) {
+            const int r0 = 8 * kk;
+            unsigned a0 = pack_bf16x2(sacc[qb][ks][r0 + 0], sacc[qb][ks][r0 + 1]);
+            unsigned a1 = pack_bf16x2(sacc[qb][ks][r0 + 2], sacc[qb][ks][r0 + 3]);
+            unsigned b0 = pack_bf16x2(sacc[qb][ks][r0 + 4], sacc[qb][ks][r0 + 5]);
+            unsigned b1 = pack_bf16x2(sacc[qb][ks][r0 + 6], sacc[qb][ks][r0 + 7]);
+            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+            pf[qb][ks * 2 + kk] = __builtin_bit_cast(bf16x8, make_uint4(s0[0], s1[0], s0[1], s1[1]));
+          }
+      }
+      // ---- O^T += V^T P^T over 4 steps of 16 keys; one V^T fragment serves both query blocks
+#pragma unroll
+      for (int kstep = 0; kstep < 4; ++kstep)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vp = Vs + (vrd0 ^ (dt << 6)) + kstep * 2048;  // + 512 B = 4 keys on
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 512));
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kstep], oacc[0][dt], 0, 0, 0);
+          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kstep], oacc[1][dt], 0, 0, 0);
+        }
+    }
+    if constexpr (!RAGGED) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
+      __syncthreads();
+    }
+  };
+  const int nfull = N / 64;
+  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+  if (nfull < nkt) tile(nfull, std::true_type{});
+
+  if (active) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int q = q0 + qb * 32 + l31;
+      const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
+      const float inv = 1.f / l_tot;
+      if (q < N) {
+        __bf16* o = reinterpret_cast<__bf16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int d = dt * 32 + 8 * g + 4 * kh;
+            uint2 pk = make_uint2(pack_bf16x2(oacc[qb][dt][4 * g + 0] * inv, oacc[qb][dt][4 * g + 1] * inv),
+                                  pack_bf16x2(oacc[qb][dt][4 * g + 2] * inv, oacc[qb][dt][4 * g + 3] * inv));
+            *reinterpret_cast<uint2*>(o + d) = pk;
+          }
+      }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fp32 parity-mode attention
 // qkv fp32 [B*N, 3D]; one thread per query row; keys/values of the (image, head) streamed through LDS.
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
@@ -249,8 +477,13 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
-    dim3 grid(cdiv(a.n_tok, 128), a.heads, a.batch);
-    hipLaunchKernelGGL(attn_bf16_kernel, grid, dim3(256), 0, st, a);
+    const char* w64_env = getenv("FP_ATTN_W64");  // read per call: tests compare the two kernels in one process
+    const int w64 = w64_env ? atoi(w64_env) : 1;
+    if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
+      hipLaunchKernelGGL(attn_bf16_w64_kernel, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(256), 0, st, a);
+    } else {
+      hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
+    }
   } else if (dtype == FP_DTYPE_F32) {
     dim3 grid(cdiv(a.n_tok, 256), a.heads, a.batch);
     hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, st, a);
