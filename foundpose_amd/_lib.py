@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16 = 0, 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -60,6 +60,7 @@ _PROTOS = {
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "fp_convert_f32_to_bf16": [vp, vp, i64, vp],
+    "fp_warp_crops": [vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp],
 }
 
 _lib = None

@@ -239,6 +239,18 @@ int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t st
   return convert_f32_to_bf16_launch(in, out, n, ST(stream));
 }
 
+int fp_warp_crops(const void* src, int n_src, int src_h, int src_w, int channels, int mode, const int32_t* src_index,
+                  const double* params, int batch, int out_h, int out_w, int depth_check, void* out, float* map_out,
+                  fp_stream_t stream) {
+  FP_REQUIRE(src && params && out, "fp_warp_crops: null pointer");
+  FP_REQUIRE(mode == FP_WARP_LINEAR || mode == FP_WARP_NEAREST, "fp_warp_crops: unknown mode %d", mode);
+  FP_REQUIRE(n_src >= 1 && src_h >= 1 && src_w >= 1 && batch >= 1 && out_h >= 1 && out_w >= 1, "fp_warp_crops: empty problem");
+  FP_REQUIRE(mode == FP_WARP_LINEAR ? channels >= 1 : channels == 1, "fp_warp_crops: a nearest-mode source is a single-channel u8 mask");
+  FP_REQUIRE(src_index || batch <= n_src, "fp_warp_crops: %d crops but %d source images and no src_index", batch, n_src);
+  WarpArgs a{src, n_src, src_h, src_w, channels, mode, src_index, params, batch, out_h, out_w, depth_check, out, map_out};
+  return launch_warp_crops(a, ST(stream));
+}
+
 // ------------------------------------------------------------------ ViT forward (launch sequence in C++)
 int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
                    int layer, fp_stream_t stream) {

@@ -62,6 +62,13 @@ struct SampleArgs {
   float* out;  // [num_points, C]
 };
 
+struct WarpArgs {
+  const void* src; int n_src, src_h, src_w, channels, mode;
+  const int* src_index; const double* params; int batch, out_h, out_w, depth_check;
+  void* out; float* map_out;
+};
+int launch_warp_crops(const WarpArgs& a, hipStream_t st);
+
 int launch_sqnorm_rows(const float* x, long long n, int d, int ld, float* out, hipStream_t st);
 int launch_normalize_rows(const float* x, long long n, int d, float eps, float* out, hipStream_t st);
 int launch_topk_rows(const float* vals, int rows, int n, int ld, const int* row_len, int k, int largest,

@@ -25,7 +25,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
 
-#define FP_ABI_VERSION 3
+#define FP_ABI_VERSION 4
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -166,6 +166,23 @@ int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, 
 int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok,
                  int dim, int heads, int dtype, fp_stream_t stream);
 int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream);
+
+/* ---- crop producer (the step right before the path) ---------------------------------------------------
+ * Batched misc.warp_image (utils/misc.py:458-519) as scripts/infer.py:433-450 calls it: every destination pixel of a
+ * crop camera is mapped through the source camera in fp64 (window_to_eye -> eye_to_world -> world_to_eye ->
+ * eye_to_window, points behind the source camera -> -1 when depth_check), cast to fp32 and resampled with cv2.remap
+ * semantics (constant border 0).
+ *   mode FP_WARP_LINEAR : src fp32 [n_src, src_h, src_w, channels] (HWC, [0,1]) -> out fp32 [batch, channels, out_h,
+ *                         out_w] (CHW: array_to_tensor(...).permute(2,0,1), infer.py:466-468); INTER_LINEAR, which is
+ *                         also what cv2.remap does for INTER_AREA
+ *   mode FP_WARP_NEAREST: src u8 [n_src, src_h, src_w] -> out u8 [batch, out_h, out_w]   (the modal mask)
+ * params [batch, 32] doubles per crop: crop camera f[2], c[2], R[9] (row-major rotation of T_world_from_eye), t[3],
+ * then the same 16 for the source camera.  src_index [batch] picks the source image of each crop (null: crop b reads
+ * image b).  map_out (may be null) receives the fp32 maps [batch, 2, out_h, out_w]. */
+enum { FP_WARP_LINEAR = 0, FP_WARP_NEAREST = 1 };
+int fp_warp_crops(const void* src, int n_src, int src_h, int src_w, int channels, int mode, const int32_t* src_index,
+                  const double* params, int batch, int out_h, int out_w, int depth_check, void* out, float* map_out,
+                  fp_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -270,6 +270,64 @@ def gen_hot_section(ref):
     print("hot_section_tiny", out["template_ids"], out["template_scores"], "Q", len(qp))
 
 
+def gen_crop(ref):
+    """Crop producer: crop box, virtual crop camera and the fp32 destination->source maps, from the reference's own
+    utils/misc.py (calc_crop_box, construct_crop_camera, warp_image) with a cv2.remap stand-in that captures the maps."""
+    import importlib
+    structs = importlib.import_module("utils.structs")
+    captured = {}
+
+    def capture(src, map_x, map_y, interpolation):
+        captured["map"] = (np.array(map_x), np.array(map_y))
+        return np.zeros(map_x.shape + src.shape[2:], dtype=src.dtype)
+
+    sys.modules["cv2"].remap = capture
+    rng = np.random.default_rng(11)
+
+    def rigid(angle_deg, axis, t):
+        a = np.asarray(axis, dtype=np.float64)
+        a /= np.linalg.norm(a)
+        th = np.deg2rad(angle_deg)
+        K = np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0]])
+        T = np.eye(4)
+        T[:3, :3] = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+        T[:3, 3] = t
+        return T
+
+    cases = [  # (name, width, height, f, c, T_world_from_eye, box ltrb, viewport, rel_pad)
+        ("lmo", 640, 480, (572.4114, 573.57043), (325.2611, 242.04899), np.eye(4), (250.0, 140.0, 380.0, 300.0), (56, 56), 0.2),
+        ("edge", 640, 480, (572.4114, 573.57043), (325.2611, 242.04899), rigid(33.0, (0.2, 1.0, -0.3), (0.1, -0.4, 1.2)),
+         (-20.0, 400.0, 90.0, 470.0), (56, 56), 0.2),
+        ("wide", 1920, 1080, (1066.778, 1067.487), (312.9869 + 640, 241.3109 + 300), rigid(-71.0, (1.0, 0.1, 0.4), (3.0, 0.2, -0.7)),
+         (900.0, 200.0, 1700.0, 520.0), (518, 518), 0.2),
+        ("tiny", 640, 480, (572.4114, 573.57043), (325.2611, 242.04899), rigid(5.0, (0.0, 0.0, 1.0), (0.0, 0.0, 0.0)),
+         (300.0, 200.0, 312.0, 230.0), (420, 420), 0.5),
+    ]
+    out = {"names": np.array([c[0] for c in cases])}
+    for name, w, h, f, c, T, box, vp, pad in cases:
+        cam = structs.PinholePlaneCameraModel(width=w, height=h, f=f, c=c, T_world_from_eye=T)
+        b = structs.AlignedBox2f(left=box[0], top=box[1], right=box[2], bottom=box[3])
+        cb = ref.misc.calc_crop_box(box=b, make_square=True)
+        cc = ref.misc.construct_crop_camera(box=cb, camera_model_c2w=cam, viewport_size=vp, viewport_rel_pad=pad)
+        ref.misc.warp_image(src_camera=cam, dst_camera=cc, src_image=np.zeros((h, w, 3), np.float32), interpolation=1)
+        mx, my = captured["map"]
+        rows = slice(None) if vp[0] <= 64 else slice(None, None, 37)
+        out.update({f"{name}_cam": np.array([w, h, *f, *c], dtype=np.float64), f"{name}_T": np.array(T),
+                    f"{name}_box": np.array(box), f"{name}_vp": np.array(vp), f"{name}_pad": np.float64(pad),
+                    f"{name}_crop_box": np.array([cb.left, cb.top, cb.right, cb.bottom]),
+                    f"{name}_crop_f": np.array(cc.f, dtype=np.float64), f"{name}_crop_c": np.array(cc.c, dtype=np.float64),
+                    f"{name}_crop_T": np.array(cc.T_world_from_eye), f"{name}_map_x": mx[rows], f"{name}_map_y": my[rows],
+                    f"{name}_map_sum": checksum(mx, my)})
+    # depth check: a destination camera turned 120 degrees away from the source sees rays behind it -> -1
+    src = structs.PinholePlaneCameraModel(width=320, height=240, f=(300.0, 300.0), c=(159.5, 119.5), T_world_from_eye=np.eye(4))
+    dst = structs.PinholePlaneCameraModel(width=48, height=40, f=(np.float32(20.0), np.float32(20.0)), c=(np.float32(23.5), np.float32(19.5)),
+                                          T_world_from_eye=rigid(80.0, (0.0, 1.0, 0.0), (0.0, 0.0, 0.0)))
+    ref.misc.warp_image(src_camera=src, dst_camera=dst, src_image=np.zeros((240, 320), np.uint8), interpolation=0)
+    out.update({"behind_map_x": captured["map"][0], "behind_map_y": captured["map"][1], "behind_dst_T": dst.T_world_from_eye})
+    np.savez_compressed(os.path.join(OUT, "crop_camera.npz"), **out)
+    print("crop_camera.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith("map_x")})
+
+
 def main():
     if not ref_shim.reference_available():
         sys.exit("reference not present; fixtures can only be generated in the build container")
@@ -279,6 +337,7 @@ def main():
     gen_points(ref)
     gen_extractor(ref)
     gen_hot_section(ref)
+    gen_crop(ref)
 
 
 if __name__ == "__main__":

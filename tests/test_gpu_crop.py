@@ -1,0 +1,99 @@
+"""Crop producer on the GPU: fp_warp_crops against the CPU oracle (oracle/crop.py, whose pixel map is pinned to the
+reference fixture in tests/test_crop_cpu.py).  Bit-exact: fp32 maps, resampled images and masks."""
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd import crop_util
+from oracle import crop as ocrop
+from tests.helpers import load_golden
+
+pytestmark = pytest.mark.gpu
+CASES = ["lmo", "edge", "wide", "tiny"]
+
+
+def _cameras(g, name):
+    w, h, fx, fy, cx, cy = g[f"{name}_cam"]
+    src = crop_util.PinholePlaneCameraModel(int(w), int(h), (fx, fy), (cx, cy), g[f"{name}_T"])
+    box = crop_util.calc_crop_box(crop_util.AlignedBox2f(*g[f"{name}_box"]), make_square=True)
+    dst = crop_util.construct_crop_camera(box, src, tuple(int(v) for v in g[f"{name}_vp"]), float(g[f"{name}_pad"]))
+    return src, dst
+
+
+def _scene(h, w, seed):
+    rng = np.random.default_rng(seed)
+    img = rng.random((h, w, 3), dtype=np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    mask = (((xx - 0.55 * w) ** 2 + (yy - 0.45 * h) ** 2) < (0.3 * min(h, w)) ** 2).astype(np.uint8)
+    return img, mask
+
+
+@pytest.mark.parametrize("name", CASES)
+def test_warp_image_matches_oracle_bitwise(name):
+    g = load_golden("crop_camera")
+    src, dst = _cameras(g, name)
+    img, mask = _scene(src.height, src.width, 3)
+    params = crop_util.camera_pair_params(src, dst)
+    mx, my = ocrop.crop_maps(params, dst.height, dst.width)
+    out, maps = crop_util._warp(torch.from_numpy(img)[None].cuda(), crop_util.INTER_LINEAR, None, params[None],
+                                (dst.height, dst.width), True, want_maps=True)
+    np.testing.assert_array_equal(maps[0, 0].cpu().numpy(), mx)
+    np.testing.assert_array_equal(maps[0, 1].cpu().numpy(), my)
+    ref = ocrop.remap_linear(img, mx, my)
+    np.testing.assert_array_equal(out[0].permute(1, 2, 0).cpu().numpy(), ref)
+    assert (ref != 0).any()
+    # reference-shaped single-image call: HxWxC result, INTER_AREA resampled as INTER_LINEAR like cv2.remap does
+    one = crop_util.warp_image(src, dst, torch.from_numpy(img).cuda(), interpolation=crop_util.INTER_AREA)
+    np.testing.assert_array_equal(one.cpu().numpy(), ref)
+    m = crop_util.warp_image(src, dst, torch.from_numpy(mask).cuda(), interpolation=crop_util.INTER_NEAREST)
+    assert m.dtype == torch.uint8 and m.shape == (dst.height, dst.width)
+    np.testing.assert_array_equal(m.cpu().numpy(), ocrop.remap_nearest(mask, mx, my))
+
+
+def test_depth_check_and_border():
+    g = load_golden("crop_camera")
+    src = crop_util.PinholePlaneCameraModel(320, 240, (300.0, 300.0), (159.5, 119.5), np.eye(4))
+    dst = crop_util.PinholePlaneCameraModel(48, 40, (np.float32(20.0),) * 2, (np.float32(23.5), np.float32(19.5)), g["behind_dst_T"])
+    img, _ = _scene(240, 320, 5)
+    params = crop_util.camera_pair_params(src, dst)
+    out, maps = crop_util._warp(torch.from_numpy(img)[None].cuda(), crop_util.INTER_LINEAR, None, params[None], (40, 48), True, want_maps=True)
+    np.testing.assert_array_equal(maps[0, 0].cpu().numpy(), g["behind_map_x"])   # straight against the reference's maps
+    np.testing.assert_array_equal(maps[0, 1].cpu().numpy(), g["behind_map_y"])
+    behind = g["behind_map_x"] == -1
+    assert (out[0].permute(1, 2, 0).cpu().numpy()[behind] == 0).all()
+    nocheck = crop_util._warp(torch.from_numpy(img)[None].cuda(), crop_util.INTER_LINEAR, None, params[None], (40, 48), False, want_maps=True)[1]
+    assert (nocheck[0, 0].cpu().numpy()[behind] != -1).any()
+
+
+def test_batched_crops_feed_the_extractor_layout():
+    """All detections of an image in one launch: [B,3,S,S] crops + [B,S,S] masks, equal to per-detection calls."""
+    src = crop_util.PinholePlaneCameraModel(640, 480, (572.4114, 573.57043), (325.2611, 242.04899), np.eye(4))
+    img, _ = _scene(480, 640, 9)
+    rng = np.random.default_rng(1)
+    boxes, masks = [], []
+    for _ in range(5):
+        l, t = rng.uniform(0, 400), rng.uniform(0, 300)
+        w, h = rng.uniform(40, 220), rng.uniform(40, 170)
+        boxes.append((l, t, l + w, t + h))
+        m = np.zeros((480, 640), np.uint8)
+        m[int(t):int(t + h), int(l):int(l + w)] = 1
+        masks.append(m)
+    image = torch.from_numpy(img).cuda()
+    crops, cmasks, cams = crop_util.crop_detections(image, torch.from_numpy(np.stack(masks)).cuda(), boxes, src, (420, 420), 0.2)
+    assert crops.shape == (5, 3, 420, 420) and crops.is_contiguous() and cmasks.shape == (5, 420, 420)
+    for b in range(5):
+        mx, my = ocrop.crop_maps(crop_util.camera_pair_params(src, cams[b]), 420, 420)
+        np.testing.assert_array_equal(crops[b].permute(1, 2, 0).cpu().numpy(), ocrop.remap_linear(img, mx, my))
+        np.testing.assert_array_equal(cmasks[b].cpu().numpy(), ocrop.remap_nearest(masks[b], mx, my))
+        ys, xs = np.nonzero(cmasks[b].cpu().numpy())   # the box is centred and padded inside the viewport
+        assert xs.min() > 0 and xs.max() < 419 and abs(0.5 * (xs.min() + xs.max()) - 209.5) < 12
+
+
+def test_loud_failures():
+    src = crop_util.PinholePlaneCameraModel(64, 48, (50.0, 50.0), (31.5, 23.5), np.eye(4))
+    with pytest.raises(Exception, match="no CPU fallback|CPU tensor"):
+        crop_util.warp_image(src, src, torch.zeros(48, 64, 3))
+    with pytest.raises(ValueError):
+        crop_util.warp_image(src, src, torch.zeros(48, 64, 3).cuda(), interpolation=2)  # INTER_CUBIC: not on this path
+    with pytest.raises(ValueError, match="rigid"):
+        crop_util.PinholePlaneCameraModel(64, 48, 50.0, (0, 0), np.diag([2.0, 1, 1, 1]))

@@ -63,6 +63,21 @@ def main():
         w, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
         ms = timeit(lambda: ops.layernorm(x, w, b, torch.bfloat16))
         print(f"layernorm rows={M}: {ms*1e3:8.1f} us  {M*D*6/ms/1e6:7.1f} GB/s", flush=True)
+    if "crop" in what:
+        import numpy as np
+        from foundpose_amd import crop_util
+        cam = crop_util.PinholePlaneCameraModel(640, 480, (572.4114, 573.57043), (325.2611, 242.04899), np.eye(4))
+        image = torch.rand(480, 640, 3, device=dev)
+        rng = np.random.default_rng(0)
+        boxes = [(l, t, l + rng.uniform(60, 220), t + rng.uniform(60, 170)) for l, t in zip(rng.uniform(0, 400, B), rng.uniform(0, 300, B))]
+        masks = torch.zeros(B, 480, 640, dtype=torch.uint8, device=dev)
+        cams = [crop_util.construct_crop_camera(crop_util.calc_crop_box(crop_util.AlignedBox2f(*b), make_square=True), cam, (518, 518), 0.2) for b in boxes]
+        params = np.stack([crop_util.camera_pair_params(cam, c) for c in cams])
+        idx = torch.zeros(B, dtype=torch.int32, device=dev)
+        ms = timeit(lambda: crop_util._warp(image[None], crop_util.INTER_LINEAR, idx, params, (518, 518), True), iters=20)
+        ms2 = timeit(lambda: crop_util._warp(masks, crop_util.INTER_NEAREST, None, params, (518, 518), True), iters=20)
+        print(f"warp_crops B={B} 518x518 from 640x480: rgb {ms*1e3:8.1f} us ({B*3*518*518*4/ms/1e6:7.1f} GB/s written, incl. the "
+              f"host->device copy of {params.nbytes} B of camera parameters), mask {ms2*1e3:8.1f} us", flush=True)
 
 
 if __name__ == "__main__":
