@@ -55,6 +55,15 @@ class FoundPoseEngine:
         feats = self._project(raw, counts, det_obj)
         return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
 
+    def infer_detections(self, image_hwc: torch.Tensor, masks_modal: torch.Tensor, boxes_amodal, camera_c2w,
+                         crop_size, crop_rel_pad: float, det_obj: Optional[Sequence[int]] = None, keep_debug: bool = False):
+        """From the uncropped input image: the crop producer (infer.py:411-450, foundpose_amd.crop_util) followed by
+        infer_batch, without leaving HBM.  image_hwc float32 [H,W,3] in [0,1], masks_modal uint8 [B,H,W], boxes_amodal
+        B x (left, top, right, bottom).  -> (MatchResult, crop cameras: the cameras the PnP tail solves in)."""
+        from . import crop_util
+        crops, crop_masks, cams = crop_util.crop_detections(image_hwc, masks_modal, boxes_amodal, camera_c2w, crop_size, crop_rel_pad)
+        return self.infer_batch(crops, crop_masks, det_obj, keep_debug), cams
+
     def _project(self, raw: torch.Tensor, counts: Sequence[int], det_obj: Sequence[int]) -> torch.Tensor:
         if raw.shape[1] == self.bank.feat_dim:
             return raw

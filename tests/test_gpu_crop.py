@@ -89,6 +89,43 @@ def test_batched_crops_feed_the_extractor_layout():
         assert xs.min() > 0 and xs.max() < 419 and abs(0.5 * (xs.min() + xs.max()) - 209.5) < 12
 
 
+def test_engine_from_uncropped_image():
+    """engine.infer_detections == crop producer followed by infer_batch on the crops it made (the planted query of the
+    hot-section fixture is pasted into a larger image and seen through an identity-like crop camera)."""
+    from foundpose_amd import engine, feature_util, projector_util, repre_util
+    from foundpose_amd.bank import DeviceBank
+    from tests.helpers import TINY
+    g = load_golden("hot_section_tiny")
+    S = int(g["image_size"])
+    ex = feature_util.make_feature_extractor("dinov2_version=tiny-reg_stride=14_facet=token_layer=2_logbin=0_norm=1",
+                                             seed=int(g["weights_seed"]), precision="fp32", arch=TINY).to("cuda")
+    proj = projector_util.projector_from_tensordict({"pca_projector": {
+        "components": torch.from_numpy(g["pca_components"]), "mean": torch.from_numpy(g["pca_mean"]), "whiten": torch.tensor(False)}})
+    repre = repre_util.FeatureBasedObjectRepre(
+        vertices=torch.from_numpy(g["vertices"]), feat_vectors=torch.from_numpy(g["bank_feats"]),
+        feat_to_template_ids=torch.from_numpy(g["f2t"]), feat_cluster_centroids=torch.from_numpy(g["centroids"]),
+        feat_cluster_idfs=torch.from_numpy(g["idfs"]), template_descs=torch.from_numpy(g["template_descs"]),
+        template_desc_opts=repre_util.TemplateDescOpts(), feat_raw_projectors=[proj])
+    eng = engine.FoundPoseEngine(ex, DeviceBank([repre]), 14.0, 5, 300, tie_order="torch")
+    H, W = 3 * S, 4 * S
+    image = torch.rand(H, W, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    image[S:2 * S, 2 * S:3 * S] = torch.from_numpy(g["q_img"]).cuda().permute(1, 2, 0)
+    masks = torch.zeros(2, H, W, dtype=torch.uint8).cuda()
+    masks[0, S:2 * S, 2 * S:3 * S] = torch.from_numpy(g["tpl_masks"][4]).cuda()
+    masks[1, S // 2:S, S // 2:2 * S] = 1
+    boxes = [(2 * S + 3.0, S + 2.0, 3 * S - 4.0, 2 * S - 3.0), (S / 2, S / 2, 2.0 * S, 1.0 * S)]
+    cam = crop_util.PinholePlaneCameraModel(W, H, (900.0, 900.0), (W / 2 - 0.5, H / 2 - 0.5), np.eye(4))
+    res, cams = eng.infer_detections(image, masks, boxes, cam, (S, S), 0.2)
+    crops, cmasks, cams2 = crop_util.crop_detections(image, masks, boxes, cam, (S, S), 0.2)
+    ref = eng.infer_batch(crops, cmasks)
+    assert len(cams) == 2 and np.array_equal(cams[0].T_world_from_eye, cams2[0].T_world_from_eye)
+    for b in range(2):
+        for s_, b_ in zip(ref.corresp_list(b), res.corresp_list(b)):
+            assert int(s_["template_id"]) == int(b_["template_id"])
+            assert torch.equal(s_["coord_2d"], b_["coord_2d"]) and torch.equal(s_["coord_3d"], b_["coord_3d"])
+    assert len(res.corresp_list(0)) == 5 and res.corresp_list(0)[0]["coord_2d"].shape[0] >= 6  # enough for the PnP tail
+
+
 def test_loud_failures():
     src = crop_util.PinholePlaneCameraModel(64, 48, (50.0, 50.0), (31.5, 23.5), np.eye(4))
     with pytest.raises(Exception, match="no CPU fallback|CPU tensor"):
