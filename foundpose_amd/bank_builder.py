@@ -82,6 +82,28 @@ def extract_template_features(extractor, templates: torch.Tensor, masks: torch.T
     return torch.cat(feats), torch.cat(ids), torch.cat(pts)
 
 
+def register_templates_in_3d(extractor, templates: torch.Tensor, depths: torch.Tensor, masks: torch.Tensor, cameras,
+                             Ts_model_from_camera: torch.Tensor, grid_cell: float = 14.0, batch_size: int = 32):
+    """Batched feature_util.get_visual_features_registered_in_3d over all rendered templates of an object
+    (scripts/gen_repre.py:136-214): masks eroded by 5x5, grid points inside them lifted through the depth images and
+    moved to model space, patch features sampled at the same points from batched extractor forwards.
+
+    templates [T,3,S,S] f32, depths [T,S,S] f32, masks [T,S,S], cameras: T pinhole models (f, c), Ts_model_from_camera
+    [T,4,4] -> (features [N_f, D], feat_to_template_ids [N_f] i32, vertices [N_f, 3] in model space,
+    feat_to_vertex_ids [N_f] i32)."""
+    from . import feature_util
+    eroded = torch.stack([feature_util.erode_mask(masks[t].cuda()) for t in range(masks.shape[0])])
+    feats, f2t, pts = extract_template_features(extractor, templates, eroded, grid_cell, batch_size)
+    verts = torch.empty(pts.shape[0], 3, dtype=torch.float32, device=pts.device)
+    off = template_offsets(f2t, templates.shape[0]).tolist()
+    for t in range(templates.shape[0]):
+        a, b = off[t], off[t + 1]
+        if b > a:
+            v = feature_util.lift_2d_points_to_3d(pts[a:b], depths[t].cuda(), cameras[t])
+            verts[a:b] = feature_util.transform_3d_points_torch(Ts_model_from_camera[t].cuda(), v)
+    return feats, f2t, verts, torch.arange(pts.shape[0], dtype=torch.int32, device=pts.device)
+
+
 def build_object_repre(raw_features: torch.Tensor, feat_to_template_ids: torch.Tensor, vertices: torch.Tensor,
                        num_templates: int, pca_components: int = 256, pca_max_samples: int = 100000,
                        cluster_num: int = 2048, cluster_iters: int = 50,

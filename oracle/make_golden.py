@@ -328,6 +328,29 @@ def gen_crop(ref):
     print("crop_camera.npz", {k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items() if k.endswith("map_x")})
 
 
+def gen_lift(ref):
+    """feature_util.lift_2d_points_to_3d + geometry.transform_3d_points_torch of the reference on a synthetic depth map."""
+    import importlib
+    structs = importlib.import_module("utils.structs")
+    geometry = importlib.import_module("utils.geometry")
+    g = torch.Generator().manual_seed(21)
+    S = 84
+    depth = 400.0 + 100.0 * torch.rand(S, S, generator=g)
+    cam = structs.PinholePlaneCameraModel(width=S, height=S, f=(131.7, 129.3), c=(41.2, 40.6), T_world_from_eye=np.eye(4))
+    grid = ref.feature_util.generate_grid_points((S, S), 14.0)
+    mask = torch.zeros(S, S, dtype=torch.uint8)
+    mask[10:70, 5:80] = 1
+    pts = ref.feature_util.filter_points_by_mask(grid, mask)
+    v_cam = ref.feature_util.lift_2d_points_to_3d(points=pts, depth_image=depth, camera_model=cam)
+    T = torch.eye(4)
+    T[:3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+    T[:3, 3] = torch.tensor([12.0, -7.5, 310.0])
+    v_model = geometry.transform_3d_points_torch(T, v_cam)
+    np.savez_compressed(os.path.join(OUT, "lift_3d.npz"), depth=t2n(depth), mask=t2n(mask), points=t2n(pts), cam=np.array([131.7, 129.3, 41.2, 40.6]),
+                        T=t2n(T), vertices_in_cam=t2n(v_cam), vertices_in_model=t2n(v_model))
+    print("lift_3d.npz", v_model.shape)
+
+
 def main():
     if not ref_shim.reference_available():
         sys.exit("reference not present; fixtures can only be generated in the build container")
@@ -338,6 +361,7 @@ def main():
     gen_extractor(ref)
     gen_hot_section(ref)
     gen_crop(ref)
+    gen_lift(ref)
 
 
 if __name__ == "__main__":

@@ -111,3 +111,39 @@ def test_build_object_repre_end_to_end_retrieval():
     assert int(corresp[0]["template_id"]) == 7 and float(corresp[0]["template_score"]) > 0.999
     first = int(torch.nonzero(sel)[0])
     assert torch.equal(corresp[0]["nn_vertex_ids"].cpu() - first, corresp[0]["coord_2d_ids"].cpu())  # patch i <-> its own bank row
+
+
+def test_register_templates_in_3d_batched_equals_per_template():
+    """bank_builder.register_templates_in_3d (batched) == feature_util.get_visual_features_registered_in_3d per template
+    (the reference's per-template routine, feature_util.py:162-237), and the lifted vertices re-project onto their pixels."""
+    from foundpose_amd import bank_builder, crop_util, feature_util, synthetic
+    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", seed=3).to("cuda")
+    T, S = 5, 224
+    templates = synthetic.make_crops(T, S, seed=4).cuda()
+    masks = synthetic.make_disc_mask(S).unsqueeze(0).repeat(T, 1, 1).cuda()
+    masks[1, :, :60] = 0
+    g = torch.Generator().manual_seed(8)
+    depths = (500.0 + 80.0 * torch.rand(T, S, S, generator=g)).cuda()
+    cams = [crop_util.PinholePlaneCameraModel(S, S, (300.0 + 5 * t, 310.0), (S / 2 - 0.5, S / 2 + 1.5), np.eye(4)) for t in range(T)]
+    Ts = torch.eye(4).repeat(T, 1, 1)
+    for t in range(T):
+        Ts[t, :3, :3] = torch.linalg.qr(torch.randn(3, 3, generator=g))[0]
+        Ts[t, :3, 3] = torch.randn(3, generator=g) * 50
+    feats, f2t, verts, f2v = bank_builder.register_templates_in_3d(ex, templates, depths, masks, cams, Ts, batch_size=2)
+    assert torch.equal(f2v.cpu(), torch.arange(feats.shape[0], dtype=torch.int32))
+    r0 = 0
+    for t in range(T):
+        fv, vid, vm = feature_util.get_visual_features_registered_in_3d(templates[t], depths[t], masks[t], cams[t], Ts[t], ex, 14.0)
+        n = fv.shape[0]
+        assert n > 20 and bool((f2t[r0:r0 + n] == t).all())
+        assert torch.equal(vm, verts[r0:r0 + n])
+        assert float((fv - feats[r0:r0 + n]).abs().max()) <= 2e-2 * float(fv.abs().max())  # bf16 ViT, batch of 1 vs batch of 2
+        # back to the camera and onto the image plane: the pixel the vertex was lifted from
+        v_cam = (vm - Ts[t, :3, 3].cuda()) @ Ts[t, :3, :3].cuda()
+        f = 0.5 * (cams[t].f[0] + cams[t].f[1])
+        uv = v_cam[:, :2] / v_cam[:, 2:3] * f + torch.tensor(cams[t].c, dtype=torch.float32).cuda()
+        grid = feature_util.generate_grid_points((S, S), 14.0).cuda()
+        q = feature_util.filter_points_by_mask(grid, feature_util.erode_mask(masks[t]))
+        assert float((uv - q).abs().max()) < 1e-2
+        r0 += n
+    assert r0 == feats.shape[0]
