@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16 = 0, 1
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -57,6 +57,8 @@ _PROTOS = {
     "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "fp_gemm_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_quantize_fp8": [vp, i32, i64, f32, vp, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "fp_convert_f32_to_bf16": [vp, vp, i64, vp],

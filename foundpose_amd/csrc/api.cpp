@@ -211,6 +211,23 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }
 
+int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                const float* col_scale, void* out, int ldo, int epilogue, fp_stream_t stream) {
+  FP_REQUIRE(A && W && out, "fp_gemm_fp8: null pointer");
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = col_scale; a.out = out; a.ldo = ldo;
+  return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
+}
+
+int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream) {
+  FP_REQUIRE(in && out, "fp_quantize_fp8: null pointer");
+  FP_REQUIRE(in_dtype == FP_F32 || in_dtype == FP_BF16, "fp_quantize_fp8: input must be fp32 or bf16");
+  FP_REQUIRE(scale > 0.f, "fp_quantize_fp8: scale must be positive");
+  return quantize_fp8_launch(in, in_dtype, n, scale, out, ST(stream));
+}
+
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_f32: null pointer");

@@ -73,7 +73,17 @@ FP_DEVICE f32x2 gelu_pk(f32x2 x) {
 }
 
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32.
-template <int EPI, int BM, int BN, int WM, int WN>
+// F8: the operands are OCP fp8 (e4m3) instead of bf16.  An fp8 row of K elements is addressed as a bf16 row of K/2
+// elements (the host passes K/2, lda/2, ldw/2), so a K-tile is the same 128-B-per-row LDS image holding 128 k-values and
+// the staging code is shared; the tile is consumed by two v_mfma_scale_f32_32x32x64_f8f6f4 per accumulator (unit block
+// scales: plain fp8 products, fp32 accumulation, twice the bf16 MFMA rate) whose operand -- lane (row, kh) holds k =
+// 32 kh .. 32 kh + 31 of a 64-wide step, tools/ubench/fp8_probe.hip -- is two adjacent 16-B chunks of the row.
+// Dequantisation lives in the epilogue: out = (acc + bias) * gamma with gamma = activation scale x per-channel weight
+// scale (x LayerScale) and bias pre-divided by that scale on the host.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+typedef __attribute__((ext_vector_type(4))) int i32x4;
+
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -153,6 +163,31 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         const bool more = t + 1 < ke;
         const char* As = smem + cur * STAGE;
         const char* Ws = As + A_BYTES;
+        if constexpr (F8) {
+#pragma unroll
+          for (int s = 0; s < 2; ++s) {
+            if (more) {
+#pragma unroll
+              for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s * 2 * PER_KS + q, t + 1, nxt);
+            }
+            const int chunk = s * 4 + kh * 2;
+            i32x8 af[TM], wf[TN];
+            auto frag8 = [&](const char* base, int row) {
+              const i32x4 lo = __builtin_bit_cast(i32x4, read_frag(base, row, chunk));
+              const i32x4 hi = __builtin_bit_cast(i32x4, read_frag(base, row, chunk + 1));
+              return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            };
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = frag8(As, wm * (BM / WM) + i * 32 + l31);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) wf[j] = frag8(Ws, wn * (BN / WN) + j * 32 + l31);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+          }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           if (more) {
@@ -172,6 +207,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
         }
       }
+        }
       __syncthreads();
     }
     if (a.dbg) ts2 = __builtin_readcyclecounter();
@@ -186,6 +222,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     // proj 152 -> 141 us, fc2 386 -> 374 us).  Only the small fp32 bias / patch-embed outputs stay register-direct.
     constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 ||
                               EPI == GEMM_EPI_SWIGLU_BF16 || EPI == GEMM_EPI_LS_RESID_F32;
+    static_assert(!F8 || USE_SLAB, "the fp8 kernels exist for the slab epilogues only");
     if constexpr (USE_SLAB) {
     constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
     constexpr int ESZ = OUT_F32 ? 4 : 2;
@@ -204,7 +241,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       for (int g = 0; g < 4; ++g) {
         const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
         bias[tn][g] = *reinterpret_cast<const float4*>(a.bias + n);
-        if constexpr (EPI == GEMM_EPI_LS_RESID_F32) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
+        if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || F8) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
       }
     __syncthreads();  // every wave is done with the operand tiles in LDS
   #pragma unroll
@@ -245,6 +282,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
+          if constexpr (F8 && EPI != GEMM_EPI_LS_RESID_F32) {  // dequantise before the non-linearity
+            const float4 gm = gam[tn][g];
+            v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
+          }
           if constexpr (EPI == GEMM_EPI_GELU_BF16) {
             const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
             v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
@@ -356,7 +397,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   unsigned grid = (a.M / BM) * (a.N / BN);
@@ -374,11 +415,11 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
@@ -395,6 +436,25 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
 }
 
 }  // namespace
+
+// fp8 (e4m3) operands: A [M, K] and W [N, K] one byte per element, K a multiple of 128, M and N multiples of 256;
+// a.gamma = dequantisation scale per output column (x LayerScale for LS_RESID), a.bias already divided by it.
+int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
+  GemmBf16Args a = a_in;
+  FP_REQUIRE(a.M > 0 && a.M % 256 == 0 && a.N > 0 && a.N % 256 == 0, "gemm_fp8: M (%d) and N (%d) must be positive multiples of 256", a.M, a.N);
+  FP_REQUIRE(a.K > 0 && a.K % 128 == 0, "gemm_fp8: K (%d) must be a multiple of 128", a.K);
+  FP_REQUIRE(a.bias != nullptr && a.gamma != nullptr, "gemm_fp8: bias and the per-column scale are required");
+  FP_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.ldo % 4 == 0, "gemm_fp8: leading dims must keep 16-byte alignment");
+  a.K /= 2; a.lda /= 2; a.ldw /= 2;  // an fp8 row addressed as a bf16 row of half the length (see the kernel header)
+  switch (epi) {
+    case GEMM_EPI_BIAS_BF16: return launch_cfg<GEMM_EPI_BIAS_BF16, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_GELU_BF16: return launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_LS_RESID_F32: return launch_cfg<GEMM_EPI_LS_RESID_F32, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_SWIGLU_BF16: return launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true>(a, st);
+  }
+  fp_set_error("gemm_fp8: epilogue %d is not available for fp8 operands", epi);
+  return FP_ERR_UNSUPPORTED;
+}
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
   FP_REQUIRE(a.M > 0 && a.M % 128 == 0, "gemm_bf16: M (%d) must be a positive multiple of 128 (pad the activation buffer)", a.M);

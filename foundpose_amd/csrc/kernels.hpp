@@ -105,6 +105,7 @@ struct GemmBf16Args {
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
+int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
 
 // ---------------------------------------------------------------- dtypes of the C ABI
 enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1 };
@@ -132,6 +133,7 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
                     int out_dtype, hipStream_t st);
 int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
+int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st);
 int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st);
 
 struct CosineArgs {

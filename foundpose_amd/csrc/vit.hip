@@ -163,6 +163,61 @@ int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* toke
   return FP_OK;
 }
 
+// ---------------------------------------------------------------- fp8 (OCP e4m3) quantisation of a GEMM operand
+// out[i] = e4m3(clamp(in[i] * scale, +-448)), round to nearest even (v_cvt_pk_fp8_f32; gfx950 converts to the OCP format).
+// 16 elements per thread: 16 output bytes, one 16-B store.
+template <typename T>
+__global__ __launch_bounds__(256) void quantize_fp8_kernel(const T* __restrict__ in, unsigned char* __restrict__ out, long long n, float scale) {
+  const long long i0 = ((long long)blockIdx.x * 256 + threadIdx.x) * 16;
+  if (i0 >= n) return;
+  float v[16];
+  if (i0 + 16 <= n) {
+    if constexpr (sizeof(T) == 4) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(in + i0 + 4 * q);
+        v[4 * q] = x.x; v[4 * q + 1] = x.y; v[4 * q + 2] = x.z; v[4 * q + 3] = x.w;
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const uint4 x = *reinterpret_cast<const uint4*>(in + i0 + 8 * q);
+        const unsigned w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          v[8 * q + 2 * j] = __uint_as_float(w[j] << 16);
+          v[8 * q + 2 * j + 1] = __uint_as_float(w[j] & 0xffff0000u);
+        }
+      }
+    }
+  } else {
+    for (int j = 0; j < 16; ++j) v[j] = i0 + j < n ? (float)in[i0 + j] : 0.f;
+  }
+  unsigned o[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fminf(fmaxf(v[4 * q + j] * scale, -448.f), 448.f);
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+    o[q] = (unsigned)w;
+  }
+  if (i0 + 16 <= n) *reinterpret_cast<uint4*>(out + i0) = make_uint4(o[0], o[1], o[2], o[3]);
+  else for (int j = 0; j < 16 && i0 + j < n; ++j) out[i0 + j] = (unsigned char)(o[j >> 2] >> (8 * (j & 3)));
+}
+
+int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st) {
+  if (n == 0) return FP_OK;
+  const unsigned grid = (unsigned)((n + 4095) / 4096);
+  if (in_dtype == FP_DTYPE_BF16)
+    hipLaunchKernelGGL(quantize_fp8_kernel<__bf16>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const __bf16*>(in), reinterpret_cast<unsigned char*>(out), n, scale);
+  else
+    hipLaunchKernelGGL(quantize_fp8_kernel<float>, dim3(grid), dim3(256), 0, st, reinterpret_cast<const float*>(in), reinterpret_cast<unsigned char*>(out), n, scale);
+  FP_CHECK_LAUNCH("quantize_fp8");
+  return FP_OK;
+}
+
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st) {
   if (n == 0) return FP_OK;
   hipLaunchKernelGGL(f32_to_bf16_kernel, dim3((unsigned)((n / 2 + 256) / 256)), dim3(256), 0, st, in, reinterpret_cast<__bf16*>(out), n);

@@ -129,6 +129,32 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma=None, 
     return out
 
 
+def quantize_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """e4m3(clamp(x * scale, +-448)) -> torch.float8_e4m3fn tensor of x's shape (x fp32 or bf16, contiguous)."""
+    require_cuda(x)
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous():
+        raise ValueError("quantize_fp8 takes a contiguous fp32 or bf16 tensor")
+    out = torch.empty(x.shape, dtype=torch.float8_e4m3fn, device=x.device)
+    call("fp_quantize_fp8", ptr(x), _lib.FP_BF16 if x.dtype == torch.bfloat16 else _lib.FP_F32, x.numel(), float(scale), ptr(out), stream())
+    return out
+
+
+def gemm_fp8(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, col_scale: torch.Tensor, out=None, epilogue: int = 0,
+             m_valid: Optional[int] = None) -> torch.Tensor:
+    """fp8 x fp8 -> fp32-accumulated GEMM: out = epilogue((a @ w.T + bias) * col_scale), a [M, K] and w [N, K] in
+    torch.float8_e4m3fn; bias is the true bias divided by col_scale (see include/foundpose_amd.h)."""
+    require_cuda(a, w, bias, col_scale)
+    if a.dtype != torch.float8_e4m3fn or w.dtype != torch.float8_e4m3fn:
+        raise ValueError("gemm_fp8 operands must be torch.float8_e4m3fn")
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=torch.float32 if epilogue == 3 else torch.bfloat16, device=a.device)
+    call("fp_gemm_fp8", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid,
+         ptr(bias), ptr(col_scale), ptr(out), out.stride(0), epilogue, stream())
+    return out
+
+
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_dtype: torch.dtype, eps: float = 1e-6):
     require_cuda(x, weight, bias)
     rows, D = x.shape

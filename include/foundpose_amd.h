@@ -25,7 +25,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
 
-#define FP_ABI_VERSION 4
+#define FP_ABI_VERSION 5
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -159,6 +159,15 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
  * tuning bits: epilogue | (128 << 8) or | (256 << 8) forces that block tile (default: chosen from the shape) */
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
+/* fp8 GEMM (BASELINE config 5, "ViT-g/14 fp8"): A [M, K] and W [N, K] hold OCP e4m3 bytes (fp_quantize_fp8), products
+ * and accumulation in fp32 on the block-scaled MFMA with unit scales (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16
+ * rate).  out = epilogue((acc + bias[n]) * col_scale[n]): col_scale = 1 / (activation scale x weight scale of channel
+ * n) (x LayerScale gamma for epilogue 3), bias pre-divided by col_scale.  Epilogues 0, 1, 3, 6 as fp_gemm_bf16;
+ * M, N multiples of 256, K a multiple of 128. */
+int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                const float* col_scale, void* out, int ldo, int epilogue, fp_stream_t stream);
+/* out[i] = e4m3(clamp(in[i] * scale, +-448)), round to nearest even; in fp32 or bf16 (in_dtype FP_F32 / FP_BF16) */
+int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream);
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);

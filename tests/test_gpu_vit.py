@@ -290,3 +290,70 @@ def test_gemm_bf16_operands_beyond_4gib():
         ref = a[r].double() @ w.double().T
         assert float((out[r].double() - ref).abs().max()) < 1e-3 * float(ref.abs().max()), r
     assert float(out[300000].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ fp8 operands (BASELINE config 5: ViT-g/14 fp8)
+def _fake_quant(x, scale):
+    return (x.float() * scale).clamp(-448, 448).to(torch.float8_e4m3fn)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_quantize_fp8_matches_torch_cast(dtype):
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(5)
+    x = (torch.randn(3, 4099, generator=g) * 3).to(dtype)
+    x[0, :8] = torch.tensor([0.0, -0.0, 1e-9, 500.0, -1e6, 447.9, 0.0009765625, 17.0]).to(dtype)
+    for scale in (1.0, 37.5):
+        got = ops.quantize_fp8(x.cuda(), scale).cpu()
+        ref = _fake_quant(x, scale)
+        assert got.dtype == torch.float8_e4m3fn and torch.equal(got.view(torch.uint8) & 0x7f, ref.view(torch.uint8) & 0x7f)  # same magnitude bits
+        assert torch.equal(got.float(), ref.float())
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 128, 0), (512, 768, 1536, 0), (256, 512, 1024, 1), (512, 256, 4096, 3), (256, 512, 256, 6)])
+def test_gemm_fp8_vs_fp64_on_quantised_operands(M, N, K, epi):
+    """fp8 x fp8 products are exact in fp32; only the accumulation order differs from an fp64 reference on the same
+    quantised operands -> fp32-accumulation tolerance, not an fp8 one.  Epilogues: bias, GELU, LayerScale-residual, SwiGLU."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + N + K + epi)
+    x, w = torch.randn(M, K, generator=g) * 2, torch.randn(N, K, generator=g) * 0.05
+    bias, gamma = torch.randn(N, generator=g), torch.rand(N, generator=g) + 0.5
+    sx = 448.0 / float(x.abs().max())
+    sw = 448.0 / w.abs().amax(dim=1)                      # per output channel
+    xq, wq = _fake_quant(x, sx), (w * sw[:, None]).clamp(-448, 448).to(torch.float8_e4m3fn)
+    deq = 1.0 / (sx * sw)                                 # per column
+    y = (xq.double() @ wq.double().T) * deq.double() + bias.double()
+    if epi == 3:
+        resid = torch.randn(M, N, generator=g)
+        ref = resid.double() + gamma.double() * y
+        col, b = deq * gamma, bias / deq
+        out = ops.gemm_fp8(xq.cuda(), wq.cuda(), b.cuda(), col.cuda(), out=resid.clone().cuda(), epilogue=3, m_valid=M - 3).cpu()
+        assert torch.equal(out[M - 3:], resid[M - 3:])    # rows past m_valid untouched
+        out, ref = out[:M - 3], ref[:M - 3]
+    else:
+        out = ops.gemm_fp8(xq.cuda(), wq.cuda(), (bias / deq).cuda(), deq.cuda(), epilogue=epi).float().cpu()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(y)
+        elif epi == 6:
+            ref = torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+        else:
+            ref = y
+    tol = 2e-5 if epi == 3 else 6e-3                      # fp32 output / bf16 output rounding
+    assert rel_err(out, ref) < tol
+    # and the quantisation error of the whole op against the unquantised product stays at the fp8 level
+    if epi == 0:
+        exact = x.double() @ w.double().T + bias.double()
+        assert rel_err(out, exact) < 6e-2
+
+
+def test_gemm_fp8_loud_failures():
+    from foundpose_amd import ops
+    from foundpose_amd._lib import FoundPoseNativeError
+    a = torch.zeros(256, 128, dtype=torch.float8_e4m3fn, device="cuda")
+    v = torch.zeros(256, device="cuda")
+    with pytest.raises(FoundPoseNativeError, match="multiple of 128"):
+        ops.gemm_fp8(torch.zeros(256, 64, dtype=torch.float8_e4m3fn, device="cuda"), torch.zeros(256, 64, dtype=torch.float8_e4m3fn, device="cuda"), v, v)
+    with pytest.raises(FoundPoseNativeError, match="not available"):
+        ops.gemm_fp8(a, a, v, v, epilogue=5)
+    with pytest.raises(ValueError):
+        ops.gemm_fp8(a.view(torch.uint8), a, v, v)

@@ -41,6 +41,17 @@ def main():
             for tile in (256, 128):
                 ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
                 print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+    if "fp8" in what:
+        for name, n, k, epi in (("qkv(bias)", 3 * D, D, 0), ("proj(ls)", D, D, 3), ("fc1(gelu)", 4 * D, D, 1), ("fc2(ls)", D, 4 * D, 3)):
+            a = ops.quantize_fp8(torch.randn(M, k, device=dev), 100.0)
+            w = ops.quantize_fp8(torch.randn(n, k, device=dev) * 0.02, 5000.0)
+            bias, col = torch.randn(n, device=dev), torch.rand(n, device=dev) * 1e-5
+            out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
+            ms = timeit(lambda: ops.gemm_fp8(a, w, bias, col, out=out, epilogue=epi, m_valid=B * N))
+            print(f"gemm_fp8 {name:10s} M={M} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+        x = torch.randn(M, 4 * D, device=dev).to(torch.bfloat16)
+        ms = timeit(lambda: ops.quantize_fp8(x, 10.0))
+        print(f"quantize_fp8 bf16 [{M}, {4*D}]: {ms*1e3:8.1f} us  {M*4*D*3/ms/1e6:7.1f} GB/s", flush=True)
     if "attn" in what:
         qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
         ms = timeit(lambda: ops.attention(qkv, B, N, D, H))
