@@ -12,8 +12,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
-FP_F32, FP_BF16 = 0, 1
-ABI_VERSION = 5
+FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
+ABI_VERSION = 6
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -22,7 +22,7 @@ class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in (
         "ln1_w", "ln1_b", "ln2_w", "ln2_b", "ls1", "ls2",
         "qkv_w", "proj_w", "fc1_w", "fc2_w",
-        "qkv_b", "proj_b", "fc1_b", "fc2_b")]
+        "qkv_b", "proj_b", "fc1_b", "fc2_b", "qkv_s", "proj_s", "fc1_s", "fc2_s")] + [("act_scale", f32 * 4)]
 
 
 class VitModel(C.Structure):
@@ -36,7 +36,7 @@ class VitModel(C.Structure):
 
 class VitWorkspace(C.Structure):
     _fields_ = [
-        ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp),
+        ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp), ("a8", vp),
         ("m_pad", i32), ("m_patch_pad", i32),
     ]
 

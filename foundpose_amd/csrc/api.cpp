@@ -272,7 +272,7 @@ int fp_warp_crops(const void* src, int n_src, int src_h, int src_w, int channels
 int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
                    int layer, fp_stream_t stream) {
   FP_REQUIRE(m && ws && images && m->blocks, "fp_vit_forward: null pointer");
-  FP_REQUIRE(layer >= 0 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);
+  FP_REQUIRE(layer >= -1 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);  // -1: token embedding only
   FP_REQUIRE(H % m->patch == 0 && W % m->patch == 0, "fp_vit_forward: image size must be a multiple of the patch size");
   const int D = m->dim, np = (H / m->patch) * (W / m->patch), ntok = 1 + m->registers + np;
   const int Mtok = B * ntok, Mp = B * np;
@@ -280,10 +280,13 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   FP_REQUIRE(ws->m_patch_pad >= Mp && ws->m_patch_pad % 128 == 0, "fp_vit_forward: workspace m_patch_pad too small");
   FP_REQUIRE(ws->patches && ws->x && ws->y && ws->qkv && ws->h, "fp_vit_forward: workspace buffer missing");
   hipStream_t st = ST(stream);
-  const bool bf = m->weight_dtype == FP_DTYPE_BF16;
+  const bool f8 = m->weight_dtype == FP_DTYPE_FP8;  // e4m3 block matrices; activations and patch embed stay bf16
+  const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
+  const int adt = bf ? FP_DTYPE_BF16 : FP_DTYPE_F32;
+  FP_REQUIRE(!f8 || (ws->a8 && ws->m_pad % 256 == 0), "fp_vit_forward: the fp8 mode needs workspace a8 and m_pad %% 256 == 0");
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
-  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, m->weight_dtype, st));
+  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, adt, st));
   TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
   if (bf) {
     GemmBf16Args g;
@@ -303,7 +306,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   }
 
   LayerNormArgs ln;
-  ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = m->weight_dtype;
+  ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = adt;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
   at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.out = ws->y; at.ld_out = D;
@@ -314,6 +317,25 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     // x += ls1 * proj(attn(ln1(x)))
     ln.weight = b.ln1_w; ln.bias = b.ln1_b;
     TRY(layernorm_launch(ln, st));
+    if (f8) {
+      // every GEMM input is quantised to e4m3 with its static scale right before the GEMM that consumes it
+      const long long nD = (long long)ws->m_pad * D, nH = (long long)ws->m_pad * m->hidden;
+      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[0], ws->a8, st));
+      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
+      TRY(attn_launch(at, FP_DTYPE_BF16, st));
+      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[1], ws->a8, st));
+      TRY(fp_gemm_fp8(ws->a8, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+      ln.weight = b.ln2_w; ln.bias = b.ln2_b;
+      TRY(layernorm_launch(ln, st));
+      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[2], ws->a8, st));
+      if (m->ffn_swiglu)
+        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, stream));
+      else
+        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
+      TRY(quantize_fp8_launch(ws->h, FP_DTYPE_BF16, nH, b.act_scale[3], ws->a8, st));
+      TRY(fp_gemm_fp8(ws->a8, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+      continue;
+    }
     if (bf) {
       TRY(fp_gemm_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, nullptr, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
       TRY(attn_launch(at, FP_DTYPE_BF16, st));

@@ -108,7 +108,7 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
 
 // ---------------------------------------------------------------- dtypes of the C ABI
-enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1 };
+enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2 };
 
 // ---------------------------------------------------------------- attn.hip
 struct AttnArgs {

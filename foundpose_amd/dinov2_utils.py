@@ -61,8 +61,13 @@ class DinoFeatureExtractor(torch.nn.Module):
             raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path (shipped configs use 'token')")
         if not 0 <= self.layer < self.arch.depth:
             raise ValueError(f"layer {self.layer} out of range for {self.version}")
-        if precision not in ("bf16", "fp32"):
-            raise ValueError("precision must be 'bf16' or 'fp32'")
+        if precision not in ("bf16", "fp32", "fp8"):
+            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+        if precision == "fp8" and (self.arch.dim % 256 or self.arch.hidden % 256):
+            raise NotImplementedError(f"precision='fp8' needs dim and hidden to be multiples of 256 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
+        # fp8 mode (BASELINE config 5): e4m3 block matrices quantised per output channel, GEMM inputs quantised per tensor
+        # with static scales taken from the first batch seen (or set beforehand with calibrate_fp8 / act_scales=)
+        self.act_scales: Optional[torch.Tensor] = None  # [depth, 4]: inputs of qkv, proj, fc1, fc2
         self.precision = precision
         self._sd = state_dict if state_dict is not None else synthetic.make_vit_state_dict(self.arch, seed)
         self._device: Optional[torch.device] = None
@@ -87,7 +92,7 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def _prepare(self, dev: torch.device) -> None:
         a, sd = self.arch, self._sd
-        wdt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+        wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
         w: Dict[str, torch.Tensor] = {}
 
         def mat(key):
@@ -131,7 +136,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m = _lib.VitModel()
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")
-        m.weight_dtype = _lib.FP_BF16 if self.precision == "bf16" else _lib.FP_F32
+        m.weight_dtype = _lib.FP_F32 if self.precision == "fp32" else _lib.FP_BF16  # "fp8": bf16 until calibrated (_to_fp8)
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
         m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
@@ -156,7 +161,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         key = (B, gh, gw)
         if key not in self._ws:
             a, dev = self.arch, self._device
-            adt = torch.bfloat16 if self.precision == "bf16" else torch.float32
+            adt = torch.float32 if self.precision == "fp32" else torch.bfloat16
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
             m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
             mp_pad = (B * np_ + 255) // 256 * 256
@@ -167,8 +172,11 @@ class DinoFeatureExtractor(torch.nn.Module):
                 torch.zeros(m_pad, 3 * a.dim, dtype=adt, device=dev),
                 torch.zeros(m_pad, a.hidden, dtype=adt, device=dev),
             ]
+            if self.precision == "fp8":
+                bufs.append(torch.zeros(m_pad, max(a.dim, a.hidden), dtype=torch.uint8, device=dev))
             ws = _lib.VitWorkspace()
-            ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs)
+            ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
+            ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
             ws.m_pad, ws.m_patch_pad = m_pad, mp_pad
             self._ws[key] = (ws, bufs)
         return self._ws[key]
@@ -189,6 +197,8 @@ class DinoFeatureExtractor(torch.nn.Module):
         pos_patch, prefix = self._grid_tables(gh, gw)
         self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
         ws, _ = self._workspace(B, gh, gw)
+        if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
+            self.calibrate_fp8(images)
         if self.use_graph:
             fmap, cls = self._forward_graph(images, ws, B, H, W, gh, gw)
         else:
@@ -197,6 +207,71 @@ class DinoFeatureExtractor(torch.nn.Module):
             self._launch(images, ws, B, H, W, gh, gw, fmap, cls)
         self.num_patches = (gh, gw)
         return fmap, cls
+
+    # ---- fp8 mode
+    def calibrate_fp8(self, images: Optional[torch.Tensor] = None, act_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Fixes the static activation scales of the fp8 mode and quantises the block matrices.
+
+        Either pass `act_scales` [depth, 4] (scale = 448 / amax of the inputs of qkv, proj, fc1, fc2 of each block) or a
+        calibration batch `images`: the blocks are then run once in bf16, op by op, and the largest magnitude of each
+        GEMM input is recorded.  -> the scales in use."""
+        from . import ops
+        if self.precision != "fp8" or self._model is None:
+            raise _lib.FoundPoseNativeError("calibrate_fp8 needs precision='fp8' and extractor.to('cuda')")
+        a, dev, w = self.arch, self._device, self._w
+        if act_scales is None:
+            if images is None:
+                raise ValueError("calibrate_fp8 needs a calibration batch or explicit act_scales")
+            images = images.float().contiguous()
+            B, _, H, W = images.shape
+            gh, gw = H // self.patch_size, W // self.patch_size
+            pos_patch, prefix = self._grid_tables(gh, gw)
+            self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
+            self._model.weight_dtype = _lib.FP_BF16
+            ws, bufs = self._workspace(B, gh, gw)
+            call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, -1, stream())  # embedding only
+            x, ntok = bufs[1], 1 + a.registers + gh * gw
+            mv = B * ntok
+            amax = torch.zeros(a.depth, 4)
+            for i in range(self.layer + 1):
+                p = f"blocks.{i}."
+                fc1_w, fc1_b, fc2 = (w[p + "mlp.fc1.weight"], w[p + "mlp.fc1.bias"], "mlp.fc2") if a.ffn == "mlp" else (w[p + "w12i"], w[p + "b12i"], "mlp.w3")
+                y = ops.layernorm(x, w[p + "norm1.weight"], w[p + "norm1.bias"], torch.bfloat16)
+                qkv = ops.gemm_bf16(y, w[p + "attn.qkv.weight"], w[p + "attn.qkv.bias"], epilogue=0, m_valid=mv)
+                o = ops.attention(qkv, B, ntok, a.dim, a.heads)
+                ops.gemm_bf16(o, w[p + "attn.proj.weight"], w[p + "attn.proj.bias"], gamma=w[p + "ls1.gamma"], out=x, epilogue=3, m_valid=mv)
+                y2 = ops.layernorm(x, w[p + "norm2.weight"], w[p + "norm2.bias"], torch.bfloat16)
+                h = ops.gemm_bf16(y2, fc1_w, fc1_b, epilogue=1 if a.ffn == "mlp" else 6, m_valid=mv)
+                ops.gemm_bf16(h, w[p + fc2 + ".weight"], w[p + fc2 + ".bias"], gamma=w[p + "ls2.gamma"], out=x, epilogue=3, m_valid=mv)
+                amax[i] = torch.stack([t[:mv].float().abs().max() for t in (y, o, y2, h)]).cpu()
+            amax[self.layer + 1:] = 1.0
+            act_scales = 448.0 / amax.clamp_min(1e-12)
+        self.act_scales = act_scales.float().cpu().clone()
+        self._to_fp8()
+        return self.act_scales
+
+    def _to_fp8(self) -> None:
+        """Per-output-channel e4m3 block matrices, column scales and pre-divided biases for fp_vit_forward's fp8 path."""
+        from . import ops
+        a, w = self.arch, self._w
+        for i in range(a.depth):
+            p, b = f"blocks.{i}.", self._blocks[i]
+            names = [("attn.qkv.weight", "attn.qkv.bias", None), ("attn.proj.weight", "attn.proj.bias", "ls1.gamma"),
+                     ("mlp.fc1.weight", "mlp.fc1.bias", None) if a.ffn == "mlp" else ("w12i", "b12i", None),
+                     ("mlp.fc2.weight", "mlp.fc2.bias", "ls2.gamma") if a.ffn == "mlp" else ("mlp.w3.weight", "mlp.w3.bias", "ls2.gamma")]
+            for j, ((wk, bk, gk), field) in enumerate(zip(names, ("qkv", "proj", "fc1", "fc2"))):
+                wt = w[p + wk].float()
+                sw = 448.0 / wt.abs().amax(dim=1).clamp_min(1e-12)
+                deq = 1.0 / (float(self.act_scales[i, j]) * sw)
+                w[p + wk + ".f8"] = ops.quantize_fp8((wt * sw[:, None]).contiguous(), 1.0)
+                w[p + wk + ".b8"] = (w[p + bk] / deq).contiguous()
+                w[p + wk + ".s8"] = (deq * w[p + gk] if gk else deq).contiguous()
+                setattr(b, field + "_w", ptr(w[p + wk + ".f8"]))
+                setattr(b, field + "_b", ptr(w[p + wk + ".b8"]))
+                setattr(b, field + "_s", ptr(w[p + wk + ".s8"]))
+                b.act_scale[j] = float(self.act_scales[i, j])
+        self._model.weight_dtype = _lib.FP_FP8
+        self._graphs.clear()
 
     def _launch(self, images, ws, B, H, W, gh, gw, fmap, cls) -> None:
         """The ~125 kernel launches of one forward (C++ launch sequence) on the current stream."""

@@ -23,9 +23,9 @@ extern "C" {
 
 typedef void* fp_stream_t; /* hipStream_t */
 
-enum { FP_F32 = 0, FP_BF16 = 1 }; /* element types of activation / weight buffers */
+enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 5
+#define FP_ABI_VERSION 6
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -111,13 +111,20 @@ typedef struct {
   const float *ln1_w, *ln1_b, *ln2_w, *ln2_b, *ls1, *ls2; /* fp32 [D] */
   const void *qkv_w, *proj_w, *fc1_w, *fc2_w;             /* [N,K] row-major (torch Linear), bf16 or f32 */
   const float *qkv_b, *proj_b, *fc1_b, *fc2_b;            /* fp32 */
+  /* weight_dtype == FP_FP8 only: the four matrices hold OCP e4m3 bytes quantised per output channel, *_s [N] are the
+   * dequantisation scales of the output columns, 1 / (act_scale x weight scale of the channel) -- proj_s and fc2_s
+   * already multiplied by ls1 / ls2 --, the four biases are divided by (1 / (act_scale x weight scale)), and
+   * act_scale[0..3] quantise the inputs of qkv, proj, fc1, fc2 (static per-tensor scales from a calibration batch) */
+  const float *qkv_s, *proj_s, *fc1_s, *fc2_s;
+  float act_scale[4];
 } fp_vit_block;
 
 typedef struct {
   int dim, depth, heads, hidden, registers, patch;
   int ffn_swiglu;          /* 1 for ViT-g: fc1_w/fc1_b hold mlp.w12 with rows INTERLEAVED (x1_j, x2_j) [2*hidden, D],
                               fc2_w/fc2_b hold mlp.w3 [D, hidden]; h = silu(x1) * x2 is fused into the first GEMM */
-  int weight_dtype;        /* FP_BF16 | FP_F32: dtype of the matrices and of the activation buffers */
+  int weight_dtype;        /* FP_BF16 | FP_F32: dtype of the matrices and of the activation buffers; FP_FP8: e4m3 block
+                              matrices (see fp_vit_block), bf16 activation buffers and patch-embed weight */
   const void* patch_w;     /* [D, patch_k_pad]: conv weight flattened (c,py,px), zero padded */
   int patch_k_pad;         /* multiple of 64 */
   const float* patch_b;    /* [D] */
@@ -133,12 +140,15 @@ typedef struct {
   void* y;       /* [m_pad, D] activation dtype (LN output / attention output) */
   void* qkv;     /* [m_pad, 3D] */
   void* h;       /* [m_pad, hidden] */
+  void* a8;      /* FP_FP8 only: [m_pad, max(D, hidden)] bytes, the quantised input of the GEMM about to run; m_pad must
+                    then be a multiple of 256 */
   int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
   int m_patch_pad; /* multiple of 128, >= B*Np */
 } fp_vit_workspace;
 
 /* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token
- * (what the reference's forward hook captures, dinov2_utils.py:160-211), blocks after `layer` are not run. */
+ * (what the reference's forward hook captures, dinov2_utils.py:160-211), blocks after `layer` are not run
+ * (layer = -1: the token embedding only -- used by the fp8 calibration pass). */
 int fp_vit_forward(const fp_vit_model* model, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
                    int layer, fp_stream_t stream);
 

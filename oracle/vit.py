@@ -33,6 +33,19 @@ def _q(x: torch.Tensor, quant: Optional[str]) -> torch.Tensor:
     return x
 
 
+def _fq_act(x: torch.Tensor, scale: float) -> torch.Tensor:
+    """fp8 mode: a GEMM input as the device sees it -- bf16 activation, times its static scale, clamped to +-448,
+    rounded to OCP e4m3 -- and back to fp32 (de-scaled)."""
+    return (x * scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32) / scale
+
+
+def _fq_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp8 mode: a block matrix quantised per output channel (scale = 448 / row amax) from its bf16 values."""
+    w = _q(w, "bf16")
+    sw = 448.0 / w.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
+    return (w * sw).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32) / sw
+
+
 def normalize_images(images: torch.Tensor) -> torch.Tensor:
     mean = torch.tensor(IMNET_MEAN, dtype=images.dtype).view(1, 3, 1, 1)
     std = torch.tensor(IMNET_STD, dtype=images.dtype).view(1, 3, 1, 1)
@@ -75,7 +88,11 @@ def embed_tokens(sd: Dict[str, torch.Tensor], arch: VitArch, x: torch.Tensor, qu
     return t
 
 
-def block_forward(sd, arch: VitArch, i: int, x: torch.Tensor, quant=None) -> torch.Tensor:
+def block_forward(sd, arch: VitArch, i: int, x: torch.Tensor, quant=None, fp8_act=None) -> torch.Tensor:
+    """fp8_act: the four static activation scales of this block (inputs of qkv, proj, fc1, fc2) -> "oracle C", the fp8
+    mode: bf16 everywhere like quant="bf16", plus e4m3 fake quantisation of every block-GEMM input and weight."""
+    if fp8_act is not None:
+        return _block_forward_fp8(sd, arch, i, x, [float(v) for v in fp8_act])
     p = f"blocks.{i}."
     B, N, D = x.shape
     h, hd = arch.heads, arch.head_dim
@@ -109,28 +126,52 @@ def block_forward(sd, arch: VitArch, i: int, x: torch.Tensor, quant=None) -> tor
     return x + sd[p + "ls2.gamma"] * o
 
 
+def _block_forward_fp8(sd, arch: VitArch, i: int, x: torch.Tensor, s) -> torch.Tensor:
+    p, q = f"blocks.{i}.", "bf16"
+    B, N, D = x.shape
+    h, hd = arch.heads, arch.head_dim
+    y = _q(F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6), q)
+    qkv = _q(F.linear(_fq_act(y, s[0]), _fq_weight(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"]), q)
+    qkv = qkv.reshape(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)
+    qq, k, v = qkv[0], qkv[1], qkv[2]
+    sc = (qq @ k.transpose(-2, -1)) * (hd ** -0.5)
+    e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+    o = _q(((_q(e, q) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, D), q)
+    x = x + sd[p + "ls1.gamma"] * F.linear(_fq_act(o, s[1]), _fq_weight(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
+    y = _q(F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6), q)
+    if arch.ffn == "mlp":
+        hdn = _q(F.gelu(F.linear(_fq_act(y, s[2]), _fq_weight(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])), q)
+        o = F.linear(_fq_act(hdn, s[3]), _fq_weight(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
+    else:
+        x12 = F.linear(_fq_act(y, s[2]), _fq_weight(sd[p + "mlp.w12.weight"]), sd[p + "mlp.w12.bias"])
+        x1, x2 = x12.chunk(2, dim=-1)
+        hdn = _q(F.silu(x1) * x2, q)
+        o = F.linear(_fq_act(hdn, s[3]), _fq_weight(sd[p + "mlp.w3.weight"]), sd[p + "mlp.w3.bias"])
+    return x + sd[p + "ls2.gamma"] * o
+
+
 @torch.no_grad()
-def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quant=None, all_blocks=False) -> torch.Tensor:
+def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quant=None, all_blocks=False, fp8_act=None) -> torch.Tensor:
     """Output of blocks[layer] for [0,1] images (what the reference's forward hook captures).
 
     `all_blocks=True` keeps running to the last block like the reference does
     (dinov2_utils.py:257 runs the entire model) -- only used by the cpu_baseline timing.
     """
-    x = embed_tokens(sd, arch, normalize_images(images), quant)
+    x = embed_tokens(sd, arch, normalize_images(images), "bf16" if fp8_act is not None else quant)
     out = None
     last = arch.depth - 1 if all_blocks else layer
     for i in range(last + 1):
-        x = block_forward(sd, arch, i, x, quant)
+        x = block_forward(sd, arch, i, x, quant, None if fp8_act is None else fp8_act[i])
         if i == layer:
             out = x
     return out
 
 
 @torch.no_grad()
-def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False):
+def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False, fp8_act=None):
     """-> {"cls_tokens": [B,D], "feature_maps": [B,D,Hp,Wp]} exactly like the reference wrapper."""
     B, _, H, W = images.shape
-    hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks)
+    hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks, fp8_act)
     cls, patch = hs[:, :1], hs[:, 1 + arch.registers:]
     if apply_norm:
         tok = F.layer_norm(torch.cat([cls, patch], 1), (arch.dim,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)

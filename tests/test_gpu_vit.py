@@ -357,3 +357,40 @@ def test_gemm_fp8_loud_failures():
         ops.gemm_fp8(a, a, v, v, epilogue=5)
     with pytest.raises(ValueError):
         ops.gemm_fp8(a.view(torch.uint8), a, v, v)
+
+
+@pytest.mark.parametrize("ffn", ["mlp", "swiglu"])
+def test_extractor_fp8_mode_vs_oracle_c(ffn):
+    """precision="fp8": e4m3 block GEMMs with static activation scales calibrated on the first batch.  Checked against
+    "oracle C" (oracle/vit.py fp8_act=: bf16 activations + e4m3 fake quantisation at the same points with the same
+    scales) at bf16-level tolerance, and against the fp32 oracle at the fp8 noise level."""
+    from foundpose_amd.vit_config import VitArch
+    arch = VitArch(f"f8test-{ffn}-reg", dim=256, depth=3, heads=4, ffn=ffn, hidden=512 if ffn == "swiglu" else 1024, registers=4,
+                   pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
+    name = f"dinov2_version={arch.name}_stride=14_facet=token_layer=2_logbin=0_norm=1"
+    from foundpose_amd import feature_util
+    mk = lambda: feature_util.make_feature_extractor(name, seed=77, precision="fp8", arch=arch).to("cuda")
+    ex = mk()
+    imgs = synthetic.make_crops(3, 56, seed=5)
+    out = ex(imgs.cuda())
+    scales = ex.act_scales
+    assert scales.shape == (3, 4) and bool((scales > 0).all())
+    fm = out["feature_maps"].cpu()
+    sd = synthetic.make_vit_state_dict(arch, 77)
+    ref_c = ov.extractor_forward(sd, arch, imgs, 2, True, fp8_act=scales)["feature_maps"]
+    ref_32 = ov.extractor_forward(sd, arch, imgs, 2, True)["feature_maps"]
+    scale = float(ref_32.abs().max())
+    assert float((fm - ref_c).abs().max()) < 4e-2 * scale       # same quantisation points: bf16-level agreement
+    assert float((fm - ref_32).abs().max()) < 0.25 * scale      # fp8 noise against the exact model
+    assert float((fm - ref_32).pow(2).mean().sqrt()) < 3e-2 * scale
+    # explicit scales reproduce the calibrated run bit for bit; a second batch reuses the static scales
+    ex2 = mk()
+    ex2.calibrate_fp8(act_scales=scales)
+    assert torch.equal(ex2(imgs.cuda())["feature_maps"].cpu(), fm)
+    assert torch.equal(ex.act_scales, scales) and torch.isfinite(ex(synthetic.make_crops(2, 56, seed=6).cuda())["feature_maps"]).all()
+
+
+def test_fp8_mode_loud_failures():
+    from foundpose_amd import feature_util
+    with pytest.raises(NotImplementedError, match="multiples of 256"):
+        feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", precision="fp8")
