@@ -57,7 +57,7 @@ _PROTOS = {
     "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "fp_gemm_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
-    "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, vp],
     "fp_quantize_fp8": [vp, i32, i64, f32, vp, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],

@@ -212,12 +212,14 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
 }
 
 int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
-                const float* col_scale, void* out, int ldo, int epilogue, fp_stream_t stream) {
+                const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_fp8: null pointer");
+  FP_REQUIRE(out_scale >= 0.f, "fp_gemm_fp8: out_scale must be >= 0");
   GemmBf16Args a;
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = col_scale; a.out = out; a.ldo = ldo;
+  a.out_scale = out_scale;
   return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
 }
 
@@ -246,6 +248,7 @@ int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int 
                  int dim, int heads, int dtype, fp_stream_t stream) {
   FP_REQUIRE(qkv && out, "fp_attention: null pointer");
   AttnArgs a;
+  a.out_fp8_scale = 0.f;
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
   a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads;
   return attn_launch(a, dtype, ST(stream));
@@ -306,9 +309,11 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   }
 
   LayerNormArgs ln;
+  ln.out_scale = 0.f;
   ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = adt;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
+  at.out_fp8_scale = 0.f;
   at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.out = ws->y; at.ld_out = D;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
 
@@ -316,26 +321,28 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     const fp_vit_block& b = m->blocks[i];
     // x += ls1 * proj(attn(ln1(x)))
     ln.weight = b.ln1_w; ln.bias = b.ln1_b;
-    TRY(layernorm_launch(ln, st));
     if (f8) {
-      // every GEMM input is quantised to e4m3 with its static scale right before the GEMM that consumes it
-      const long long nD = (long long)ws->m_pad * D, nH = (long long)ws->m_pad * m->hidden;
-      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[0], ws->a8, st));
-      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
-      TRY(attn_launch(at, FP_DTYPE_BF16, st));
-      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[1], ws->a8, st));
-      TRY(fp_gemm_fp8(ws->a8, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
-      ln.weight = b.ln2_w; ln.bias = b.ln2_b;
-      TRY(layernorm_launch(ln, st));
-      TRY(quantize_fp8_launch(ws->y, FP_DTYPE_BF16, nD, b.act_scale[2], ws->a8, st));
+      // fp8 block: every GEMM input is produced as e4m3 bytes by the kernel in front of it -- LayerNorm, attention and
+      // the GELU / SwiGLU epilogue quantise with the block's static scales on their way out (ws->a8; the hidden
+      // activations reuse ws->h as a byte buffer) -- so the four GEMMs run on the fp8 MFMA with no extra pass.
+      LayerNormArgs l8 = ln;
+      l8.out = ws->a8; l8.ld_out = D; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
+      TRY(layernorm_launch(l8, st));
+      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, 0.f, stream));
+      AttnArgs a8 = at;
+      a8.out = ws->a8; a8.ld_out = D; a8.out_fp8_scale = b.act_scale[1];
+      TRY(attn_launch(a8, FP_DTYPE_BF16, st));
+      TRY(fp_gemm_fp8(ws->a8, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
+      l8.weight = b.ln2_w; l8.bias = b.ln2_b; l8.out_scale = b.act_scale[2];
+      TRY(layernorm_launch(l8, st));
       if (m->ffn_swiglu)
-        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, stream));
+        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], stream));
       else
-        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
-      TRY(quantize_fp8_launch(ws->h, FP_DTYPE_BF16, nH, b.act_scale[3], ws->a8, st));
-      TRY(fp_gemm_fp8(ws->a8, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_GELU_BF16, b.act_scale[3], stream));
+      TRY(fp_gemm_fp8(ws->h, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
       continue;
     }
+    TRY(layernorm_launch(ln, st));
     if (bf) {
       TRY(fp_gemm_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, nullptr, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
       TRY(attn_launch(at, FP_DTYPE_BF16, st));
@@ -372,6 +379,7 @@ int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, in
   hipStream_t st = ST(stream);
   if (apply_norm) {
     LayerNormArgs ln;
+    ln.out_scale = 0.f;
     ln.x = ws->x; ln.ld_x = D; ln.weight = m->norm_w; ln.bias = m->norm_b; ln.eps = 1e-6f;
     ln.out_dtype = FP_DTYPE_F32; ln.dim = D; ln.in_rows_per_img = ntok; ln.ld_out = D;
     ln.out = fmap; ln.out_rows = B * n_patches; ln.out_rows_per_img = n_patches; ln.in_skip = 1 + m->registers;

@@ -404,7 +404,16 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
       const int q = q0 + qb * 32 + l31;
       const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
       const float inv = 1.f / l_tot;
-      if (q < N) {
+      if (q < N && a.out_fp8_scale > 0.f) {  // fp8 mode: the proj GEMM's input, quantised here (ld_out in bytes)
+        unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
+        const float sc = inv * a.out_fp8_scale;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<unsigned*>(o + dt * 32 + 8 * g + 4 * kh) =
+                pack_fp8x4(oacc[qb][dt][4 * g + 0] * sc, oacc[qb][dt][4 * g + 1] * sc, oacc[qb][dt][4 * g + 2] * sc, oacc[qb][dt][4 * g + 3] * sc);
+      } else if (q < N) {
         __bf16* o = reinterpret_cast<__bf16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -479,6 +488,7 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
     const char* w64_env = getenv("FP_ATTN_W64");  // read per call: tests compare the two kernels in one process
     const int w64 = w64_env ? atoi(w64_env) : 1;
+    FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
       hipLaunchKernelGGL(attn_bf16_w64_kernel, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(256), 0, st, a);
     } else {

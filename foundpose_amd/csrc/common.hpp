@@ -42,6 +42,13 @@ void fp_set_error(const char* fmt, ...);
 // ---- bf16 <-> f32
 FP_DEVICE float bf16_to_f32(__bf16 v) { return (float)v; }
 
+// four floats -> four OCP e4m3 bytes (round to nearest even, saturating at +-448)
+FP_DEVICE float clamp448(float v) { return fminf(fmaxf(v, -448.f), 448.f); }
+FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0), clamp448(v1), 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v2), clamp448(v3), w, true);
+}
+
 FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
   f32x2 p = {lo, hi};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)

@@ -83,8 +83,11 @@ FP_DEVICE f32x2 gelu_pk(f32x2 x) {
 typedef __attribute__((ext_vector_type(8))) int i32x8;
 typedef __attribute__((ext_vector_type(4))) int i32x4;
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false>
+// F8OUT (GELU / SwiGLU epilogues of the fp8 kernels): the result is itself the input of the next fp8 GEMM and leaves as
+// e4m3(clamp(value * a.out_scale, +-448)) bytes, [M, N] (or [M, N/2]) with ldo in bytes -- no separate quantisation pass.
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
+  static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   // DMA issue is asymmetric on the 8-wave tile: only the waves of row wm == 0 fetch (every SIMD hosts one wave of each
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     static_assert(!F8 || USE_SLAB, "the fp8 kernels exist for the slab epilogues only");
     if constexpr (USE_SLAB) {
     constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
-    constexpr int ESZ = OUT_F32 ? 4 : 2;
+    constexpr int ESZ = OUT_F32 ? 4 : (F8OUT ? 1 : 2);
     constexpr int OUT_COLS = EPI == GEMM_EPI_SWIGLU_BF16 ? BN / 2 : BN;  // SwiGLU folds column pairs
     constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = OUT_COLS * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
     constexpr int CHUNKS_PER_ROW = OUT_COLS * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
@@ -297,8 +300,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           if constexpr (EPI == GEMM_EPI_SWIGLU_BF16) {
             const float h0 = v0 / (1.f + __builtin_amdgcn_exp2f(-v0 * 1.44269504088896340736f)) * v1;  // silu(x1) * x2
             const float h1 = v2 / (1.f + __builtin_amdgcn_exp2f(-v2 * 1.44269504088896340736f)) * v3;
-            *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
+            if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f);
+            else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
           } else if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
+          else if constexpr (F8OUT) *reinterpret_cast<unsigned*>(srow + col) = pack_fp8x4(v0 * a.out_scale, v1 * a.out_scale, v2 * a.out_scale, v3 * a.out_scale);
           else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       __syncthreads();
@@ -309,7 +314,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
         if (!ok[it]) continue;
         const char* sp = slab + r * SLAB_STRIDE + c * 16;
-        if constexpr (!OUT_F32) {
+        if constexpr (F8OUT) {
+          const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 16;
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
+        } else if constexpr (!OUT_F32) {
           const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 8;
           *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
         } else {
@@ -397,7 +405,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   unsigned grid = (a.M / BM) * (a.N / BN);
@@ -415,11 +423,11 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static bool attr = false;
   if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     attr = true;
   }
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
@@ -446,6 +454,13 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   FP_REQUIRE(a.bias != nullptr && a.gamma != nullptr, "gemm_fp8: bias and the per-column scale are required");
   FP_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.ldo % 4 == 0, "gemm_fp8: leading dims must keep 16-byte alignment");
   a.K /= 2; a.lda /= 2; a.ldw /= 2;  // an fp8 row addressed as a bf16 row of half the length (see the kernel header)
+  if (a.out_scale > 0.f) {  // fp8 output
+    FP_REQUIRE(a.ldo % 16 == 0, "gemm_fp8: an fp8 output needs ldo %% 16 == 0");
+    if (epi == GEMM_EPI_GELU_BF16) return launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true, true>(a, st);
+    if (epi == GEMM_EPI_SWIGLU_BF16) return launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true, true>(a, st);
+    fp_set_error("gemm_fp8: fp8 output exists for the GELU and SwiGLU epilogues only (epilogue %d)", epi);
+    return FP_ERR_UNSUPPORTED;
+  }
   switch (epi) {
     case GEMM_EPI_BIAS_BF16: return launch_cfg<GEMM_EPI_BIAS_BF16, 256, 256, 2, 4, true>(a, st);
     case GEMM_EPI_GELU_BF16: return launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true>(a, st);

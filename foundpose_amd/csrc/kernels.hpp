@@ -101,6 +101,7 @@ struct GemmBf16Args {
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
   int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
   unsigned rast_r, rast_gn;
+  float out_scale;            // fp8 kernels: > 0 -> the GELU / SwiGLU result leaves as e4m3(value * out_scale) bytes
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
 };
 
@@ -115,6 +116,7 @@ struct AttnArgs {
   const void* qkv; int ld_qkv;   // [B*N, 3D] (bf16 or f32): q | k | v column blocks, head-major inside
   void* out; int ld_out;         // [B*N, D]
   int batch, n_tok, dim, heads;
+  float out_fp8_scale;           // bf16 kernel: > 0 -> the output leaves as e4m3(o * scale) bytes (ld_out in bytes)
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 
@@ -122,7 +124,8 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 struct LayerNormArgs {
   const float* x; int ld_x;      // fp32 residual stream
   const float* weight; const float* bias; float eps;
-  void* out; int ld_out; int out_dtype;
+  void* out; int ld_out; int out_dtype;   // FP_DTYPE_FP8: e4m3(y * out_scale) bytes, ld_out in bytes (dim % 256 == 0)
+  float out_scale;
   int dim;
   int out_rows;                  // rows to produce
   int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi

@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
         vec_t y;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) y[e] = (v[i][e] - mean) * rstd * w[e] + b[e];
-        if (a.out_dtype == FP_DTYPE_BF16) {
+        if (a.out_dtype == FP_DTYPE_FP8) {
+          if constexpr (VEC == 4)
+            *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.out) + (size_t)row * a.ld_out + c) =
+                pack_fp8x4(y[0] * a.out_scale, y[1] * a.out_scale, y[2] * a.out_scale, y[3] * a.out_scale);
+        } else if (a.out_dtype == FP_DTYPE_BF16) {
           __bf16* o = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c;
           if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
           else *reinterpret_cast<unsigned*>(o) = pack_bf16x2(y[0], y[1]);
@@ -132,6 +136,8 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   if (a.out_rows == 0) return FP_OK;
   const int wgs = cdiv(a.out_rows, 4);
   const int grid = wgs < 2048 ? wgs : 2048;  // 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
+  FP_REQUIRE(a.out_dtype != FP_DTYPE_FP8 || (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0 && a.out_scale > 0.f),
+             "layernorm: fp8 output needs dim %% 256 == 0 and a positive scale");
   if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0)
     hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, st, a);
   else

@@ -140,7 +140,7 @@ def quantize_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
 
 
 def gemm_fp8(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, col_scale: torch.Tensor, out=None, epilogue: int = 0,
-             m_valid: Optional[int] = None) -> torch.Tensor:
+             m_valid: Optional[int] = None, out_scale: float = 0.0) -> torch.Tensor:
     """fp8 x fp8 -> fp32-accumulated GEMM: out = epilogue((a @ w.T + bias) * col_scale), a [M, K] and w [N, K] in
     torch.float8_e4m3fn; bias is the true bias divided by col_scale (see include/foundpose_amd.h)."""
     require_cuda(a, w, bias, col_scale)
@@ -149,9 +149,10 @@ def gemm_fp8(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, col_scale: to
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=torch.float32 if epilogue == 3 else torch.bfloat16, device=a.device)
+        odt = torch.float8_e4m3fn if out_scale > 0 else (torch.float32 if epilogue == 3 else torch.bfloat16)
+        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=odt, device=a.device)  # out_scale > 0: e4m3(result * out_scale)
     call("fp_gemm_fp8", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid,
-         ptr(bias), ptr(col_scale), ptr(out), out.stride(0), epilogue, stream())
+         ptr(bias), ptr(col_scale), ptr(out), out.stride(0), epilogue, float(out_scale), stream())
     return out
 
 

@@ -173,9 +173,11 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
  * and accumulation in fp32 on the block-scaled MFMA with unit scales (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16
  * rate).  out = epilogue((acc + bias[n]) * col_scale[n]): col_scale = 1 / (activation scale x weight scale of channel
  * n) (x LayerScale gamma for epilogue 3), bias pre-divided by col_scale.  Epilogues 0, 1, 3, 6 as fp_gemm_bf16;
- * M, N multiples of 256, K a multiple of 128. */
+ * M, N multiples of 256, K a multiple of 128.
+ * out_scale > 0 (epilogues 1 and 6 only): the result feeds the next fp8 GEMM and is written as e4m3(value * out_scale)
+ * bytes, ldo in bytes; out_scale = 0: bf16 / fp32 output as fp_gemm_bf16. */
 int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
-                const float* col_scale, void* out, int ldo, int epilogue, fp_stream_t stream);
+                const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream);
 /* out[i] = e4m3(clamp(in[i] * scale, +-448)), round to nearest even; in fp32 or bf16 (in_dtype FP_F32 / FP_BF16) */
 int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream);
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */

@@ -34,8 +34,8 @@ def _q(x: torch.Tensor, quant: Optional[str]) -> torch.Tensor:
 
 
 def _fq_act(x: torch.Tensor, scale: float) -> torch.Tensor:
-    """fp8 mode: a GEMM input as the device sees it -- bf16 activation, times its static scale, clamped to +-448,
-    rounded to OCP e4m3 -- and back to fp32 (de-scaled)."""
+    """fp8 mode: a GEMM input as the device sees it -- times its static scale, clamped to +-448, rounded to OCP e4m3 --
+    and back to fp32 (de-scaled)."""
     return (x * scale).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32) / scale
 
 
@@ -127,26 +127,28 @@ def block_forward(sd, arch: VitArch, i: int, x: torch.Tensor, quant=None, fp8_ac
 
 
 def _block_forward_fp8(sd, arch: VitArch, i: int, x: torch.Tensor, s) -> torch.Tensor:
+    """The device's fp8 block: the four GEMM inputs are quantised to e4m3 straight from the fp32 values the producing
+    kernel holds (LayerNorm output, attention output o / l, GELU or SwiGLU output); qkv and the residual stream are
+    bf16 / fp32 as in the bf16 mode."""
     p, q = f"blocks.{i}.", "bf16"
     B, N, D = x.shape
     h, hd = arch.heads, arch.head_dim
-    y = _q(F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6), q)
+    y = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
     qkv = _q(F.linear(_fq_act(y, s[0]), _fq_weight(sd[p + "attn.qkv.weight"]), sd[p + "attn.qkv.bias"]), q)
     qkv = qkv.reshape(B, N, 3, h, hd).permute(2, 0, 3, 1, 4)
     qq, k, v = qkv[0], qkv[1], qkv[2]
     sc = (qq @ k.transpose(-2, -1)) * (hd ** -0.5)
     e = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
-    o = _q(((_q(e, q) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, D), q)
+    o = ((_q(e, q) @ v) / e.sum(dim=-1, keepdim=True)).transpose(1, 2).reshape(B, N, D)
     x = x + sd[p + "ls1.gamma"] * F.linear(_fq_act(o, s[1]), _fq_weight(sd[p + "attn.proj.weight"]), sd[p + "attn.proj.bias"])
-    y = _q(F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6), q)
+    y = F.layer_norm(x, (D,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], eps=1e-6)
     if arch.ffn == "mlp":
-        hdn = _q(F.gelu(F.linear(_fq_act(y, s[2]), _fq_weight(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"])), q)
+        hdn = F.gelu(F.linear(_fq_act(y, s[2]), _fq_weight(sd[p + "mlp.fc1.weight"]), sd[p + "mlp.fc1.bias"]))
         o = F.linear(_fq_act(hdn, s[3]), _fq_weight(sd[p + "mlp.fc2.weight"]), sd[p + "mlp.fc2.bias"])
     else:
         x12 = F.linear(_fq_act(y, s[2]), _fq_weight(sd[p + "mlp.w12.weight"]), sd[p + "mlp.w12.bias"])
         x1, x2 = x12.chunk(2, dim=-1)
-        hdn = _q(F.silu(x1) * x2, q)
-        o = F.linear(_fq_act(hdn, s[3]), _fq_weight(sd[p + "mlp.w3.weight"]), sd[p + "mlp.w3.bias"])
+        o = F.linear(_fq_act(F.silu(x1) * x2, s[3]), _fq_weight(sd[p + "mlp.w3.weight"]), sd[p + "mlp.w3.bias"])
     return x + sd[p + "ls2.gamma"] * o
 
 

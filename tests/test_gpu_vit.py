@@ -346,6 +346,27 @@ def test_gemm_fp8_vs_fp64_on_quantised_operands(M, N, K, epi):
         assert rel_err(out, exact) < 6e-2
 
 
+@pytest.mark.parametrize("epi", [1, 6])
+def test_gemm_fp8_quantised_output(epi):
+    """out_scale > 0: the GELU / SwiGLU result leaves as e4m3 bytes == quantising the bf16-free fp32 result."""
+    from foundpose_amd import ops
+    M, N, K = 512, 512, 256
+    g = torch.Generator().manual_seed(epi)
+    xq, wq = _fake_quant(torch.randn(M, K, generator=g), 60.0), _fake_quant(torch.randn(N, K, generator=g) * 0.05, 2000.0)
+    bias, deq = torch.randn(N, generator=g) * 0.1, torch.full((N,), 1.0 / (60.0 * 2000.0))
+    y = (xq.double() @ wq.double().T) * deq.double() + bias.double()
+    ref = torch.nn.functional.gelu(y) if epi == 1 else torch.nn.functional.silu(y[:, 0::2]) * y[:, 1::2]
+    s_out = 448.0 / float(ref.abs().max())
+    out = ops.gemm_fp8(xq.cuda(), wq.cuda(), (bias / deq).cuda(), deq.cuda(), epilogue=epi, out_scale=s_out, m_valid=M - 2).cpu()
+    assert out.dtype == torch.float8_e4m3fn and out.shape == ref.shape
+    assert bool((out[M - 2:].float() == 0).all())         # rows past m_valid untouched (zero-initialised)
+    got, want = out[:M - 2].float() / s_out, ref[:M - 2]
+    # one e4m3 rounding of the value (2^-4 relative, 2^-10 / s_out below the normal range) + the epilogue's own
+    # approximation error (polynomial GELU / exp2-based sigmoid: ~1e-3 absolute, as in the bf16 epilogue tests)
+    assert bool(((got - want).abs() <= want.abs() * 2 ** -4 + 2 ** -9 / s_out + 2e-3).all())
+    assert float((got - want).abs().mean()) < 0.03 * float(want.abs().mean())
+
+
 def test_gemm_fp8_loud_failures():
     from foundpose_amd import ops
     from foundpose_amd._lib import FoundPoseNativeError
@@ -355,6 +376,8 @@ def test_gemm_fp8_loud_failures():
         ops.gemm_fp8(torch.zeros(256, 64, dtype=torch.float8_e4m3fn, device="cuda"), torch.zeros(256, 64, dtype=torch.float8_e4m3fn, device="cuda"), v, v)
     with pytest.raises(FoundPoseNativeError, match="not available"):
         ops.gemm_fp8(a, a, v, v, epilogue=5)
+    with pytest.raises(FoundPoseNativeError, match="GELU and SwiGLU"):
+        ops.gemm_fp8(a, a, v, v, epilogue=0, out_scale=1.0)
     with pytest.raises(ValueError):
         ops.gemm_fp8(a.view(torch.uint8), a, v, v)
 
