@@ -19,6 +19,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md chip table)
+PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled MFMA), --precision fp8 only (BASELINE config 5; never the headline run)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 
 
@@ -150,12 +151,20 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel: the fc1 GEMM (+bias+GELU) of a ViT block, M = B*tokens
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
-        M = (B * n_tok + 127) // 128 * 128
+        M = (B * n_tok + 255) // 256 * 256
         a = torch.randn(M, arch.dim, device=dev).to(torch.bfloat16)
         w = (torch.randn(arch.hidden, arch.dim, device=dev) * 0.02).to(torch.bfloat16)
         bias = torch.zeros(arch.hidden, device=dev)
         h = torch.empty(M, arch.hidden, dtype=torch.bfloat16, device=dev)
-        ms = time_kernel(lambda: ops.gemm_bf16(a, w, bias, out=h, epilogue=1, m_valid=B * n_tok))
+        peak_mfma, gemm_name = PEAK_BF16_TFLOPS, "gemm_bf16_kernel<GELU> (fc1 of one ViT block)"
+        if args.precision == "fp8":
+            peak_mfma, gemm_name = PEAK_FP8_TFLOPS, "gemm_bf16_kernel<GELU, fp8 operands, fp8 output> (fc1 of one ViT block)"
+            a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
+            col = torch.full((arch.hidden,), 1.0 / (50.0 * 5000.0), device=dev)
+            h8 = torch.empty(M, arch.hidden, dtype=torch.float8_e4m3fn, device=dev)
+            ms = time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=h8, epilogue=1, m_valid=B * n_tok, out_scale=100.0))
+        else:
+            ms = time_kernel(lambda: ops.gemm_bf16(a, w, bias, out=h, epilogue=1, m_valid=B * n_tok))
         gemm_flops = 2.0 * B * n_tok * arch.dim * arch.hidden   # algorithmic: valid rows only
         ach = gemm_flops / (ms * 1e-3) / 1e12
         vit_tf = vit_flops_per_crop(arch, args.size, args.layer) * det_per_s / world / 1e12
@@ -179,11 +188,11 @@ def main():
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
                                    f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}",
                        "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step"},
-            "roofline": {"kernel": "gemm_bf16_kernel<GELU> (fc1 of one ViT block)", "bound": "mfma", "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(ach / PEAK_BF16_TFLOPS, 4), "traffic": hbm_traffic_fc1(args, arch, B), "launch_ms": round(ms, 4),
+            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_mfma,
+                         "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "traffic": hbm_traffic_fc1(args, arch, B), "launch_ms": round(ms, 4),
                          "flops_per_launch": gemm_flops},
-            "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                                        "frac": round(vit_tf / PEAK_BF16_TFLOPS, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
+            "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
+                                        "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
             "roofline_knn": {"kernel": "fp_cosine_topk (template-descriptor streaming + top-5)", "bound": "hbm", "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1),
                              "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
                              "bytes_per_launch": knn_bytes},
