@@ -66,3 +66,9 @@ def test_oracle_topn_is_clamped_to_the_template_count():
     assert [o["template_id"] for o in out][0] == 1 and len(out) == 2
     with pytest.raises(ValueError):
         clib.topk_torch(np.zeros(3, np.float32), 5)
+
+
+def test_graft_entry_build_runs():
+    """The driver's "does it build" hook: compiles what is stale (nothing, normally), loads the library, checks the ABI."""
+    import __graft_entry__ as entry
+    entry.build()
