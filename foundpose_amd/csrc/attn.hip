@@ -225,7 +225,10 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
 // Rows past the last token read as zeros (buffer range check) and are masked exactly like before.
 typedef __attribute__((address_space(3))) void lds_void_t;
 
-__global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
+// QB = 32-query blocks per wave: 2 (4 waves per block, 208 VGPRs, 2 waves/SIMD -- the default) or 1 (8 waves per block of the
+// same 256 queries, <= 128 VGPRs, 4 waves/SIMD: more waves to overlap, twice the LDS fragment traffic per flop).
+template <int QB>
+__global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: DMA offsets
   const int l31 = lane & 31, kh = lane >> 5;
@@ -246,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   }
   const int N = a.n_tok, D = a.dim;
   const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
-  const int q0 = qt * 256 + wave * 64;
+  const int q0 = qt * 256 + wave * (32 * QB);
   const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
 
   // ---- staging: wave w issues row groups 2w, 2w+1 (8 keys x 128 B each) of K and of V
@@ -257,38 +260,46 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   const unsigned voff_k1 = rowoff + ((sp ^ ((sr >> 1) + 4)) << 4);  // odd row group: ... + 4
   const unsigned voff_v = rowoff + ((sp ^ (((sr >> 1) & 1) << 2)) << 4);
   const unsigned tile_stride = (unsigned)(64 * a.ld_qkv) * 2u, grp_stride = (unsigned)(8 * a.ld_qkv) * 2u;
-  const unsigned soff_k = (unsigned)(D + head * 64) * 2u + 2u * wave * grp_stride, soff_v = soff_k + (unsigned)D * 2u;
+  const unsigned soff_k = (unsigned)(D + head * 64) * 2u + (unsigned)QB * wave * grp_stride, soff_v = soff_k + (unsigned)D * 2u;
+  const unsigned voff_kw = (wave & 1) ? voff_k1 : voff_k0;  // QB == 1: wave w stages row group w only
   auto stage_tile = [&](int kt, int stage) {
     const unsigned t = kt * tile_stride;
-    char* kd = KV[stage][0] + wave * 2048;
-    char* vd = KV[stage][1] + wave * 2048;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(vd + 1024), 16, voff_v, soff_v + t + grp_stride, 0, 0);
+    char* kd = KV[stage][0] + wave * (1024 * QB);
+    char* vd = KV[stage][1] + wave * (1024 * QB);
+    if constexpr (QB == 2) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(vd + 1024), 16, voff_v, soff_v + t + grp_stride, 0, 0);
+    } else {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_kw, soff_k + t, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
+    }
   };
   const int nkt = (N + 63) / 64;
   stage_tile(0, 0);
 
   const float c = 0.125f * 1.44269504088896340736f;  // head_dim^-0.5 * log2(e)
   // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d]
-  bf16x8 qf[2][4];
+  bf16x8 qf[QB][4];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb) {
+  for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + qb * 32 + l31;
     const int qc = q < N ? q : N - 1;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
       qf[qb][ds] = *reinterpret_cast<const bf16x8*>(qkv + (size_t)qc * a.ld_qkv + head * 64 + (ds * 2 + kh) * 8);
   }
-  f32x16 oacc[2][2];
+  f32x16 oacc[QB][2];
 #pragma unroll
-  for (int qb = 0; qb < 2; ++qb)
+  for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[qb][i][r] = 0.f;
-  float m_run[2] = {-INFINITY, -INFINITY}, l_run[2] = {0.f, 0.f};
+  float m_run[QB], l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) { m_run[qb] = -INFINITY; l_run[qb] = 0.f; }
   // transpose-read base inside the V image: key = kh*8 + kq, 16-d block b, 8-B piece; the 64-B half flips with kq >> 1
   const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
   const int vrd0 = (kh * 8 + kq) * 128 + (((kq >> 1) & 1) << 6) + vb * 32 + (lane & 3) * 8;
@@ -308,23 +319,24 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);  // the other stage was last read one iteration ago
     if (active) {
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
-      f32x16 sacc[2][2];
+      f32x16 sacc[QB][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int qb = 0; qb < 2; ++qb)
+        for (int qb = 0; qb < QB; ++qb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[qb][ks][r] = 0.f;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
           const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
-          sacc[0][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[0][ds], sacc[0][ks], 0, 0, 0);
-          sacc[1][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[1][ds], sacc[1][ks], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
         }
       }
-      bf16x8 pf[2][4];
+      bf16x8 pf[QB][4];
 #pragma unroll
-      for (int qb = 0; qb < 2; ++qb) {
+      for (int qb = 0; qb < QB; ++qb) {
         if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
           const int lim = N - key0 - 4 * kh;
 #pragma unroll
@@ -385,8 +397,9 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 512));
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          oacc[0][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[0][kstep], oacc[0][dt], 0, 0, 0);
-          oacc[1][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[1][kstep], oacc[1][dt], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb)
+            oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kstep], oacc[qb][dt], 0, 0, 0);
         }
     }
     if constexpr (!RAGGED) {
@@ -400,7 +413,7 @@ __global__ __launch_bounds__(256, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 
   if (active) {
 #pragma unroll
-    for (int qb = 0; qb < 2; ++qb) {
+    for (int qb = 0; qb < QB; ++qb) {
       const int q = q0 + qb * 32 + l31;
       const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
       const float inv = 1.f / l_tot;
@@ -490,7 +503,8 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     const int w64 = w64_env ? atoi(w64_env) : 1;
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
-      hipLaunchKernelGGL(attn_bf16_w64_kernel, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(256), 0, st, a);
+      if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
     }

@@ -116,9 +116,11 @@ def test_attention_bf16_work_splits_agree_bitwise(B, N, heads, monkeypatch):
     monkeypatch.setenv("FP_ATTN_W64", "0")
     o_a = ops.attention(q16, B, N, D, heads).clone()
     monkeypatch.setenv("FP_ATTN_W64", "1")
-    o_b = ops.attention(q16, B, N, D, heads)
+    o_b = ops.attention(q16, B, N, D, heads).clone()
+    monkeypatch.setenv("FP_ATTN_W64", "2")   # the DMA kernel with one 32-query block per wave, 8 waves per block
+    o_c = ops.attention(q16, B, N, D, heads)
     torch.cuda.synchronize()
-    assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16))
+    assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_c.view(torch.int16))
 
 
 def _extractor(arch, name, seed, precision):
