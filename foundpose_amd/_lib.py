@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -30,14 +30,14 @@ class VitModel(C.Structure):
         ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
         ("ffn_swiglu", i32), ("weight_dtype", i32),
         ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
-        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32),
     ]
 
 
 class VitWorkspace(C.Structure):
     _fields_ = [
         ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp), ("a8", vp),
-        ("m_pad", i32), ("m_patch_pad", i32),
+        ("ld_y", i32), ("ld_h", i32), ("ld_qkv", i32), ("m_pad", i32), ("m_patch_pad", i32),
     ]
 
 

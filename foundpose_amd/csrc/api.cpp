@@ -308,13 +308,19 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     TRY(f32_tile_launch(F32_EPI_TOKENS, a, Mp, D, 1, st));
   }
 
+  // row strides of the bf16 / fp32 operands (fp8 mode: dense)
+  const int ldy = (!f8 && ws->ld_y) ? ws->ld_y : D, ldh = (!f8 && ws->ld_h) ? ws->ld_h : m->hidden;
+  const int ldq = ws->ld_qkv ? ws->ld_qkv : 3 * D;
+  const int ldwd = (!f8 && m->ld_w_dim) ? m->ld_w_dim : D, ldwh = (!f8 && m->ld_w_hidden) ? m->ld_w_hidden : m->hidden;
+  FP_REQUIRE(ldy >= D && ldh >= m->hidden && ldwd >= D && ldwh >= m->hidden && ldy % 8 == 0 && ldh % 8 == 0 && ldwd % 8 == 0 && ldwh % 8 == 0 && ldq >= 3 * D && ldq % 8 == 0,
+             "fp_vit_forward: operand row strides must cover the row and keep 16-byte alignment");
   LayerNormArgs ln;
   ln.out_scale = 0.f;
-  ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = D; ln.out_dtype = adt;
+  ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = ldy; ln.out_dtype = adt;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
   at.out_fp8_scale = 0.f;
-  at.qkv = ws->qkv; at.ld_qkv = 3 * D; at.out = ws->y; at.ld_out = D;
+  at.qkv = ws->qkv; at.ld_qkv = ldq; at.out = ws->y; at.ld_out = ldy;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
 
   for (int i = 0; i <= layer; ++i) {
@@ -328,7 +334,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
       LayerNormArgs l8 = ln;
       l8.out = ws->a8; l8.ld_out = D; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
       TRY(layernorm_launch(l8, st));
-      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, 0.f, stream));
+      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, stream));
       AttnArgs a8 = at;
       a8.out = ws->a8; a8.ld_out = D; a8.out_fp8_scale = b.act_scale[1];
       TRY(attn_launch(a8, FP_DTYPE_BF16, st));
@@ -344,29 +350,29 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     }
     TRY(layernorm_launch(ln, st));
     if (bf) {
-      TRY(fp_gemm_bf16(ws->y, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, nullptr, ws->qkv, 3 * D, GEMM_EPI_BIAS_BF16, stream));
+      TRY(fp_gemm_bf16(ws->y, ldy, b.qkv_w, ldwd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, stream));
       TRY(attn_launch(at, FP_DTYPE_BF16, st));
-      TRY(fp_gemm_bf16(ws->y, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+      TRY(fp_gemm_bf16(ws->y, ldy, b.proj_w, ldwd, ws->m_pad, D, D, Mtok, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
     } else {
-      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.qkv_w, D, Mtok, 3 * D, D, b.qkv_b, nullptr, (float*)ws->qkv, 3 * D, F32_EPI_BIAS, stream));
+      TRY(fp_gemm_f32((const float*)ws->y, ldy, (const float*)b.qkv_w, ldwd, Mtok, 3 * D, D, b.qkv_b, nullptr, (float*)ws->qkv, ldq, F32_EPI_BIAS, stream));
       TRY(attn_launch(at, FP_DTYPE_F32, st));
-      TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.proj_w, D, Mtok, D, D, b.proj_b, b.ls1, ws->x, D, F32_EPI_LS_RESID, stream));
+      TRY(fp_gemm_f32((const float*)ws->y, ldy, (const float*)b.proj_w, ldwd, Mtok, D, D, b.proj_b, b.ls1, ws->x, D, F32_EPI_LS_RESID, stream));
     }
     // x += ls2 * fc2(gelu(fc1(ln2(x))))
     ln.weight = b.ln2_w; ln.bias = b.ln2_b;
     TRY(layernorm_launch(ln, st));
     if (bf) {
       if (m->ffn_swiglu)  // fc1_w = w12 with rows interleaved (x1_j, x2_j); h = silu(x1) * x2
-        TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, stream));
+        TRY(fp_gemm_bf16(ws->y, ldy, b.fc1_w, ldwd, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, stream));
       else
-        TRY(fp_gemm_bf16(ws->y, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, m->hidden, GEMM_EPI_GELU_BF16, stream));
-      TRY(fp_gemm_bf16(ws->h, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
+        TRY(fp_gemm_bf16(ws->y, ldy, b.fc1_w, ldwd, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, stream));
+      TRY(fp_gemm_bf16(ws->h, ldh, b.fc2_w, ldwh, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, stream));
     } else {
       if (m->ffn_swiglu)
-        TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, 2 * m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_SWIGLU, stream));
+        TRY(fp_gemm_f32((const float*)ws->y, ldy, (const float*)b.fc1_w, ldwd, Mtok, 2 * m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, ldh, F32_EPI_SWIGLU, stream));
       else
-        TRY(fp_gemm_f32((const float*)ws->y, D, (const float*)b.fc1_w, D, Mtok, m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, m->hidden, F32_EPI_BIAS_GELU, stream));
-      TRY(fp_gemm_f32((const float*)ws->h, m->hidden, (const float*)b.fc2_w, m->hidden, Mtok, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, F32_EPI_LS_RESID, stream));
+        TRY(fp_gemm_f32((const float*)ws->y, ldy, (const float*)b.fc1_w, ldwd, Mtok, m->hidden, D, b.fc1_b, nullptr, (float*)ws->h, ldh, F32_EPI_BIAS_GELU, stream));
+      TRY(fp_gemm_f32((const float*)ws->h, ldh, (const float*)b.fc2_w, ldwh, Mtok, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, F32_EPI_LS_RESID, stream));
     }
   }
   return FP_OK;

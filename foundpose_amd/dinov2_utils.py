@@ -10,6 +10,7 @@ Not implemented (unused by the shipped configs): stride != 14 and the key/query/
 """
 
 import ctypes as C
+import os
 import math
 from typing import Dict, Optional, Tuple
 
@@ -95,8 +96,26 @@ class DinoFeatureExtractor(torch.nn.Module):
         wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
         w: Dict[str, torch.Tensor] = {}
 
+        # Row strides of the block matrices and of the y / h activation buffers are padded by `pad` elements so that a
+        # stride is never a multiple of 2 KiB: the 8 rows one staging instruction of the GEMM fetches then spread over
+        # the L2 channels instead of queueing on one (FP_LD_PAD overrides; 0 = dense; fp8 mode stays dense).
+        pad = int(os.environ.get("FP_LD_PAD", "64")) if self.precision != "fp8" else 0
+        if pad % 8:
+            raise ValueError("FP_LD_PAD must be a multiple of 8")
+        self._ld_pad = pad
+        # the qkv buffer's stride can be padded too (FP_LD_PAD_QKV): in isolation the attention kernel and the qkv GEMM gain
+        # 5-9 % from +64..128 elements, inside the pipeline nothing (998 detections/s at 0 / 64 / 128 / 256) -> dense
+        self._ld_pad_qkv = int(os.environ.get("FP_LD_PAD_QKV", "0"))
+
+        def padded(t2d):  # [N, K] -> view of an [N, K + pad] buffer
+            if pad == 0:
+                return t2d.contiguous()
+            buf = torch.zeros(t2d.shape[0], t2d.shape[1] + pad, dtype=t2d.dtype, device=t2d.device)
+            buf[:, :t2d.shape[1]] = t2d
+            return buf[:, :t2d.shape[1]]
+
         def mat(key):
-            w[key] = sd[key].to(dev, torch.float32).to(wdt).contiguous()
+            w[key] = padded(sd[key].to(dev, torch.float32).to(wdt))
             return w[key]
 
         def vec(key):
@@ -129,7 +148,7 @@ class DinoFeatureExtractor(torch.nn.Module):
                 w12 = sd[p + "mlp.w12.weight"].to(dev, torch.float32)
                 b12 = sd[p + "mlp.w12.bias"].to(dev, torch.float32)
                 hdn = w12.shape[0] // 2
-                w[p + "w12i"] = torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1).to(wdt).contiguous()
+                w[p + "w12i"] = padded(torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1).to(wdt))
                 w[p + "b12i"] = torch.stack([b12[:hdn], b12[hdn:]], 1).reshape(-1).contiguous()
                 b.fc1_w, b.fc1_b = ptr(w[p + "w12i"]), ptr(w[p + "b12i"])
                 b.fc2_w, b.fc2_b = ptr(mat(p + "mlp.w3.weight")), ptr(vec(p + "mlp.w3.bias"))
@@ -140,6 +159,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
         m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
+        m.ld_w_dim, m.ld_w_hidden = (a.dim + pad, a.hidden + pad) if pad else (0, 0)
         self._w, self._model, self._blocks, self._device = w, m, blocks, dev
         self._grids.clear()
         self._ws.clear()
@@ -168,15 +188,17 @@ class DinoFeatureExtractor(torch.nn.Module):
             bufs = [
                 torch.zeros(mp_pad, self._model.patch_k_pad, dtype=adt, device=dev),
                 torch.zeros(m_pad, a.dim, dtype=torch.float32, device=dev),
-                torch.zeros(m_pad, a.dim, dtype=adt, device=dev),
-                torch.zeros(m_pad, 3 * a.dim, dtype=adt, device=dev),
-                torch.zeros(m_pad, a.hidden, dtype=adt, device=dev),
+                torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev),
+                torch.zeros(m_pad, 3 * a.dim + self._ld_pad_qkv, dtype=adt, device=dev),
+                torch.zeros(m_pad, a.hidden + self._ld_pad, dtype=adt, device=dev),
             ]
             if self.precision == "fp8":
                 bufs.append(torch.zeros(m_pad, max(a.dim, a.hidden), dtype=torch.uint8, device=dev))
             ws = _lib.VitWorkspace()
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
             ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
+            ws.ld_y, ws.ld_h = (a.dim + self._ld_pad, a.hidden + self._ld_pad) if self._ld_pad else (0, 0)
+            ws.ld_qkv = 3 * a.dim + self._ld_pad_qkv
             ws.m_pad, ws.m_patch_pad = m_pad, mp_pad
             self._ws[key] = (ws, bufs)
         return self._ws[key]

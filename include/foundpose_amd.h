@@ -25,7 +25,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 6
+#define FP_ABI_VERSION 7
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -132,6 +132,9 @@ typedef struct {
   const float* prefix;     /* [1+registers, D]: cls_token + pos[0], then the register tokens */
   const float *norm_w, *norm_b;
   const fp_vit_block* blocks; /* HOST array of `depth` entries */
+  int ld_w_dim, ld_w_hidden;  /* row strides (elements) of the block matrices with K = dim (qkv, proj, fc1) and with
+                                 K = hidden (fc2); 0 = dense (dim / hidden).  A stride that is not a multiple of 2 KiB
+                                 keeps the 8 rows of a staging instruction off one L2 channel */
 } fp_vit_model;
 
 typedef struct {
@@ -142,6 +145,7 @@ typedef struct {
   void* h;       /* [m_pad, hidden] */
   void* a8;      /* FP_FP8 only: [m_pad, max(D, hidden)] bytes, the quantised input of the GEMM about to run; m_pad must
                     then be a multiple of 256 */
+  int ld_y, ld_h, ld_qkv; /* row strides (elements) of y, h and qkv; 0 = dense (D / hidden / 3D) */
   int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
   int m_patch_pad; /* multiple of 128, >= B*Np */
 } fp_vit_workspace;
