@@ -6,7 +6,7 @@ Differences that do not change results:
     block's output, dinov2_utils.py:257) and no autograd graph is built;
   * weights: the reference downloads the pretrained hub checkpoint (`pretrained=True`, dinov2_utils.py:82);
     there is no network here, so pass `state_dict=` (upstream DINOv2 key names) or get seeded random weights.
-Not implemented (unused by the shipped configs): stride != 14 and the key/query/value facets.
+Not implemented: stride != 14 (the reference's own code for it cannot run) and the "attn" facet.
 """
 
 import ctypes as C
@@ -58,8 +58,10 @@ class DinoFeatureExtractor(torch.nn.Module):
                 "stride != patch size is not implemented on the MI355X path.  (The reference's own code for it cannot run "
                 "either: _fix_pos_enc returns a function without a `self` parameter and binds it with types.MethodType "
                 "(dinov2_utils.py:326,386-388), so its first forward raises TypeError; there is no behaviour to match.)")
-        if self.facet != "token":
-            raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path (shipped configs use 'token')")
+        if self.facet not in ("token", "key", "query", "value"):
+            raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path ('token', 'key', 'query', 'value' are)")
+        if self.facet != "token" and use_graph:
+            raise NotImplementedError("use_graph replays the token path only")
         if not 0 <= self.layer < self.arch.depth:
             raise ValueError(f"layer {self.layer} out of range for {self.version}")
         if precision not in ("bf16", "fp32", "fp8"):
@@ -221,7 +223,9 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
             self.calibrate_fp8(images)
-        if self.use_graph:
+        if self.facet != "token":
+            fmap, cls = self._forward_facet(images, B, H, W, gh, gw)
+        elif self.use_graph:
             fmap, cls = self._forward_graph(images, ws, B, H, W, gh, gw)
         else:
             fmap = torch.empty(B, gh * gw, self.arch.dim, dtype=torch.float32, device=images.device)
@@ -229,6 +233,21 @@ class DinoFeatureExtractor(torch.nn.Module):
             self._launch(images, ws, B, H, W, gh, gw, fmap, cls)
         self.num_patches = (gh, gw)
         return fmap, cls
+
+    def _forward_facet(self, images, B, H, W, gh, gw):
+        """key / query / value facet (dinov2_utils.py:176-194, 294-311 in the reference): the qkv projection of
+        blocks[layer] is what the forward leaves in the workspace; per token the reference orders the vector (d, head)."""
+        from . import ops
+        a = self.arch
+        ws, bufs = self._workspace(B, gh, gw)
+        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        ntok, fi = 1 + a.registers + gh * gw, {"query": 0, "key": 1, "value": 2}[self.facet]
+        f = bufs[3][:B * ntok, fi * a.dim:(fi + 1) * a.dim].float()
+        f = f.reshape(B, ntok, a.heads, a.head_dim).permute(0, 1, 3, 2).reshape(B, ntok, a.dim)
+        tok = torch.cat([f[:, :1], f[:, 1 + a.registers:]], dim=1)
+        if self.apply_norm:
+            tok = ops.layernorm(tok.reshape(-1, a.dim).contiguous(), self._w["norm.weight"], self._w["norm.bias"], torch.float32).reshape(B, -1, a.dim)
+        return tok[:, 1:].contiguous(), tok[:, 0].contiguous()
 
     # ---- fp8 mode
     def calibrate_fp8(self, images: Optional[torch.Tensor] = None, act_scales: Optional[torch.Tensor] = None) -> torch.Tensor:

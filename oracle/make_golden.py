@@ -174,6 +174,18 @@ def gen_extractor(ref):
     np.savez_compressed(os.path.join(OUT, "extractor_tiny.npz"), **out)
     print("extractor_tiny", out["fmap_l1_n1"].shape)
 
+    # (a') key / query / value facets through the reference wrapper's attention hooks (dinov2_utils.py:176-194)
+    fac = {"weights_seed": np.int64(1234), "image_seed": np.int64(0)}
+    for facet in ("key", "query", "value"):
+        for layer, norm in ((1, 1), (2, 0)):
+            ex = _make_ref_extractor(ref, TINY, sd, 56, f"dinov2_version=tiny-reg_stride=14_facet={facet}_layer={layer}_logbin=0_norm={norm}")
+            with torch.no_grad():
+                o = ex(imgs)
+            fac[f"fmap_{facet}_l{layer}_n{norm}"] = t2n(o["feature_maps"]).astype(np.float32)
+            fac[f"cls_{facet}_l{layer}_n{norm}"] = t2n(o["cls_tokens"]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "extractor_tiny_facets.npz"), **fac)
+    print("extractor_tiny_facets", fac["fmap_key_l1_n1"].shape)
+
     # (b) ViT-S/14-reg at 518 (no pos-embed interpolation), the shipped LM-O extractor name.
     arch = ARCHS["vits14-reg"]
     sd = synthetic.make_vit_state_dict(arch, seed=1234)

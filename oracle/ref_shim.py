@@ -173,6 +173,14 @@ class HFBackboneAdapter(torch.nn.Module):
                 m[t + "mlp.weights_out.weight"] = sd[s + "mlp.w3.weight"]
                 m[t + "mlp.weights_out.bias"] = sd[s + "mlp.w3.bias"]
         missing, unexpected = hf.load_state_dict(m, strict=True)
+        # attribute surface of upstream blocks that the key / query / value facet hooks touch (dinov2_utils.py:184-194,
+        # 206-214): block.attn is called with norm1(x), has .qkv (one fused projection) and .num_heads
+        for layer in hf.encoder.layer:
+            att = layer.attention
+            inner = att.attention
+            att.qkv = (lambda x, a=inner: torch.cat([a.query(x), a.key(x), a.value(x)], dim=-1))
+            att.num_heads = arch.heads
+            layer.attn = att
         self.hf = hf
         self.blocks = hf.encoder.layer
         self.norm = hf.layernorm

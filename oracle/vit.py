@@ -170,10 +170,29 @@ def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quan
 
 
 @torch.no_grad()
-def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False, fp8_act=None):
+def facet_tokens(sd, arch: VitArch, images: torch.Tensor, layer: int, facet: str, quant=None) -> torch.Tensor:
+    """key / query / value facet of blocks[layer] as the reference's attention hook delivers it (dinov2_utils.py:176-194,
+    294-311): qkv(norm1(x)) -> [B, h, t, d] -> per token the vector indexed (d, head), i.e. [B, t, d * h + head]."""
+    x = embed_tokens(sd, arch, normalize_images(images), quant)
+    for i in range(layer):
+        x = block_forward(sd, arch, i, x, quant)
+    p = f"blocks.{layer}."
+    B, N, D = x.shape
+    y = F.layer_norm(x, (D,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], eps=1e-6)
+    qkv = _q(F.linear(_q(y, quant), _q(sd[p + "attn.qkv.weight"], quant), sd[p + "attn.qkv.bias"]), quant)
+    f = qkv.reshape(B, N, 3, arch.heads, arch.head_dim)[:, :, {"query": 0, "key": 1, "value": 2}[facet]]  # [B, t, h, d]
+    return f.permute(0, 1, 3, 2).reshape(B, N, D)
+
+
+@torch.no_grad()
+def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False, fp8_act=None,
+                      facet: str = "token"):
     """-> {"cls_tokens": [B,D], "feature_maps": [B,D,Hp,Wp]} exactly like the reference wrapper."""
     B, _, H, W = images.shape
-    hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks, fp8_act)
+    if facet == "token":
+        hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks, fp8_act)
+    else:
+        hs = facet_tokens(sd, arch, images, layer, facet, quant)
     cls, patch = hs[:, :1], hs[:, 1 + arch.registers:]
     if apply_norm:
         tok = F.layer_norm(torch.cat([cls, patch], 1), (arch.dim,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)

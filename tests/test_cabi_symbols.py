@@ -49,7 +49,7 @@ def test_bank_builder_entry_points_refuse_cpu_tensors_and_bad_names():
     with pytest.raises(NotImplementedError, match="no behaviour to match"):
         feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=7_facet=token_layer=9_norm=1")
     with pytest.raises(NotImplementedError):
-        feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=key_layer=9_norm=1")
+        feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=attn_layer=9_norm=1")
     with pytest.raises(ValueError):
         knn_util.KNN(k=1, metric="manhattan").fit(torch.zeros(4, 4))         # knn_util.py:61-63 in the reference
 

@@ -123,6 +123,20 @@ def test_attention_bf16_work_splits_agree_bitwise(B, N, heads, monkeypatch):
     assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_c.view(torch.int16))
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("bf16", 3e-2)])
+def test_extractor_key_query_value_facets_vs_reference_wrapper_fixture(precision, tol):
+    g = load_golden("extractor_tiny_facets")
+    imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"])).cuda()
+    for facet in ("key", "query", "value"):
+        for layer, norm in ((1, 1), (2, 0)):
+            ex = _extractor(TINY, f"dinov2_version=tiny-reg_stride=14_facet={facet}_layer={layer}_logbin=0_norm={norm}", int(g["weights_seed"]), precision)
+            o = ex(imgs)
+            ref = g[f"fmap_{facet}_l{layer}_n{norm}"]
+            assert o["feature_maps"].shape == (2, 128, 4, 4)
+            np.testing.assert_allclose(o["feature_maps"].cpu().numpy(), ref, rtol=0, atol=tol * np.abs(ref).max())
+            np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g[f"cls_{facet}_l{layer}_n{norm}"], rtol=0, atol=tol * np.abs(ref).max())
+
+
 def _extractor(arch, name, seed, precision):
     from foundpose_amd import feature_util
     ex = feature_util.make_feature_extractor(name, seed=seed, precision=precision, arch=arch if arch is TINY else None)

@@ -93,3 +93,19 @@ def test_hot_section_composite():
     # and through the oracle's own features (fp32 noise 1e-5): same retrieved templates
     out2 = om.establish_correspondences(qp.numpy(), qfp.numpy(), repre, 5, 300, "torch")
     assert [o["template_id"] for o in out2] == list(g["template_ids"])
+
+
+def test_oracle_facets_match_reference_wrapper_fixture():
+    """key / query / value facets: oracle vs the reference wrapper's attention hooks (tests/golden/extractor_tiny_facets.npz)."""
+    import numpy as np
+    from foundpose_amd import synthetic
+    from oracle import vit as ov
+    from tests.helpers import TINY, load_golden
+    g = load_golden("extractor_tiny_facets")
+    sd = synthetic.make_vit_state_dict(TINY, int(g["weights_seed"]))
+    imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"]))
+    for facet in ("key", "query", "value"):
+        for layer, norm in ((1, 1), (2, 0)):
+            o = ov.extractor_forward(sd, TINY, imgs, layer, bool(norm), facet=facet)
+            np.testing.assert_allclose(o["feature_maps"].numpy(), g[f"fmap_{facet}_l{layer}_n{norm}"], rtol=0, atol=5e-6)
+            np.testing.assert_allclose(o["cls_tokens"].numpy(), g[f"cls_{facet}_l{layer}_n{norm}"], rtol=0, atol=5e-6)
