@@ -180,7 +180,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         return self._grids[key]
 
     def _workspace(self, B: int, gh: int, gw: int):
-        key = (B, gh, gw)
+        key = (B, gh, gw, torch.cuda.current_stream().cuda_stream)  # one workspace per stream: concurrent sub-batches
         if key not in self._ws:
             a, dev = self.arch, self._device
             adt = torch.float32 if self.precision == "fp32" else torch.bfloat16
