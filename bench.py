@@ -98,12 +98,20 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    # FP_BENCH_ONE_DEVICE=1 (+ FP_BENCH_BACKEND=gloo): dry run of the multi-rank path on a single-GPU box -- every rank
+    # uses cuda:0 and the records travel through host memory.  Never set by the driver; the real runs use RCCL.
+    if os.environ.get("FP_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        backend = os.environ.get("FP_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from foundpose_amd import engine as fe
     from foundpose_amd import feature_util, ops, synthetic
@@ -142,7 +150,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     det_per_s = world * B * args.steps / elapsed

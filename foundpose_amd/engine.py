@@ -115,6 +115,11 @@ def gather_records(local: torch.Tensor, world_size: int) -> torch.Tensor:
     if world_size == 1:
         return local
     import torch.distributed as dist
+    if local.is_cuda and dist.get_backend() == "gloo":  # dry runs of the multi-rank path without RCCL: through host memory
+        host = local.cpu()
+        out = torch.empty(world_size * host.shape[0], host.shape[1], dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.to(local.device)
     out = torch.empty(world_size * local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
     return out

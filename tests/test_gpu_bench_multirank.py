@@ -1,0 +1,27 @@
+"""bench.py under torch.distributed.run with two ranks, dry-run mode (both ranks on cuda:0, records through host memory
+over gloo): the launch contract, sharding, the gather step, the max-over-ranks timing and the one JSON line from rank 0.
+The real multi-GPU runs use RCCL; nothing else differs."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_two_ranks_dry_run():
+    env = dict(os.environ, FP_BENCH_ONE_DEVICE="1", FP_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--templates", "600", "--batch", "8", "--version", "vits14-reg", "--layer", "9", "--size", "224"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
+    assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 0.02 * d["value"]  # whole-job rate
+    assert "cpu_baseline" not in d and "roofline" in d      # the CPU baseline is timed at N = 1 only
