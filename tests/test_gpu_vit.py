@@ -326,7 +326,8 @@ def test_quantize_fp8_matches_torch_cast(dtype):
         assert torch.equal(got.float(), ref.float())
 
 
-@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 128, 0), (512, 768, 1536, 0), (256, 512, 1024, 1), (512, 256, 4096, 3), (256, 512, 256, 6)])
+@pytest.mark.parametrize("M,N,K,epi", [(256, 256, 128, 0), (512, 768, 1536, 0), (256, 512, 1024, 1), (512, 256, 4096, 3), (256, 512, 256, 6),
+                                       (256, 4608, 1536, 0), (256, 8192, 1536, 6), (256, 1536, 4096, 3)])  # last three: ViT-g/14 block shapes
 def test_gemm_fp8_vs_fp64_on_quantised_operands(M, N, K, epi):
     """fp8 x fp8 products are exact in fp32; only the accumulation order differs from an fp64 reference on the same
     quantised operands -> fp32-accumulation tolerance, not an fp8 one.  Epilogues: bias, GELU, LayerScale-residual, SwiGLU."""
