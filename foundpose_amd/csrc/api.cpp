@@ -287,6 +287,9 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
   const int adt = bf ? FP_DTYPE_BF16 : FP_DTYPE_F32;
   FP_REQUIRE(!f8 || (ws->a8 && ws->m_pad % 256 == 0), "fp_vit_forward: the fp8 mode needs workspace a8 and m_pad %% 256 == 0");
+  FP_REQUIRE(!f8 || ((ws->ld_y == 0 || (ws->ld_y >= m->dim && ws->ld_y % 16 == 0)) && (ws->ld_h == 0 || (ws->ld_h >= m->hidden && ws->ld_h % 16 == 0)) &&
+                     (m->ld_w_dim == 0 || (m->ld_w_dim >= m->dim && m->ld_w_dim % 16 == 0)) && (m->ld_w_hidden == 0 || (m->ld_w_hidden >= m->hidden && m->ld_w_hidden % 16 == 0))),
+             "fp_vit_forward: fp8 row strides (bytes) must cover the row and keep 16-byte alignment");
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
   TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, adt, st));
@@ -331,21 +334,24 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
       // fp8 block: every GEMM input is produced as e4m3 bytes by the kernel in front of it -- LayerNorm, attention and
       // the GELU / SwiGLU epilogue quantise with the block's static scales on their way out (ws->a8; the hidden
       // activations reuse ws->h as a byte buffer) -- so the four GEMMs run on the fp8 MFMA with no extra pass.
+      // row strides in bytes (= fp8 elements): a8 [m_pad, ld8y], hidden bytes [m_pad, ld8h], matrices [N, ld8wd / ld8wh]
+      const int ld8y = ws->ld_y ? ws->ld_y : D, ld8h = ws->ld_h ? ws->ld_h : m->hidden;
+      const int ld8wd = m->ld_w_dim ? m->ld_w_dim : D, ld8wh = m->ld_w_hidden ? m->ld_w_hidden : m->hidden;
       LayerNormArgs l8 = ln;
-      l8.out = ws->a8; l8.ld_out = D; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
+      l8.out = ws->a8; l8.ld_out = ld8y; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
       TRY(layernorm_launch(l8, st));
-      TRY(fp_gemm_fp8(ws->a8, D, b.qkv_w, D, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, stream));
+      TRY(fp_gemm_fp8(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, stream));
       AttnArgs a8 = at;
-      a8.out = ws->a8; a8.ld_out = D; a8.out_fp8_scale = b.act_scale[1];
+      a8.out = ws->a8; a8.ld_out = ld8y; a8.out_fp8_scale = b.act_scale[1];
       TRY(attn_launch(a8, FP_DTYPE_BF16, st));
-      TRY(fp_gemm_fp8(ws->a8, D, b.proj_w, D, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
+      TRY(fp_gemm_fp8(ws->a8, ld8y, b.proj_w, ld8wd, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
       l8.weight = b.ln2_w; l8.bias = b.ln2_b; l8.out_scale = b.act_scale[2];
       TRY(layernorm_launch(l8, st));
       if (m->ffn_swiglu)
-        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], stream));
+        TRY(fp_gemm_fp8(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], stream));
       else
-        TRY(fp_gemm_fp8(ws->a8, D, b.fc1_w, D, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, m->hidden, GEMM_EPI_GELU_BF16, b.act_scale[3], stream));
-      TRY(fp_gemm_fp8(ws->h, m->hidden, b.fc2_w, m->hidden, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
+        TRY(fp_gemm_fp8(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], stream));
+      TRY(fp_gemm_fp8(ws->h, ld8h, b.fc2_w, ld8wh, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
       continue;
     }
     TRY(layernorm_launch(ln, st));
