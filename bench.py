@@ -5,6 +5,11 @@ bank, one process per GPU.  Contract: see the task prompt / DESIGN.md "Measureme
   python bench.py                       # 1 GPU, finishes in a few minutes
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+
+The workload is PLANTED (foundpose_amd/workload.py): every crop's fp32 features sit, with graded noise, in five
+consecutive templates of the bank, so the expected output of a step is known and the line carries index-agreement
+numbers ("parity") next to the throughput: against oracle A (the fp32 CPU restatement, on the detections the
+cpu_baseline leg runs anyway) and against the library's own fp32 mode on every detection of the batch.
 """
 
 import argparse
@@ -22,44 +27,17 @@ PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guide: MI355X_MICROARCH.md
 PEAK_FP8_TFLOPS = 5000.0    # dense fp8 (block-scaled MFMA), --precision fp8 only (BASELINE config 5; never the headline run)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 
+# HBM-side bytes of one launch of the dominant kernel template from the rocprofv3 --pmc passes of THIS code (per the
+# guide's gfx950 corrections); keyed by (version, size, batch, precision).  Source file + commit are reported next to it.
+PMC_TRAFFIC = {}
+PMC_TRAFFIC_SOURCE = None
+
 
 def vit_flops_per_crop(arch, size, layer):
     np_ = (size // arch.patch) ** 2
     n = 1 + arch.registers + np_
     blk = 24 * n * arch.dim ** 2 + 4 * n * n * arch.dim
     return np_ * 3 * arch.patch ** 2 * arch.dim * 2 + (layer + 1) * blk
-
-
-def build_synthetic_bank(num_templates, feat_dim, raw_dim, num_words, seed, device):
-    """Planted-structure bank built with the device bank builder: P_t ~ U{300..450}."""
-    from foundpose_amd import bank_builder, projector_util, repre_util
-    g = torch.Generator(device="cpu").manual_seed(seed)
-    counts = torch.randint(300, 451, (num_templates,), generator=g)
-    n_f = int(counts.sum())
-    gd = torch.Generator(device=device).manual_seed(seed)
-    sigma = torch.arange(1, feat_dim + 1, dtype=torch.float32, device=device) ** -0.5
-    feats = torch.randn(n_f, feat_dim, generator=gd, device=device) * sigma
-    verts = torch.randn(n_f, 3, generator=gd, device=device) * 50.0
-    f2t = torch.repeat_interleave(torch.arange(num_templates, dtype=torch.int32), counts).to(device)
-    words = feats[torch.randperm(n_f, generator=g)[:num_words].to(device)].clone()
-    opts = repre_util.TemplateDescOpts()
-    descs, idfs, f2c = bank_builder.calc_tfidf_descriptors(feats, f2t, words, num_templates, opts)
-    comps = torch.linalg.qr(torch.randn(raw_dim, feat_dim, generator=g))[0].T.contiguous()  # [feat_dim, raw_dim] orthonormal rows
-    proj = projector_util.projector_from_tensordict({"pca_projector": {
-        "components": comps, "mean": torch.randn(raw_dim, generator=g) * 0.1, "whiten": torch.tensor(False)}})
-    return repre_util.FeatureBasedObjectRepre(
-        vertices=verts, feat_vectors=feats, feat_to_template_ids=f2t, feat_to_cluster_ids=f2c,
-        feat_to_vertex_ids=torch.arange(n_f, dtype=torch.int32, device=device), feat_cluster_centroids=words,
-        feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj])
-
-
-def hbm_traffic_fc1(args, arch, B):
-    """HBM-side bytes per fc1 launch from the rocprofv3 PMC passes of this exact shape (profiles/r1_pmc_counters.txt:
-    FETCH_SIZE 266533.5 KiB doubled per the gfx950 correction + WRITE_SIZE 351744.0 KiB, super-tile raster;
-    455183.5 KiB fetched with the plain tile order); null for any other shape."""
-    if (args.version, args.size, B, args.precision) == ("vitl14-reg", 518, 32, "bf16"):
-        return int((2 * 266533.5 + 351744.0) * 1024)
-    return None
 
 
 def time_kernel(fn, iters=20):
@@ -87,8 +65,11 @@ def main():
     ap.add_argument("--layer", type=int, default=18)
     ap.add_argument("--size", type=int, default=518)
     ap.add_argument("--precision", default="bf16")
+    ap.add_argument("--tie-order", default="torch", choices=["torch", "canonical"],
+                    help="'torch' (default, the headline): the reference's torch.topk tie order replayed on the device; 'canonical': (value, lowest index)")
     ap.add_argument("--graph", action="store_true", help="replay the ViT forward as one hipGraph (measured: no gain, the step is GPU-bound: 34.51 vs 34.44 ms)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
     ap.add_argument("--cpu-detections", type=int, default=3)
     args = ap.parse_args()
 
@@ -104,6 +85,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -114,136 +96,190 @@ def main():
             dist.init_process_group(backend)
 
     from foundpose_amd import engine as fe
-    from foundpose_amd import feature_util, ops, synthetic
+    from foundpose_amd import feature_util, ops, workload
     from foundpose_amd.bank import DeviceBank
     from foundpose_amd.vit_config import ARCHS
 
     arch = ARCHS[args.version]
     name = f"dinov2_version={args.version}_stride=14_facet=token_layer={args.layer}_norm=1"
-    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
-    repres = [build_synthetic_bank(args.templates, 256, arch.dim, 2048, seed=7 + o, device=dev) for o in range(args.objects)]
-    repre = repres[0]
-    bank = DeviceBank(repres, device=dev)
-    eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300)
-
     B = args.batch
-    images = synthetic.make_crops(B, args.size, seed=rank).to(dev)       # inputs resident in HBM before timing
-    masks = synthetic.make_disc_mask(args.size).unsqueeze(0).repeat(B, 1, 1).to(dev)
+    # ---- planted workload: the fp32 mode of the library produces the features that are planted (the reference's arithmetic)
+    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to(dev)
+    wl = workload.build_planted_workload(ex32, B, args.size, args.objects, args.templates, 256, 2048, seed=7, crop_seed=rank)
+    bank = DeviceBank(wl.repres, device=dev)
+    images, masks, det_obj = wl.crops, wl.masks, wl.det_obj     # inputs resident in HBM before timing
+    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
+    if args.precision == "fp8":
+        extractor.calibrate_fp8(images)  # static activation scales are part of the fp8 model (no implicit calibration)
+    eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order)
 
-    det_obj = sorted(i % args.objects for i in range(B))  # object id per crop, grouped by object (bank streamed once per group)
-
-    def step():
-        res = eng.infer_batch(images, masks, det_obj)
+    def step(e=eng):
+        res = e.infer_batch(images, masks, det_obj)
         rec = fe.pack_result(res)
-        return fe.gather_records(rec, world)   # the one exchange step (RCCL all-gather over xGMI)
+        return fe.gather_records(rec, world), res   # the one exchange step (RCCL all-gather over xGMI)
+
+    def timed(e, steps):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step(e)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
 
     for _ in range(args.warmup):
         step()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, (gathered, last) = timed(eng, args.steps)
     det_per_s = world * B * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+    if world > 1:
+        ranks_seen = int(gathered.shape[0] // B)
+        cnt = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
+        dist.all_reduce(cnt)
+        assert int(cnt.item()) == world == ranks_seen, "every rank must contribute its records to the gather"
+    # the other tie order, timed next to the headline (same inputs; not part of `value`)
+    other = "canonical" if args.tie_order == "torch" else "torch"
+    eng_o = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=other)
+    step(eng_o)
+    el_o, _ = timed(eng_o, max(3, args.steps // 2))
+    ms_other = 1e3 * el_o / max(3, args.steps // 2)
 
     if rank == 0:
-        # ---- roofline of the dominant kernel: the fc1 GEMM (+bias+GELU) of a ViT block, M = B*tokens
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
         M = (B * n_tok + 255) // 256 * 256
-        a = torch.randn(M, arch.dim, device=dev).to(torch.bfloat16)
-        w = (torch.randn(arch.hidden, arch.dim, device=dev) * 0.02).to(torch.bfloat16)
-        bias = torch.zeros(arch.hidden, device=dev)
-        h = torch.empty(M, arch.hidden, dtype=torch.bfloat16, device=dev)
-        peak_mfma, gemm_name = PEAK_BF16_TFLOPS, "gemm_bf16_kernel<GELU> (fc1 of one ViT block)"
-        if args.precision == "fp8":
-            peak_mfma, gemm_name = PEAK_FP8_TFLOPS, "gemm_bf16_kernel<GELU, fp8 operands, fp8 output> (fc1 of one ViT block)"
-            a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
-            col = torch.full((arch.hidden,), 1.0 / (50.0 * 5000.0), device=dev)
-            h8 = torch.empty(M, arch.hidden, dtype=torch.float8_e4m3fn, device=dev)
-            ms = time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=h8, epilogue=1, m_valid=B * n_tok, out_scale=100.0))
-        else:
-            ms = time_kernel(lambda: ops.gemm_bf16(a, w, bias, out=h, epilogue=1, m_valid=B * n_tok))
-        gemm_flops = 2.0 * B * n_tok * arch.dim * arch.hidden   # algorithmic: valid rows only
-        ach = gemm_flops / (ms * 1e-3) / 1e12
+        mv = B * n_tok
+        peak_mfma = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
+        # ---- roofline of the dominant kernel = the largest time bucket of a step: the LayerScale+residual GEMM template
+        # (gemm_bf16_kernel<LS_RESID>), launched twice per block: attn.proj (K = D) and mlp.fc2 (K = hidden)
+        def gemm_ms(n, k, epi):
+            a = torch.randn(M, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+            bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
+            out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
+            if args.precision == "fp8":
+                a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
+                col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
+                return time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=out, epilogue=epi, m_valid=mv))
+            return time_kernel(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi, m_valid=mv))
+        hid = arch.hidden
+        ms_proj, ms_fc2 = gemm_ms(arch.dim, arch.dim, 3), gemm_ms(arch.dim, hid, 3)
+        ms_fc1 = gemm_ms(hid if arch.ffn == "mlp" else 2 * hid, arch.dim, 1 if arch.ffn == "mlp" else 6)
+        ms_qkv = gemm_ms(3 * arch.dim, arch.dim, 0)
+        fl = lambda n, k: 2.0 * mv * n * k     # algorithmic: valid rows only
+        ls_flops, ls_ms = fl(arch.dim, arch.dim) + fl(arch.dim, hid), ms_proj + ms_fc2
+        ach = ls_flops / (ls_ms * 1e-3) / 1e12
         vit_tf = vit_flops_per_crop(arch, args.size, args.layer) * det_per_s / world / 1e12
-        # ---- HBM roofline of the bank-streaming retrieval kernel (template descriptors read once per batch)
-        from foundpose_amd._lib import call, ptr, stream
-        Bq = min(B, 32)  # detections of one object per retrieval launch (the kernel takes <= 64 per object per call)
+        # ---- HBM roofline of the template retrieval (descriptors of the object's templates read once per 32 detections)
+        from foundpose_amd._lib import call, cosine_scratch_floats, ptr, stream
+        Bq = min(B, 32)
         desc_n = ops.normalize_rows(torch.rand(Bq, 2048, device=dev))
         seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
         nt = torch.full((Bq,), args.templates, dtype=torch.int32, device=dev)
-        sims = torch.empty(9, Bq, args.templates, device=dev)
+        sims = torch.empty(cosine_scratch_floats(Bq, args.templates), device=dev)
         sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
-        ms_knn = time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
-                                          1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), 0, stream()))
-        knn_bytes = args.templates * 2048 * 4 + Bq * 2048 * 4 + Bq * args.templates * 4 * 2
+        tie_mode = 1 if args.tie_order == "torch" else 0
+        knn = lambda mode: time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
+                                                    bank.num_objects, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)
+        ms_knn, ms_knn_other = knn(tie_mode), knn(1 - tie_mode)
+        knn_bytes = args.templates * 2048 * 4 + Bq * 2048 * 4 + Bq * args.templates * 4   # bank + queries + finished scores
+        key = (args.version, args.size, B, args.precision)
         result = {
             "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",
             "value": round(det_per_s, 2), "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic (seeded crops/masks, random-init ViT weights, planted-structure bank)",
+            "dtype": args.precision, "data": "synthetic (seeded noise crops, disc masks, random-init ViT weights, planted bank: each crop's fp32 features "
+                                             "sit with graded noise in 5 consecutive templates, the rest are random patch mixtures)",
             "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block), "
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
-                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}",
-                       "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step"},
-            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": round(ach, 1), "peak": peak_mfma,
-                         "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4), "traffic": hbm_traffic_fc1(args, arch, B), "launch_ms": round(ms, 4),
-                         "flops_per_launch": gemm_flops},
+                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}, "
+                                   f"tie order '{args.tie_order}'" + (" (the reference's torch.topk order, replayed on the device)" if args.tie_order == "torch" else ""),
+                       "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step",
+                       "tie_order": args.tie_order},
+            "ranks_seen": ranks_seen,
+            "tie_order_cost": {args.tie_order + "_ms_per_step": round(ms_per_step, 3), other + "_ms_per_step": round(ms_other, 3)},
+            "roofline": {"kernel": "gemm_bf16_kernel<LS_RESID> (attn.proj + mlp.fc2 of one ViT block: the largest time bucket of a step)", "bound": "mfma",
+                         "achieved": round(ach, 1), "peak": peak_mfma, "unit": "TFLOP/s", "frac": round(ach / peak_mfma, 4),
+                         "traffic": PMC_TRAFFIC.get(key), "traffic_source": PMC_TRAFFIC_SOURCE if key in PMC_TRAFFIC else None,
+                         "launch_ms": round(ls_ms / 2, 4), "launch_ms_proj": round(ms_proj, 4), "launch_ms_fc2": round(ms_fc2, 4),
+                         "flops_per_launch": ls_flops / 2},
+            "roofline_other_gemms": {"fc1": {"launch_ms": round(ms_fc1, 4), "frac": round(fl(hid if arch.ffn == "mlp" else 2 * hid, arch.dim) / (ms_fc1 * 1e-3) / 1e12 / peak_mfma, 4)},
+                                     "qkv": {"launch_ms": round(ms_qkv, 4), "frac": round(fl(3 * arch.dim, arch.dim) / (ms_qkv * 1e-3) / 1e12 / peak_mfma, 4)},
+                                     "proj": {"launch_ms": round(ms_proj, 4), "frac": round(fl(arch.dim, arch.dim) / (ms_proj * 1e-3) / 1e12 / peak_mfma, 4)},
+                                     "fc2": {"launch_ms": round(ms_fc2, 4), "frac": round(fl(arch.dim, hid) / (ms_fc2 * 1e-3) / 1e12 / peak_mfma, 4)}},
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
                                         "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
-            "roofline_knn": {"kernel": "fp_cosine_topk (template-descriptor streaming + top-5)", "bound": "hbm", "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1),
-                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
-                             "bytes_per_launch": knn_bytes},
+            "roofline_knn": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}' (template-descriptor streaming + top-5, whole call)", "bound": "hbm",
+                             "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
+                             "launch_ms_" + other: round(ms_knn_other, 4), "bytes_per_launch": knn_bytes},
         }
+        lists = [last.corresp_list(b) for b in range(B)]
+        parity = {"tie_order": args.tie_order, "planted": workload.planted_stats(lists, wl.targets.tolist())}
+        if not args.no_parity:  # the library's fp32 mode on every detection of the batch (same bank, same tie order)
+            eng32 = fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order=args.tie_order)
+            res32 = eng32.infer_batch(images, masks, det_obj)
+            parity["vs_fp32_mode"] = workload.parity_stats(lists, [res32.corresp_list(b) for b in range(B)])
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            result["cpu_baseline"] = cpu_baseline(arch, args, repre, images, masks)
+            result["cpu_baseline"], parity["vs_oracle_a"] = cpu_baseline(arch, args, bank, wl, lists)
+        result["parity"] = parity
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(arch, args, repre, images, masks):
-    """The oracle's reference-equivalent CPU path on the host cores, bounded sample of the same workload."""
-    from foundpose_amd import synthetic
+def cpu_baseline(arch, args, bank, wl, gpu_lists):
+    """The oracle's reference-equivalent CPU path on the host cores, bounded sample of the same workload; its fp32
+    features then go through the oracle's pinned matching arithmetic (reference tie order) and are compared index for
+    index with what the GPU produced for the same detections."""
+    from foundpose_amd import synthetic, workload
     from oracle import baseline
     # torch-CPU on ViT-sized matrices stops scaling (and regresses) far below the 256 hardware threads of the
     # GPU box's host; 32 threads is what the reference's own defaults would be tuned to on such a machine.
     cores = min(os.cpu_count() or 1, int(os.environ.get("FP_CPU_BASELINE_THREADS", "32")))
     torch.set_num_threads(cores)
     sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    repre = wl.repres[wl.det_obj[0]]
     proj = repre.feat_raw_projectors[0]
-    bank = {
+    cpu_bank = {
         "feat_vectors": repre.feat_vectors.cpu(), "feat_to_template_ids": repre.feat_to_template_ids.cpu(),
         "feat_cluster_centroids": repre.feat_cluster_centroids.cpu(), "feat_cluster_idfs": repre.feat_cluster_idfs.cpu(),
         "template_descs": repre.template_descs.cpu(), "pca_components": proj.components.cpu(), "pca_mean": proj.mean.cpu(),
     }
-    n = args.cpu_detections
-    imgs, msk = images[:n].cpu(), masks[:n].cpu()
+    n = min(args.cpu_detections, sum(1 for o in wl.det_obj if o == wl.det_obj[0]))
+    imgs, msk = wl.crops[:n].cpu(), wl.masks[:n].cpu()
     tw = time.perf_counter()
-    baseline.run_detection(sd, arch, args.layer, imgs[0], msk[0], bank)  # warm-up (thread pools, page-in)
+    baseline.run_detection(sd, arch, args.layer, imgs[0], msk[0], cpu_bank)  # warm-up (thread pools, page-in)
     if time.perf_counter() - tw > 15.0:
         n = 1  # keep the default bench run within a few minutes on slow hosts
     t0 = time.perf_counter()
-    stages = {}
+    stages, feats = {}, []
     for i in range(n):
-        t, _ = baseline.run_detection(sd, arch, args.layer, imgs[i], msk[i], bank)
+        t, _, qpf = baseline.run_detection(sd, arch, args.layer, imgs[i], msk[i], cpu_bank, return_features=True)
+        feats.append(qpf)
         for k, v in t.items():
             stages[k] = stages.get(k, 0.0) + v / n
     dt = time.perf_counter() - t0
-    return {"value": round(n / dt, 4), "unit": "detections/s", "cores": cores, "kind": "port",
+    base = {"value": round(n / dt, 4), "unit": "detections/s", "cores": cores, "kind": "port",
             "sample": f"{n} detection(s) after 1 warm-up, batch of one, fp32 torch-CPU on {cores} threads, all {arch.depth} blocks run like the reference",
             "s_per_stage": {k: round(v, 4) for k, v in stages.items()}}
+    # ---- oracle A on those detections: same fp32 features -> pinned matching arithmetic, the reference's tie order
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.bincount(cpu_bank["feat_to_template_ids"].long(), minlength=repre.template_descs.shape[0]), 0)])
+    small = {"feat_cluster_centroids": cpu_bank["feat_cluster_centroids"].numpy(), "feat_cluster_idfs": cpu_bank["feat_cluster_idfs"].numpy(),
+             "template_descs": cpu_bank["template_descs"].numpy(), "template_desc_opts": repre.template_desc_opts._asdict()}
+    fetch = lambda tid: (cpu_bank["feat_vectors"][int(off[tid]):int(off[tid + 1])].numpy(), int(off[tid]))
+    ora = [baseline.exact_matching(qp.numpy(), qf.numpy(), small, fetch, 5, 300, "torch" if args.tie_order == "torch" else "canonical") for qp, qf in feats]
+    par = workload.parity_stats(gpu_lists[:n], ora)
+    par["oracle"] = f"oracle A: fp32 CPU features of {n} detection(s) through oracle/match.py (pinned to the reference fixtures), tie order '{args.tie_order}'"
+    return base, par
 
 
 if __name__ == "__main__":

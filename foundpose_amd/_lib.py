@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
@@ -91,6 +91,11 @@ def lib() -> C.CDLL:
             raise FoundPoseNativeError("libfoundpose_amd.so ABI version mismatch; rebuild")
         _lib = handle
     return _lib
+
+
+def cosine_scratch_floats(num_det: int, max_templates: int) -> int:
+    """FP_COSINE_SCRATCH_FLOATS of include/foundpose_amd.h."""
+    return 2 * num_det * max_templates + 16 * num_det + 2
 
 
 def exported_symbols():

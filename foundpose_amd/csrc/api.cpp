@@ -94,25 +94,24 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
   FP_REQUIRE(num_obj >= 1 && max_templates >= 1 && n_top >= 1, "fp_cosine_topk: bad sizes");
   if (num_det == 0) return FP_OK;
   FP_REQUIRE(tie_mode == 0 || tie_mode == 1, "fp_cosine_topk: tie_mode must be 0 (canonical) or 1 (torch)");
-  if (num_words % 16 == 0 && max_det_per_obj <= 64 && (n_top <= 8 || tie_mode == 1)) {  // bank-streaming path (HBM-bound)
+  if (num_words % 16 == 0) {
+    // one arithmetic (8 k-slice chains when num_words % 128 == 0) whatever the batch: a score never depends on how many
+    // detections share the launch; > 32 detections of an object are served in 32-detection chunks by the same kernel
     CosineArgs c;
+    memset(&c, 0, sizeof(c));
     c.desc_n = desc_n; c.bank_n = bank_n; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
     c.sims = scratch_sims; c.ld_sims = max_templates;
-    c.k_slices = (num_words % 128 == 0) ? 8 : 1;  // canonical chain split, see include/foundpose_amd.h
-    c.slice_stride = (long long)num_det * max_templates;
+    c.cand = reinterpret_cast<unsigned long long*>(scratch_sims + (size_t)num_det * max_templates + ((size_t)num_det * max_templates & 1));
     return launch_cosine_topk(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores,
                               out_ids, tie_mode, ST(stream));
   }
-  // generic tile path (k-ascending chains): odd descriptor sizes or very large groups
+  // descriptor sizes that are not a multiple of 16 words: generic fp32 tile, k-ascending chains
   F32TileArgs a = zero_tile_args();
   a.A = desc_n; a.lda = num_words; a.B = bank_n; a.ldb = num_words; a.K = num_words;
   a.a_seg_off = det_seg_off; a.b_seg_off = obj_tpl_off;
   a.out = scratch_sims; a.ldo = max_templates; a.out_row_global = 1;
   TRY(f32_tile_launch(F32_EPI_STORE, a, max_det_per_obj, max_templates, num_obj, ST(stream)));
-  if (tie_mode == 1)
-    return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, 1, 1, 0, nullptr, ST(stream));
-  return launch_topk_rows(scratch_sims, num_det, max_templates, max_templates, det_num_templates, n_top, 1,
-                          out_scores, out_ids, ST(stream));
+  return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, ST(stream));
 }
 
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
@@ -207,9 +206,26 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
   a.tile_override = tile;
-  a.dbg = reinterpret_cast<unsigned long long*>(getenv("FP_GEMM_DBG_PTR") ? strtoull(getenv("FP_GEMM_DBG_PTR"), nullptr, 0) : 0ull);
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }
+
+#ifdef FP_GEMM_TIMELINE
+// Measurement build only (tools/build_variant.sh -DFP_GEMM_TIMELINE, tools/gemm_timeline.py): the same GEMM writing four
+// shader-clock stamps per workgroup into a caller-owned buffer of dbg_len >= 4 * grid u64 slots.
+int fp_gemm_bf16_timeline(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                          const float* gamma, void* out, int ldo, int epilogue, unsigned long long* dbg, int64_t dbg_len,
+                          fp_stream_t stream) {
+  FP_REQUIRE(A && W && out && dbg, "fp_gemm_bf16_timeline: null pointer");
+  FP_REQUIRE(dbg_len >= 4ll * ((M + 127) / 128) * ((N + 127) / 128) * 2, "fp_gemm_bf16_timeline: stamp buffer too small");
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
+  a.tile_override = (epilogue >> 8) & 0xfff;
+  a.dbg = dbg;
+  return gemm_bf16_launch(epilogue & 0xff, a, ST(stream));
+}
+#endif
 
 int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                 const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream) {

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -90,3 +92,36 @@ FP_DEVICE unsigned xcd_remap(unsigned bid, unsigned nwg) {
 }
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// ---- per-device launch-time caches.  hipFuncSetAttribute(MaxDynamicSharedMemorySize) and the CU count are properties
+// of a (kernel, device) pair: the flag is kept per device id, so a process that drives several GPUs sets the attribute
+// on each of them.  The cached values are idempotent (two host threads racing on a flag both set the same attribute),
+// which is the only mutable state the library keeps.
+constexpr int FP_MAX_DEVICES = 64;
+struct FpDeviceOnce {
+  std::atomic<unsigned char> done[FP_MAX_DEVICES];
+};
+// true when `o` has not been marked on the calling thread's current device yet (always true for device ids past the table)
+static inline bool fp_first_on_device(FpDeviceOnce& o) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FP_MAX_DEVICES) return true;
+  if (o.done[dev].load(std::memory_order_acquire)) return false;
+  o.done[dev].store(1, std::memory_order_release);
+  return true;
+}
+// raise a kernel's dynamic-LDS limit once per device
+template <class K>
+static inline void fp_allow_dynamic_lds(FpDeviceOnce& o, K kernel, int bytes) {
+  if (fp_first_on_device(o)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+// compute units of the current device (cached per device)
+static inline int fp_num_cus() {
+  static std::atomic<int> cus[FP_MAX_DEVICES];
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= FP_MAX_DEVICES) return 256;
+  n = cus[dev].load(std::memory_order_relaxed);
+  if (n > 0) return n;
+  if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  cus[dev].store(n, std::memory_order_relaxed);
+  return n;
+}

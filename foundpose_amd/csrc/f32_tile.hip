@@ -231,11 +231,8 @@ template <int EPI>
 int launch(const F32TileArgs& a, int max_m, int max_n, int pairs, hipStream_t st) {
   dim3 grid(cdiv(max_n, BN), cdiv(max_m, BM), pairs);
   size_t lds = 4 * STAGE_FLOATS * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&f32_tile_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr_set = true;
-  }
+  static FpDeviceOnce attr;
+  fp_allow_dynamic_lds(attr, &f32_tile_kernel<EPI>, (int)lds);
   hipLaunchKernelGGL(f32_tile_kernel<EPI>, grid, dim3(256), lds, st, a);
   FP_CHECK_LAUNCH("f32_tile_kernel");
   return FP_OK;

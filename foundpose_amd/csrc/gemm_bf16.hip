@@ -122,8 +122,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   }
   const int kb = 0, ke = a.K / BK;
 
+#ifdef FP_GEMM_TIMELINE  // tools/build_variant.sh -DFP_GEMM_TIMELINE: per-workgroup shader-clock stamps (never in the shipped library)
   unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
   if (a.dbg) ts0 = __builtin_readcyclecounter();
+#endif
   {
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -161,7 +163,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         const int cur = (t - kb) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t have landed
         __syncthreads();                                  // ... everyone's have; the other stage has no readers left
+#ifdef FP_GEMM_TIMELINE
         if (a.dbg && t == 0) ts1 = __builtin_readcyclecounter();
+#endif
         char* nxt = smem + (cur ^ 1) * STAGE;
         const bool more = t + 1 < ke;
         const char* As = smem + cur * STAGE;
@@ -213,7 +217,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         }
       __syncthreads();
     }
+#ifdef FP_GEMM_TIMELINE
     if (a.dbg) ts2 = __builtin_readcyclecounter();
+#endif
 
     // ---- epilogue: acc[tm][tn][r] = C[m][n],  m = m0 + wm*(BM/WM) + tm*32 + (lane&31),
     //      n = n0 + wn*(BN/WN) + tn*32 + 8*(r>>2) + 4*(lane>>5) + (r&3)
@@ -394,6 +400,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         }
     }
     }
+#ifdef FP_GEMM_TIMELINE
     if (a.dbg) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       const unsigned long long ts3 = __builtin_readcyclecounter();
@@ -402,6 +409,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = ts3;
       }
     }
+#endif
   }
 }
 
@@ -421,12 +429,8 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
     grid = ((a.M / BM + 7) / 8) * ((a.N / BN) / 4) * 32;
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    attr = true;
-  }
+  static FpDeviceOnce attr;
+  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>, (int)lds);
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;

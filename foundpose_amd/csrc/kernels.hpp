@@ -145,10 +145,12 @@ struct CosineArgs {
   const int* det_seg_off;  // [num_obj + 1]
   const int* obj_tpl_off;  // [num_obj + 1]
   int W;
-  float* sims; int ld_sims;  // [k_slices][num_det, ld_sims]; slice 0 holds the finished scores afterwards
-  int k_slices; long long slice_stride;
+  float* sims; int ld_sims;  // [num_det, ld_sims] finished scores
+  int k_slices;              // set by the launcher: 8 when W % 128 == 0, else 1 (canonical chain split)
+  unsigned long long* cand;  // [num_det, grid.x, n_top] candidate keys of the fused kernel (null: not wanted)
+  int n_top;
 };
 int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
-int launch_topn_rows(float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
-                     int* out_ids, int tie_mode, int k_slices, long long slice_stride, unsigned long long* cand_scratch, hipStream_t st);
+int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
+                     int* out_ids, int tie_mode, hipStream_t st);

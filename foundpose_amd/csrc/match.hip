@@ -86,146 +86,124 @@ __global__ void topk_rows_kernel(const float* __restrict__ vals, int rows, int n
   }
 }
 
-// ------------------------------------------------------------------ template retrieval: bank-streaming cosine scores
-// sims[det][t] = <bank_n[t,:], q_n[det,:]> for every template t of the detection's object.
-// HBM-bound by design: each wave owns 16 template rows and streams them ONCE, straight from HBM into registers
-// (16 B per lane, no LDS: the rows are not shared between waves), against all <= 64 detections of the object
-// (query rows come from L2).  v_mfma_f32_16x16x4_f32: A = 16 templates x 4 k, B = 4 k x 16 detections.
-// A lane's float4 covers k = 16j + 4g .. +3 (g = lane>>4), so MFMA step u consumes k = 16j + 4g' + u, g' = 0..3:
-// the per-(template, detection) fp32 fma chain visits each 16-block of k in the order
-// [0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15] -- the canonical order of this stage (oracle: orc_dot_rows_perm16).
-// A-operand (bank) loads of one chunk of U 16-blocks: 16 B per lane, non-temporal (streamed once).
-template <int U>
-FP_DEVICE void cos_load_a(f32x4 (&av)[U], const float* ap, int chunk) {
-#pragma unroll
-  for (int u = 0; u < U; ++u) av[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(ap + 16 * (chunk * U + u)));
-}
-// MFMAs of one chunk; the query fragments come from the LDS slice image (ds_read_b128, conflict-free: row pitch 1040 B).
-// Accumulators alternate between consecutive MFMAs (dependent latency of 16x16x4 f32 > its issue interval).
-template <int NQ, int U>
-FP_DEVICE void cos_mma(f32x4 (&acc)[NQ], const f32x4 (&av)[U], const char* qs, int chunk, int pitch) {
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    float4 bv[NQ];
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) bv[q] = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + (chunk * U + u) * 64);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[q].x, acc[q], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[q].y, acc[q], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[q].z, acc[q], 0, 0, 0);
-#pragma unroll
-    for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[q].w, acc[q], 0, 0, 0);
-  }
-}
+// ------------------------------------------------------------------ template retrieval: cosine scores
+// sims[det][t] = <bank_n[t,:], q_n[det,:]> for every template t of the detection's object, + top-n.
+// v_mfma_f32_16x16x4_f32: A = 16 templates x 4 k, B = 4 k x 16 detections.  A lane's float4 covers
+// k = 16j + 4g .. +3 (g = lane>>4), so MFMA step u consumes k = 16j + 4g' + u, g' = 0..3: the per-(template, detection)
+// fp32 fma chain visits each 16-block of k in the order [0,4,8,12, 1,5,9,13, 2,6,10,14, 3,7,11,15].  K is cut into
+// a.k_slices contiguous slices, each slice is one such chain starting from zero, and the slice sums are added in slice
+// order: the canonical order of this stage (oracle: orc_dot_rows_perm16).  Both kernels below produce exactly that
+// chain, so a score does not depend on which kernel ran or on how many detections share the launch.
 
+// Generic shapes (any num_words % 16 == 0): 4 waves x 16 templates per workgroup, bank rows register-direct (16 B per
+// lane), the query slice restaged in LDS for every k-slice.  Not tuned -- production shapes take cosine_fused_kernel.
 template <int NQ>
-__global__ __launch_bounds__(256) void cosine_sims_kernel(CosineArgs a) {
+__global__ __launch_bounds__(256) void cosine_generic_kernel(CosineArgs a) {
   extern __shared__ __attribute__((aligned(16))) char qlds[];  // [NQ*16 detections][wslice floats + 16 B pad]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int obj = blockIdx.y;
   const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
-  const int d0 = a.det_seg_off[obj], nd = a.det_seg_off[obj + 1] - d0;
+  const int d0 = a.det_seg_off[obj] + blockIdx.z * (NQ * 16);
+  const int nd = min(NQ * 16, a.det_seg_off[obj + 1] - d0);
   if (blockIdx.x * 64 >= T || nd <= 0) return;  // block-uniform
-  // K is cut into a.k_slices contiguous slices (blockIdx.z): more waves than SIMDs, so the fp32 matrix pipe of
-  // every SIMD works on the stream; the slice chains are summed in slice order by the top-n kernel.
-  const int kslice = blockIdx.z, wslice = a.W / a.k_slices;
-  const int pitch = wslice * 4 + 16;
-  // ---- the object's query descriptors (this k-slice) go to LDS once per block, as whole rows (1 KiB per wave
-  // instruction at wslice = 256): per-wave register loads of them cost 2/3 of the kernel's load instructions and the
-  // address path, not HBM, became the limit (profiles/r1_pmc_counters.txt)
-  for (int r = wave; r < NQ * 16; r += 4) {
-    const float* src = a.desc_n + (size_t)(d0 + min(r, nd - 1)) * a.W + kslice * wslice;
-    for (int c = lane * 4; c < wslice; c += 256)
-      *reinterpret_cast<float4*>(qlds + r * pitch + c * 4) = *reinterpret_cast<const float4*>(src + c);
-  }
+  const int wslice = a.W / a.k_slices, pitch = wslice * 4 + 16;
   const int t0 = (blockIdx.x * 4 + wave) * 16;
   const int i = lane & 15, g = lane >> 4;
   const int trow = min(t0 + i, T - 1);
-  const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + kslice * wslice + 4 * g;
   const char* qs = qlds + i * pitch + g * 16;
-  f32x4 acc[NQ];
+  f32x4 tot[NQ];
+  for (int sl = 0; sl < a.k_slices; ++sl) {
+    __syncthreads();  // the previous slice has no readers left
+    for (int r = wave; r < NQ * 16; r += 4) {
+      const float* src = a.desc_n + (size_t)(d0 + min(r, nd - 1)) * a.W + sl * wslice;
+      for (int c = lane * 4; c < wslice; c += 256)
+        *reinterpret_cast<float4*>(qlds + r * pitch + c * 4) = *reinterpret_cast<const float4*>(src + c);
+    }
+    __syncthreads();
+    const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + sl * wslice + 4 * g;
+    f32x4 acc[NQ];
 #pragma unroll
-  for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const int nb = wslice / 16;
-  // Software pipeline: chunks of U 16-blocks; chunk c+1's bank loads are in flight while chunk c's MFMAs run
-  // (a wave keeps 2 x U KiB of the bank stream outstanding -- what it takes to pull HBM bandwidth without LDS).
-  constexpr int U = 8;
-  f32x4 a0[U], a1[U];
-  const int nch = nb / U;
-  const bool active = t0 < T;
-  if (active && nch > 0) cos_load_a<U>(a0, ap, 0);
-  __syncthreads();  // query slice staged
-  if (!active) return;
-  for (int c = 0; c < nch; c += 2) {
-    if (c + 1 < nch) cos_load_a<U>(a1, ap, c + 1);
-    cos_mma<NQ, U>(acc, a0, qs, c, pitch);
-    if (c + 2 < nch) cos_load_a<U>(a0, ap, c + 2);
-    if (c + 1 < nch) cos_mma<NQ, U>(acc, a1, qs, c + 1, pitch);
-  }
-  for (int j = nch * U; j < nb; ++j) {  // remainder blocks (slice not a multiple of 128 floats)
-    const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+    for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < wslice / 16; ++j) {
+      const f32x4 av = *reinterpret_cast<const f32x4*>(ap + 16 * j);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const float4 bv = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + j * 64);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv.x, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv.y, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv.z, acc[q], 0, 0, 0);
+        acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv.w, acc[q], 0, 0, 0);
+      }
+    }
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const float4 bv = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + j * 64);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[0], bv.x, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[1], bv.y, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[2], bv.z, acc[q], 0, 0, 0);
-      acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[3], bv.w, acc[q], 0, 0, 0);
+      if (sl == 0) tot[q] = acc[q];
+      else tot[q] += acc[q];  // slice sums added in slice order
     }
   }
   // D[i = template 4g + r][j = detection lane&15]
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int det = q * 16 + i;
-    if (det >= nd) continue;
-    float* o = a.sims + (size_t)kslice * a.slice_stride + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
+    if (det >= nd || t0 >= T) continue;
+    float* o = a.sims + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (t0 + 4 * g + r < T) o[r] = acc[q][r];
+      if (t0 + 4 * g + r < T) o[r] = tot[q][r];
   }
 }
 
-// Same arithmetic, bank rows staged through LDS by DMA.  The register-direct kernel above reads 16 B per lane from 16
-// different template rows per load instruction (the MFMA operand layout): 64 B-per-row accesses cost the address path
-// four times what whole rows cost, and that -- not HBM -- bounded it at ~2.5 TB/s.  Here one persistent 8-wave
-// workgroup per CU serves one (object, k-slice); each wave streams its 16-template blocks as 4-KiB chunks (16 rows x
-// 256 B, fetched as whole 256-B row segments by four global_load_lds) through a private three-slot LDS ring: two
-// chunks (8 KiB per wave, 64 KiB per CU) are always in flight under the MFMAs of the third, waits are counted vmcnt,
-// and no barrier is needed because a wave only reads what it fetched itself.  The 16-B pieces of a row are XOR-placed
-// by the row index (on the DMA source address) so the per-lane fragment reads hit 16 different bank groups.
-// Fragment contents and MFMA order are those of cosine_sims_kernel: bit-identical scores.
+// Production shape (num_words = 8 slices of 64..256 words): HBM-bound by design, one pass over the bank, no partial
+// scores in memory.  One persistent 8-wave workgroup per CU; wave s owns k-slice s.  The <= 32 query descriptors of the
+// launch live in REGISTERS (a wave holds its slice of all of them as MFMA B fragments: 128 VGPRs at 256 words x 32
+// detections) -- LDS could hold only one slice of them, which is why the earlier version cut K across workgroups, wrote
+// [8, B, T] partial scores and re-read them across XCDs in a second and third kernel.  The workgroup walks the object's
+// 16-template blocks; the eight waves stream the same 16 rows (128 KiB contiguous per block), each its own 1-KiB
+// segment of every row as 4-KiB chunks (16 rows x 256 B, whole row segments fetched by four global_load_lds, 16-B
+// pieces XOR-placed by row so the fragment reads are conflict-free) through a private three-slot LDS ring with counted
+// vmcnt waits; a landed chunk moves to registers at once so all three slots stay in flight (96 KiB per CU).  After a
+// block's chunks the eight slice sums meet in LDS (one barrier per 128 KiB of bank), thread (detection, template) adds
+// them in slice order, stores the finished score and keeps the best n_top it has seen as sorted (score, id) keys; at
+// the end the 16 lanes of a detection merge their lists and the workgroup emits n_top candidate keys per detection.
 typedef __attribute__((address_space(3))) void cos_lds_void;
 typedef __attribute__((address_space(1))) const void cos_gbl_cvoid;
+constexpr int COS_NMAX = 8;          // candidates kept per thread / emitted per (workgroup, detection)
+constexpr int COS_RED_PITCH = 68;    // floats per 16-lane group of a wave's score tile (64 + 4: de-phases the groups across banks)
 
 template <int NQ>
-__global__ __launch_bounds__(1024) void cosine_stream_kernel(CosineArgs a) {
-  extern __shared__ __attribute__((aligned(16))) char qlds[];  // [NQ*16 detections][wslice floats + 16 B] | [waves][3][4 KiB]
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+__global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [8 waves][3][4 KiB] ring | red[2][8 slices][NQ][4][68] floats
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int obj = blockIdx.y;
   const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
-  const int d0 = a.det_seg_off[obj], nd = a.det_seg_off[obj + 1] - d0;
-  if (T <= 0 || nd <= 0) return;  // block-uniform
-  const int kslice = blockIdx.z, wslice = a.W / a.k_slices;
-  const int pitch = wslice * 4 + 16;
-  const int nwave = blockDim.x >> 6;
-  for (int r = wave; r < NQ * 16; r += nwave) {
-    const float* src = a.desc_n + (size_t)(d0 + min(r, nd - 1)) * a.W + kslice * wslice;
-    for (int c = lane * 4; c < wslice; c += 256)
-      *reinterpret_cast<float4*>(qlds + r * pitch + c * 4) = *reinterpret_cast<const float4*>(src + c);
-  }
-  char* ring = qlds + NQ * 16 * pitch + wave * (3 * 4096);
-  const int nblk = (T + 15) >> 4, nch = wslice >> 6;         // 16-template blocks of the object, 64-word chunks per block
-  const int first = blockIdx.x * nwave + wave, stride = gridDim.x * nwave;
+  const int d0 = a.det_seg_off[obj] + blockIdx.z * (NQ * 16);
+  const int nd = min(NQ * 16, a.det_seg_off[obj + 1] - d0);
+  if (nd <= 0) return;  // block-uniform: no detection rows, nothing to emit
+  const int wslice = a.W >> 3, nch = wslice >> 6;  // 64-word chunks per slice (1..4)
+  const int i = lane & 15, g = lane >> 4;
+  char* ring = smem + wave * (3 * 4096);
+  float* red = reinterpret_cast<float*>(smem + 8 * 3 * 4096);
+  constexpr int RED_SLICE = NQ * 4 * COS_RED_PITCH;  // floats per (buffer, slice)
+
+  const int nblk = (T + 15) >> 4;
+  const int first = blockIdx.x, stride = gridDim.x;
   const int ntask = first < nblk ? (nblk - first + stride - 1) / stride : 0;
   const int total = ntask * nch;
-  __syncthreads();  // query slice staged (the only barrier)
-  if (total == 0) return;
 
-  const int i = lane & 15, g = lane >> 4;
-  const float* slice_base = a.bank_n + (size_t)tb * a.W + kslice * wslice;
-  // issue side: (task, chunk) cursor of the next chunk to fetch
+  // ---- this wave's slice of the query descriptors -> registers, in MFMA B-fragment order
+  float4 qv[16][NQ];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        qv[c * 4 + j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < nch && total > 0)
+          qv[c * 4 + j][q] = *reinterpret_cast<const float4*>(a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + wave * wslice + (c * 4 + j) * 16 + g * 4);
+      }
+
+  const float* slice_base = a.bank_n + (size_t)tb * a.W + wave * wslice;
   int it_blk = first, it_ch = 0, it_slot = 0;
   auto issue = [&]() {
     const int t0 = it_blk * 16;
@@ -239,93 +217,154 @@ __global__ __launch_bounds__(1024) void cosine_stream_kernel(CosineArgs a) {
     if (++it_ch == nch) { it_ch = 0; it_blk += stride; }
     it_slot = it_slot == 2 ? 0 : it_slot + 1;
   };
-  issue();
+  if (total > 0) issue();
   if (total > 1) issue();
   if (total > 2) issue();
+
+  // reduce-phase role of this thread: detection rd (of the launch's NQ*16), template rt of the block
+  const int rd = tid >> 4, rt = tid & 15;
+  const bool reducer = rd < NQ * 16;
+  const int red_off = (rd >> 4) * (4 * COS_RED_PITCH) + (rt >> 2) * COS_RED_PITCH + (rd & 15) * 4 + (rt & 3);
+  unsigned long long best[COS_NMAX];
+#pragma unroll
+  for (int s = 0; s < COS_NMAX; ++s) best[s] = ~0ull;
 
   f32x4 acc[NQ];
 #pragma unroll
   for (int q = 0; q < NQ; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const char* qs = qlds + i * pitch + g * 16;
-  int blk = first, ch = 0, slot = 0;
-  for (int cc = 0; cc < total; ++cc) {
-    // loads return in order: chunk cc has landed once at most the later chunks' DMAs are outstanding
-    if (cc + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (cc + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    // the chunk moves to registers at once, so its slot can be refilled now: all three ring slots (12 KiB per wave,
-    // 96 KiB per CU) are in flight while the MFMAs below run
-    const char* cs = ring + slot * 4096 + i * 256;
-    f32x4 av[4];
-    float4 bv[4][NQ];
+  int blk = first, slot = 0, buf = 0;
+  for (int task = 0; task < ntask; ++task) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(cs + (((4 * j + g) ^ i) << 4));
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch < nch) {
+        const int cc = task * nch + ch;
+        // loads return in order: chunk cc has landed once at most the later chunks' DMAs are outstanding
+        if (cc + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (cc + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const char* cs = ring + slot * 4096 + i * 256;
+        f32x4 av[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(cs + (((4 * j + g) ^ i) << 4));
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the slot is handed back
+        if (cc + 3 < total) issue();
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) bv[j][q] = *reinterpret_cast<const float4*>(qs + q * 16 * pitch + (ch * 4 + j) * 64);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the slot is handed back
-    if (cc + 3 < total) issue();
+        for (int j = 0; j < 4; ++j) {  // two alternating accumulator chains (NQ = 2)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {  // 32 (NQ = 2) back-to-back MFMAs, two alternating accumulator chains
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], qv[ch * 4 + j][q].x, acc[q], 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][0], bv[j][q].x, acc[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], qv[ch * 4 + j][q].y, acc[q], 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][1], bv[j][q].y, acc[q], 0, 0, 0);
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], qv[ch * 4 + j][q].z, acc[q], 0, 0, 0);
 #pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][2], bv[j][q].z, acc[q], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], bv[j][q].w, acc[q], 0, 0, 0);
-    }
-    slot = slot == 2 ? 0 : slot + 1;
-    if (++ch == nch) {
-      // D[i = template 4g + r][j = detection lane&15]
-      const int t0 = blk * 16;
-#pragma unroll
-      for (int q = 0; q < NQ; ++q) {
-        const int det = q * 16 + i;
-        if (det < nd) {
-          // a lane holds 4 consecutive templates of one detection: one 16-B store when the row pitch allows it
-          float* o = a.sims + (size_t)kslice * a.slice_stride + (size_t)(d0 + det) * a.ld_sims + t0 + 4 * g;
-          if (t0 + 16 <= T && (a.ld_sims & 3) == 0) {
-            *reinterpret_cast<f32x4*>(o) = acc[q];
-          } else {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (t0 + 4 * g + r < T) o[r] = acc[q][r];
-          }
+          for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], qv[ch * 4 + j][q].w, acc[q], 0, 0, 0);
         }
-        acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        slot = slot == 2 ? 0 : slot + 1;
       }
-      ch = 0;
-      blk += stride;
+    }
+    // ---- the block's eight slice sums meet in LDS: D[template 4g + r][detection q*16 + i] of this wave's slice
+    float* mine = red + (buf * 8 + wave) * RED_SLICE;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      *reinterpret_cast<f32x4*>(mine + q * (4 * COS_RED_PITCH) + g * COS_RED_PITCH + i * 4) = acc[q];
+      acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();  // (also orders this buffer's readers of two blocks ago before its next writers)
+    if (reducer) {
+      const float* rp = red + buf * 8 * RED_SLICE + red_off;
+      float v = rp[0];
+#pragma unroll
+      for (int sl = 1; sl < 8; ++sl) v += rp[sl * RED_SLICE];  // slice sums added in slice order
+      const int t = blk * 16 + rt;
+      if (t < T && rd < nd) {
+        a.sims[(size_t)(d0 + rd) * a.ld_sims + t] = v;
+        unsigned long long key = ((unsigned long long)order_key(v, true) << 32) | (unsigned)t;
+#pragma unroll
+        for (int s = 0; s < COS_NMAX; ++s) {  // sorted insertion (ascending keys = best first)
+          const unsigned long long lo = key < best[s] ? key : best[s];
+          key = key < best[s] ? best[s] : key;
+          best[s] = lo;
+        }
+      }
+    }
+    buf ^= 1;
+    blk += stride;
+  }
+  // ---- the 16 lanes of a detection merge their lists: n_top candidate keys per (workgroup, detection)
+  if (reducer && a.cand) {
+    for (int s = 0; s < a.n_top; ++s) {
+      unsigned long long m = best[0];
+#pragma unroll
+      for (int o = 8; o > 0; o >>= 1) {
+        const unsigned long long t = __shfl_xor(m, o, 16);
+        m = t < m ? t : m;
+      }
+      if (m != ~0ull && best[0] == m) {  // exactly one lane owns the winner (keys carry the unique template id)
+#pragma unroll
+        for (int t = 0; t + 1 < COS_NMAX; ++t) best[t] = best[t + 1];
+        best[COS_NMAX - 1] = ~0ull;
+      }
+      if (rt == 0 && rd < nd) a.cand[((size_t)(d0 + rd) * gridDim.x + blockIdx.x) * a.n_top + s] = m;
     }
   }
 }
 
-// Canonical top-n of each row (largest first, ties -> lowest index), one 256-thread block per row:
-// per-thread top-n over a strided slice (registers), then n rounds of block-wide arg-best over the candidates.
+// Canonical top-n of each row from the candidate keys of cosine_fused_kernel: one wave per detection, per-lane sorted
+// lists over a strided share of the ncand keys, then n rounds of wave-wide arg-best.  The score travels inside the key.
+__global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
+                                                         float* __restrict__ out_val, int* __restrict__ out_idx) {
+  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const unsigned long long* c = cand + (size_t)row * ncand;
+  unsigned long long best[COS_NMAX];
+#pragma unroll
+  for (int s = 0; s < COS_NMAX; ++s) best[s] = ~0ull;
+  for (int j0 = lane; j0 < ncand; j0 += 256) {
+    unsigned long long k[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) k[e] = j0 + 64 * e < ncand ? c[j0 + 64 * e] : ~0ull;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      unsigned long long key = k[e];
+#pragma unroll
+      for (int s = 0; s < COS_NMAX; ++s) {
+        const unsigned long long lo = key < best[s] ? key : best[s];
+        key = key < best[s] ? best[s] : key;
+        best[s] = lo;
+      }
+    }
+  }
+  for (int s = 0; s < n_top; ++s) {
+    const unsigned long long b = wave_min_u64(best[0]);
+    if (b == ~0ull) {
+      if (lane == 0) { out_idx[(size_t)row * n_top + s] = -1; out_val[(size_t)row * n_top + s] = -INFINITY; }
+    } else if (best[0] == b) {
+      const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits
+      out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
+      out_val[(size_t)row * n_top + s] = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+#pragma unroll
+      for (int t = 0; t + 1 < COS_NMAX; ++t) best[t] = best[t + 1];
+      best[COS_NMAX - 1] = ~0ull;
+    }
+  }
+}
+
+// Canonical top-n of each row (largest first, ties -> lowest index) straight from the scores, one 256-thread block per
+// row: per-thread top-n over a strided slice (registers), then n rounds of block-wide arg-best over the candidates.
 template <int NMAX>
-__global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                              int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
-                                                              int k_slices, long long slice_stride, unsigned long long* __restrict__ cand_out) {
+__global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                              int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
   __shared__ unsigned long long cand[256 * NMAX];
   __shared__ unsigned long long wbest[4];
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = row_len ? row_len[row] : n_default;
-  float* r = vals + (size_t)row * ld;
-  // gridDim.y > 1: this block scans one contiguous split of the row and emits its n_top best keys (phase A);
-  // a merge launch (gridDim.y == 1 over the candidate keys) finishes the row.
-  const int nsplit = gridDim.y, split = blockIdx.y;
-  const int per = (len + nsplit - 1) / nsplit;
-  const int j_begin = split * per, j_end = min(len, j_begin + per);
+  const float* r = vals + (size_t)row * ld;
   unsigned long long best[NMAX];
 #pragma unroll
   for (int s = 0; s < NMAX; ++s) best[s] = ~0ull;
-  for (int j = j_begin + tid; j < j_end; j += 256) {
-    float v = r[j];
-    for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];  // slice chains added in slice order
-    unsigned long long key = ((unsigned long long)order_key(v, true) << 32) | (unsigned)j;
+  for (int j = tid; j < len; j += 256) {
+    unsigned long long key = ((unsigned long long)order_key(r[j], true) << 32) | (unsigned)j;
 #pragma unroll
     for (int s = 0; s < NMAX; ++s) {  // sorted insertion (ascending keys = best first)
       const unsigned long long lo = key < best[s] ? key : best[s];
@@ -349,23 +388,11 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict_
     b = wbest[0];
 #pragma unroll
     for (int w = 1; w < 4; ++w) b = wbest[w] < b ? wbest[w] : b;
-    if (tid == 0 && cand_out) {  // phase A of the split top-n: key + finished score of this split's s-th best
-      const size_t slot = ((size_t)row * nsplit + split) * n_top + s;
-      cand_out[slot] = b;
-      float v = -INFINITY;
+    if (tid == 0) {
       if (b != ~0ull) {
         const int j = (int)(b & 0xffffffffu);
-        v = r[j];
-        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
-      }
-      reinterpret_cast<float*>(cand_out + (size_t)gridDim.x * nsplit * n_top)[slot] = v;
-    } else if (tid == 0) {
-      if (b != ~0ull) {
-        const int j = (int)(b & 0xffffffffu);
-        float v = r[j];
-        for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
         out_idx[(size_t)row * n_top + s] = j;
-        out_val[(size_t)row * n_top + s] = v;
+        out_val[(size_t)row * n_top + s] = r[j];
       } else {
         out_idx[(size_t)row * n_top + s] = -1;
         out_val[(size_t)row * n_top + s] = -INFINITY;
@@ -376,110 +403,97 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(float* __restrict_
   }
 }
 
-// Phase A of the split top-n, one WAVE per (row, split): per-lane sorted top-n over a contiguous split (slice chains
-// summed in slice order), then n rounds of wave-wide arg-best over the lanes' heads -- registers and lane shuffles only
-// (the block-wide version above spent its time in 5 x (LDS scan + barrier) rounds).
-template <int NMAX>
-__global__ __launch_bounds__(256) void topn_rows_wave_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                             int n_default, int n_top, int k_slices, long long slice_stride, int nsplit,
-                                                             int rows, unsigned long long* __restrict__ cand_out) {
-  const int row = blockIdx.x, lane = threadIdx.x & 63, split = blockIdx.y * 4 + (threadIdx.x >> 6);
-  if (split >= nsplit) return;
+// Strict-order top-n: the reference's torch.topk(scores, n) on a CPU tensor, ties included (stl_order.hpp), one block per
+// row, rows of any length.  ATen runs std::partial_sort when n*64 <= len: a heap of the n best seen so far, and an
+// element only acts when it beats the heap's root -- a handful of times in a row of thousands.  One wave replays it 256
+// elements at a step: the row is staged through LDS in segments, 64 lanes test four 64-element chunks against the
+// current root at once, and only the (rare) hits go through the sequential pop_heap, in index order, the root re-read
+// after each.  Element moves inside the heap are libstdc++'s, so the surviving order among ties is too.  Short rows
+// (n*64 > len) take nth_element + sort on one lane, as ATen does.
+constexpr int STRICT_SEG = 16384;  // floats per staged segment (64 KiB)
+__global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                               int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* seg = reinterpret_cast<float*>(smem_raw);
+  __shared__ stl_order::Elem heap_s[64];
+  volatile stl_order::Elem* heap_v = heap_s;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int len = row_len ? row_len[row] : n_default;
   const float* r = vals + (size_t)row * ld;
-  const int per = (len + nsplit - 1) / nsplit;
-  const int j_begin = split * per, j_end = min(len, j_begin + per);
-  unsigned long long best[NMAX];
-#pragma unroll
-  for (int s = 0; s < NMAX; ++s) best[s] = ~0ull;
-  // the partial scores were written by other XCDs, so every load here is an Infinity-Cache round trip (~1 us): batches
-  // of 4 elements per lane put 4 x k_slices independent loads in flight before the first add
-  for (int j0 = j_begin + lane; j0 < j_end; j0 += 256) {
-    float v[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = j0 + 64 * e < j_end ? r[j0 + 64 * e] : 0.f;
-    for (int sl = 1; sl < k_slices; ++sl) {  // slice chains added in slice order
-      float w[4];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) w[e] = j0 + 64 * e < j_end ? r[(size_t)sl * slice_stride + j0 + 64 * e] : 0.f;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] += w[e];
+  const int k = min(n_top, len);
+  if ((long long)k * 64 > (long long)len) {  // len < 64 * n_top <= 4096: (value, index) pairs fit the segment buffer
+    stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(smem_raw);
+    for (int j = tid; j < len; j += 256) el[j] = stl_order::Elem{r[j], j};
+    __syncthreads();
+    if (tid == 0) stl_order::topk_torch_largest(el, len, k);
+    __syncthreads();
+    if (tid < n_top) {
+      out_idx[(size_t)row * n_top + tid] = tid < k ? el[tid].idx : -1;
+      out_val[(size_t)row * n_top + tid] = tid < k ? el[tid].v : -INFINITY;
     }
+    return;
+  }
+  for (int s0 = 0; s0 < len; s0 += STRICT_SEG) {
+    const int s1 = min(len, s0 + STRICT_SEG);
+    __syncthreads();  // the previous segment has no readers left
+    for (int j = s0 + tid * 4; j < s1; j += 1024) {
+      if (j + 4 <= s1 && ((ld & 3) == 0)) {
+        *reinterpret_cast<float4*>(seg + (j - s0)) = *reinterpret_cast<const float4*>(r + j);
+      } else {
+        for (int e = 0; e < 4 && j + e < s1; ++e) seg[j - s0 + e] = r[j + e];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      int c0 = s0;
+      if (s0 == 0) {  // std::make_heap over the first k elements
+        if (lane == 0) {
+          for (int j = 0; j < k; ++j) heap_s[j] = stl_order::Elem{seg[j], j};
+          stl_order::make_heap_(heap_s, k);
+        }
+        c0 = k;
+      }
+      for (; c0 < s1; c0 += 256) {
+        float v[4];
+        bool ok[4];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      unsigned long long key = j0 + 64 * e < j_end ? ((unsigned long long)order_key(v[e], true) << 32) | (unsigned)(j0 + 64 * e) : ~0ull;
+        for (int e = 0; e < 4; ++e) {
+          const int j = c0 + 64 * e + lane;
+          ok[e] = j < s1;
+          v[e] = ok[e] ? seg[j - s0] : 0.f;
+        }
+        stl_order::Elem top{heap_v[0].v, 0};
+        unsigned long long m[4];
+        bool any = false;
 #pragma unroll
-      for (int s = 0; s < NMAX; ++s) {  // sorted insertion (ascending keys = best first)
-        const unsigned long long lo = key < best[s] ? key : best[s];
-        key = key < best[s] ? best[s] : key;
-        best[s] = lo;
+        for (int e = 0; e < 4; ++e) {
+          m[e] = __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
+          any |= m[e] != 0;
+        }
+        if (!any) continue;  // wave-uniform: nothing in these 256 elements beats the root
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsigned long long me = e == 0 ? m[0] : __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
+          while (me) {
+            const int l = __builtin_ctzll(me);
+            const float vl = __shfl(v[e], l, 64);
+            if (lane == 0) {
+              stl_order::Elem x{vl, c0 + 64 * e + l};
+              stl_order::pop_heap_(heap_s, k, &x);  // __pop_heap(first, middle, i): the old root leaves, *i enters
+            }
+            top.v = heap_v[0].v;
+            me = __ballot(ok[e] && lane > l && stl_order::gt(stl_order::Elem{v[e], 0}, top));
+          }
+        }
       }
     }
   }
-  float* cval = reinterpret_cast<float*>(cand_out + (size_t)rows * nsplit * n_top);
-  for (int s = 0; s < n_top; ++s) {
-    const unsigned long long b = wave_min_u64(best[0]);
-    const size_t slot = ((size_t)row * nsplit + split) * n_top + s;
-    if (b == ~0ull) {
-      if (lane == 0) { cand_out[slot] = b; cval[slot] = -INFINITY; }
-    } else if (best[0] == b) {  // exactly one lane owns the winner (keys carry the unique column index)
-      const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits, no reload
-      cand_out[slot] = b;
-      cval[slot] = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
-#pragma unroll
-      for (int t = 0; t + 1 < NMAX; ++t) best[t] = best[t + 1];
-      best[NMAX - 1] = ~0ull;
-    }
-  }
-}
-
-// Phase B of the split top-n: one wave per row merges the nsplit * n_top (<= 128) candidates held in registers.
-__global__ void topn_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
-                                  float* __restrict__ out_val, int* __restrict__ out_idx) {
-  const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (row >= rows) return;
-  const int lane = threadIdx.x & 63;
-  const unsigned long long* c = cand + (size_t)row * ncand;
-  const float* cv = reinterpret_cast<const float*>(cand + (size_t)rows * ncand) + (size_t)row * ncand;
-  unsigned long long k0 = lane < ncand ? c[lane] : ~0ull, k1 = lane + 64 < ncand ? c[lane + 64] : ~0ull;
-  const float v0 = lane < ncand ? cv[lane] : 0.f, v1 = lane + 64 < ncand ? cv[lane + 64] : 0.f;
-  for (int s = 0; s < n_top; ++s) {
-    const unsigned long long mine = k0 < k1 ? k0 : k1;
-    const unsigned long long b = wave_min_u64(mine);
-    if (b != ~0ull && mine == b) {  // exactly one lane owns the winner (keys carry the unique column index)
-      out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
-      out_val[(size_t)row * n_top + s] = (k0 == b) ? v0 : v1;
-      if (k0 == b) k0 = ~0ull; else k1 = ~0ull;
-    }
-    if (b == ~0ull && lane == 0) {
-      out_idx[(size_t)row * n_top + s] = -1;
-      out_val[(size_t)row * n_top + s] = -INFINITY;
-    }
-  }
-}
-
-// Strict-order variant: one block per row, the row staged in LDS as (value, index) pairs, one lane replays
-// torch.topk's CPU algorithm (stl_order.hpp).  Rows of up to 20000 elements (160 KiB of LDS).
-__global__ __launch_bounds__(256) void topn_rows_stl_kernel(float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                            int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
-                                                            int k_slices, long long slice_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(smem_raw);
-  const int row = blockIdx.x, tid = threadIdx.x;
-  const int len = row_len ? row_len[row] : n_default;
-  float* r = vals + (size_t)row * ld;
-  for (int j = tid; j < len; j += 256) {
-    float v = r[j];
-    for (int sl = 1; sl < k_slices; ++sl) v += r[(size_t)sl * slice_stride + j];
-    el[j] = stl_order::Elem{v, j};
-  }
   __syncthreads();
-  const int k = min(n_top, len);
-  if (tid == 0) stl_order::topk_torch_largest(el, len, k);
+  if (tid == 0) stl_order::sort_heap_(heap_s, k);
   __syncthreads();
   if (tid < n_top) {
-    out_idx[(size_t)row * n_top + tid] = tid < k ? el[tid].idx : -1;
-    out_val[(size_t)row * n_top + tid] = tid < k ? el[tid].v : -INFINITY;
+    out_idx[(size_t)row * n_top + tid] = tid < k ? heap_s[tid].idx : -1;
+    out_val[(size_t)row * n_top + tid] = tid < k ? heap_s[tid].v : -INFINITY;
   }
 }
 
@@ -523,14 +537,14 @@ __global__ __launch_bounds__(256) void tfidf_build_kernel(
       }
       const float wn = wj / fmaxf(sqrtf(nrm2), 1e-12f);
       const float tf = wn / fQ;
-      const int id = idr[j];
+      const int id = idr[j];  // -1: the k-NN had fewer than knn_k words to offer (padding, like faiss) -> no bin
       ids[e] = id;
-      vals[e] = tf * idf[id];
+      vals[e] = id >= 0 ? tf * idf[id] : 0.f;
     }
     __syncthreads();
     for (int e = 0; e < cnt; ++e) {
       const int id = ids[e];
-      if ((id & 255) == tid) bins[id] += vals[e];
+      if (id >= 0 && (id & 255) == tid) bins[id] += vals[e];
     }
   }
   __syncthreads();
@@ -577,8 +591,10 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   const int q0 = a.q_off[det], Q = a.q_off[det + 1] - q0;
   const int tpl = a.tpl_ids[pair];
   const int kk = min(a.top_k, Q);
-  if (tid == 0) a.out_count[pair] = (tpl >= 0) ? kk : 0;
-  if (tpl < 0 || Q == 0) return;
+  // an empty slot (fewer templates than n_slots) or a template without features yields no correspondences
+  const bool live = tpl >= 0 && a.tpl_off[tpl + 1] > a.tpl_off[tpl];
+  if (tid == 0) a.out_count[pair] = live ? kk : 0;
+  if (!live || Q == 0) return;
   const int f0 = a.tpl_off[tpl];
   const unsigned long long* rb = a.row_best + (size_t)pair * a.row_stride;
   const unsigned long long* cb = a.col_best + (size_t)pair * a.col_stride;
@@ -742,11 +758,8 @@ int launch_tfidf_build(const int* word_ids, const float* word_d2, int knn_k, con
   FP_REQUIRE(knn_k >= 1 && knn_k <= 16, "tfidf_build: knn_k out of range");
   if (num_segs == 0) return FP_OK;
   size_t lds = (size_t)num_words * 4 + 4096 * 8;
-  static bool attr = false;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&tfidf_build_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 16384 * 4 + 4096 * 8);
-    attr = true;
-  }
+  static FpDeviceOnce attr;
+  fp_allow_dynamic_lds(attr, &tfidf_build_kernel, 16384 * 4 + 4096 * 8);
   hipLaunchKernelGGL(tfidf_build_kernel, dim3(num_segs), dim3(256), lds, st, word_ids, word_d2, knn_k, seg_off, idf,
                      num_words, soft, 2.0f * sigma_sq, sqrt_dists, desc, desc_n, eps);
   FP_CHECK_LAUNCH("tfidf_build");
@@ -783,84 +796,69 @@ int launch_unpack_best(const unsigned long long* best, long long n, float* d2, i
   return FP_OK;
 }
 
-int launch_topn_rows(float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
-                     int* out_ids, int tie_mode, int k_slices, long long slice_stride, unsigned long long* cand_scratch, hipStream_t st) {
+// Top-n of finished scores [rows, ld]: tie_mode 1 = the reference's torch.topk order, 0 = canonical.
+int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
+                     int* out_ids, int tie_mode, hipStream_t st) {
   if (rows == 0) return FP_OK;
   if (tie_mode == 1) {
-    FP_REQUIRE(max_len <= 20000, "strict (torch) tie order supports rows of at most 20000 elements (got %d)", max_len);
-    const size_t lds = (size_t)max_len * 8;
-    static size_t attr = 0;
-    if (lds > attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&topn_rows_stl_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160000);
-      attr = 160000;
-    }
-    hipLaunchKernelGGL(topn_rows_stl_kernel, dim3(rows), dim3(256), lds, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids, k_slices, slice_stride);
+    FP_REQUIRE(n_top <= 64, "strict (torch) tie order: n_top must be <= 64 (got %d)", n_top);
+    static FpDeviceOnce attr;
+    fp_allow_dynamic_lds(attr, &topn_rows_strict_kernel, STRICT_SEG * 4);
+    hipLaunchKernelGGL(topn_rows_strict_kernel, dim3(rows), dim3(256), STRICT_SEG * 4, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+  } else if (n_top <= 8) {
+    hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
   } else {
-    FP_REQUIRE(n_top <= 8, "top-n: n_top must be <= 8 on the canonical block path");
-    if (cand_scratch && max_len >= 4096) {
-      const int nsplit = 128 / n_top < 24 ? 128 / n_top : 24;  // the merge wave holds nsplit * n_top <= 128 candidates
-      hipLaunchKernelGGL(topn_rows_wave_kernel<8>, dim3(rows, cdiv(nsplit, 4)), dim3(256), 0, st, sims, ld, row_len, max_len, n_top,
-                         k_slices, slice_stride, nsplit, rows, cand_scratch);
-      hipLaunchKernelGGL(topn_merge_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cand_scratch, nsplit * n_top, rows, n_top, out_scores, out_ids);
-    } else {
-      hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids,
-                         k_slices, slice_stride, (unsigned long long*)nullptr);
-    }
+    return launch_topk_rows(sims, rows, max_len, ld, row_len, n_top, 1, out_scores, out_ids, st);  // n selection passes
   }
   FP_CHECK_LAUNCH("topn_rows");
   return FP_OK;
 }
 
-int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st) {
-  FP_REQUIRE(a.W % 16 == 0, "cosine_topk: the streaming kernel needs num_words %% 16 == 0");
-  FP_REQUIRE(max_det_per_obj <= 64, "cosine_topk: at most 64 detections per object per call (got %d); split the batch", max_det_per_obj);
-  const int nq = cdiv(max_det_per_obj, 16) <= 1 ? 1 : (cdiv(max_det_per_obj, 16) == 2 ? 2 : 4);
+  CosineArgs a = a_in;
+  FP_REQUIRE(a.W % 16 == 0, "cosine_topk: num_words %% 16 == 0 required on this path");
+  a.k_slices = (a.W % 128 == 0) ? 8 : 1;  // canonical chain split, see include/foundpose_amd.h
   const int wslice = a.W / a.k_slices;
-  const size_t lds = (size_t)nq * 16 * ((size_t)wslice * 4 + 16);
-  FP_REQUIRE(lds <= 160 * 1024, "cosine_topk: query slice does not fit LDS (num_words %d)", a.W);
-  static bool attr = false;
-  static int num_cus = 256;
-  if (!attr) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_sims_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_stream_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_stream_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) num_cus = n;
-    attr = true;
-  }
-  // FP_COSINE_STREAM=0 (read once): A/B switch back to the register-direct kernel
-  static const int env_stream = getenv("FP_COSINE_STREAM") ? atoi(getenv("FP_COSINE_STREAM")) : 1;
-  if (env_stream && nq <= 2 && wslice % 64 == 0 && lds + 8 * 3 * 4096 <= 160 * 1024) {
-    // one persistent workgroup per CU: the (object, slice) pairs share the CUs evenly.  8..12 waves per workgroup,
-    // whichever splits the 16-template blocks most evenly over the waves (the kernel is close to MFMA-bound, so a
-    // wave with 3 blocks next to waves with 2 costs what the slowest wave costs)
-    const int nblk = cdiv(max_templates, 16);
-    const int per = num_cus / (num_obj * a.k_slices);
-    const int gx = per < 1 ? 1 : (per > cdiv(nblk, 8) ? cdiv(nblk, 8) : per);
-    int nw = 8;
-    double best = 0.0;
-    for (int w = 8; w <= 12; ++w) {
-      if (lds + (size_t)w * 3 * 4096 > 160 * 1024) break;
-      const int slots = gx * w, mx = cdiv(nblk, slots);
-      const double eff = (double)nblk / slots / mx;
-      if (eff >= best) { best = eff; nw = w; }
+  const int nblk = cdiv(max_templates, 16);
+  bool fused = a.k_slices == 8 && wslice % 64 == 0 && wslice <= 256;
+  const bool want_cand = tie_mode == 0 && n_top <= COS_NMAX;
+  if (fused) {
+    // one persistent workgroup per CU, shared evenly by the (object, 32-detection chunk) pairs of the launch
+    const int nq = max_det_per_obj <= 16 ? 1 : 2;
+    const int chunks = cdiv(max_det_per_obj, nq * 16);
+    const int per = fp_num_cus() / (num_obj * chunks);
+    const int gx = per < 1 ? 1 : (per > nblk ? nblk : per);
+    a.n_top = n_top;
+    if (!want_cand) a.cand = nullptr;
+    const size_t lds = 8 * 3 * 4096 + (size_t)2 * 8 * nq * 4 * COS_RED_PITCH * 4;
+    static FpDeviceOnce attr1, attr2;
+    fp_allow_dynamic_lds(attr1, &cosine_fused_kernel<1>, 8 * 3 * 4096 + 2 * 8 * 1 * 4 * COS_RED_PITCH * 4);
+    fp_allow_dynamic_lds(attr2, &cosine_fused_kernel<2>, 8 * 3 * 4096 + 2 * 8 * 2 * 4 * COS_RED_PITCH * 4);
+    dim3 grid(gx, num_obj, chunks);
+    if (nq == 1) hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);
+    FP_CHECK_LAUNCH("cosine_fused");
+    if (want_cand) {
+      hipLaunchKernelGGL(cand_merge_kernel, dim3(cdiv(num_det, 4)), dim3(256), 0, st, a.cand, gx * n_top, num_det, n_top, out_scores, out_ids);
+      FP_CHECK_LAUNCH("cand_merge");
+      return FP_OK;
     }
-    const size_t lds_stream = lds + (size_t)nw * 3 * 4096;
-    dim3 sgrid(gx, num_obj, a.k_slices);
-    if (nq == 1) hipLaunchKernelGGL(cosine_stream_kernel<1>, sgrid, dim3(nw * 64), lds_stream, st, a);
-    else hipLaunchKernelGGL(cosine_stream_kernel<2>, sgrid, dim3(nw * 64), lds_stream, st, a);
   } else {
-    dim3 grid(cdiv(cdiv(max_templates, 16), 4), num_obj, a.k_slices);
-    if (nq == 1) hipLaunchKernelGGL(cosine_sims_kernel<1>, grid, dim3(256), lds, st, a);
-    else if (nq == 2) hipLaunchKernelGGL(cosine_sims_kernel<2>, grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL(cosine_sims_kernel<4>, grid, dim3(256), lds, st, a);
+    const int nq = max_det_per_obj <= 16 ? 1 : (max_det_per_obj <= 32 ? 2 : 4);
+    const size_t lds = (size_t)nq * 16 * ((size_t)wslice * 4 + 16);
+    FP_REQUIRE(lds <= 160 * 1024, "cosine_topk: query slice does not fit LDS (num_words %d)", a.W);
+    static FpDeviceOnce attr;
+    if (fp_first_on_device(attr)) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_generic_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_generic_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&cosine_generic_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+    dim3 grid(cdiv(nblk, 4), num_obj, cdiv(max_det_per_obj, nq * 16));
+    if (nq == 1) hipLaunchKernelGGL(cosine_generic_kernel<1>, grid, dim3(256), lds, st, a);
+    else if (nq == 2) hipLaunchKernelGGL(cosine_generic_kernel<2>, grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL(cosine_generic_kernel<4>, grid, dim3(256), lds, st, a);
+    FP_CHECK_LAUNCH("cosine_generic");
   }
-  FP_CHECK_LAUNCH("cosine_sims");
-  // candidate keys of the split top-n live behind the 8 slice buffers (scratch contract: 9 slices)
-  unsigned long long* cand = reinterpret_cast<unsigned long long*>(a.sims + 8 * (size_t)num_det * a.ld_sims);
-  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode,
-                          a.k_slices, a.slice_stride, (24 * n_top * 3 <= a.ld_sims) ? cand : nullptr, st);
+  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st);
 }

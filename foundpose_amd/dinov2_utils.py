@@ -42,7 +42,8 @@ def _interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: 
 
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
-                 precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False) -> None:
+                 precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
+                 act_scales: Optional[torch.Tensor] = None) -> None:
         super().__init__()
         self.use_graph = use_graph  # replay the forward's launch sequence as one hipGraph (static buffers per batch shape)
         if arch is not None:  # non-hub architecture (unit tests use a tiny one)
@@ -69,8 +70,13 @@ class DinoFeatureExtractor(torch.nn.Module):
         if precision == "fp8" and (self.arch.dim % 256 or self.arch.hidden % 256):
             raise NotImplementedError(f"precision='fp8' needs dim and hidden to be multiples of 256 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
         # fp8 mode (BASELINE config 5): e4m3 block matrices quantised per output channel, GEMM inputs quantised per tensor
-        # with static scales taken from the first batch seen (or set beforehand with calibrate_fp8 / act_scales=)
-        self.act_scales: Optional[torch.Tensor] = None  # [depth, 4]: inputs of qkv, proj, fc1, fc2
+        # with STATIC scales.  They are part of the model: set them with act_scales= (e.g. the scales stored with the bank,
+        # repre.extractor_fp8_act_scales) or with an explicit calibrate_fp8(images) call.  A forward without them raises --
+        # scales picked up from whichever batch happens to come first would make the features depend on call order and
+        # would quantise bank and query descriptors inconsistently.
+        self.act_scales: Optional[torch.Tensor] = None if act_scales is None else torch.as_tensor(act_scales, dtype=torch.float32).cpu().clone()  # [depth, 4]: inputs of qkv, proj, fc1, fc2
+        if self.act_scales is not None and (precision != "fp8" or tuple(self.act_scales.shape) != (self.arch.depth, 4)):
+            raise ValueError(f"act_scales is the [depth, 4] scale table of precision='fp8' (got {tuple(self.act_scales.shape)}, precision {precision})")
         self.precision = precision
         self._sd = state_dict if state_dict is not None else synthetic.make_vit_state_dict(self.arch, seed)
         self._device: Optional[torch.device] = None
@@ -167,6 +173,8 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._grids.clear()
         self._ws.clear()
         self._graphs.clear()
+        if self.precision == "fp8" and self.act_scales is not None:
+            self._to_fp8()
 
     def _grid_tables(self, gh: int, gw: int):
         key = (gh, gw)
@@ -226,7 +234,9 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
-            self.calibrate_fp8(images)
+            raise _lib.FoundPoseNativeError(
+                "precision='fp8' needs its static activation scales before the first forward: construct the extractor with "
+                "act_scales= (the table stored with the bank) or call calibrate_fp8(calibration_images) once")
         if self.facet != "token":
             fmap, cls = self._forward_facet(images, B, H, W, gh, gw)
         elif self.use_graph:
@@ -305,7 +315,7 @@ class DinoFeatureExtractor(torch.nn.Module):
                      ("mlp.fc1.weight", "mlp.fc1.bias", None) if a.ffn == "mlp" else ("w12i", "b12i", None),
                      ("mlp.fc2.weight", "mlp.fc2.bias", "ls2.gamma") if a.ffn == "mlp" else ("mlp.w3.weight", "mlp.w3.bias", "ls2.gamma")]
             for j, ((wk, bk, gk), field) in enumerate(zip(names, ("qkv", "proj", "fc1", "fc2"))):
-                wt = w[p + wk].float()
+                wt = self._fp32_matrix(p, wk)  # quantised from the fp32 checkpoint values, not from their bf16 rounding
                 sw = 448.0 / wt.abs().amax(dim=1).clamp_min(1e-12)
                 deq = 1.0 / (float(self.act_scales[i, j]) * sw)
                 q8 = ops.quantize_fp8((wt * sw[:, None]).contiguous(), 1.0)
@@ -324,6 +334,14 @@ class DinoFeatureExtractor(torch.nn.Module):
         p8 = self._ld_pad8
         self._model.ld_w_dim, self._model.ld_w_hidden = (a.dim + p8, a.hidden + p8) if p8 else (0, 0)
         self._graphs.clear()
+
+    def _fp32_matrix(self, p: str, wk: str) -> torch.Tensor:
+        sd, dev = self._sd, self._device
+        if wk == "w12i":  # SwiGLU: rows interleaved (x1_j, x2_j) like the bf16 operand
+            w12 = sd[p + "mlp.w12.weight"].to(dev, torch.float32)
+            hdn = w12.shape[0] // 2
+            return torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1).contiguous()
+        return sd[p + wk].to(dev, torch.float32).contiguous()
 
     def _launch(self, images, ws, B, H, W, gh, gw, fmap, cls) -> None:
         """The ~125 kernel launches of one forward (C++ launch sequence) on the current stream."""

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import ops
-from ._lib import call, ptr, stream, require_cuda
+from ._lib import call, cosine_scratch_floats, ptr, stream, require_cuda
 from .bank import DeviceBank
 
 
@@ -129,7 +129,7 @@ def match_batch(
     det_seg = torch.tensor(det_seg_h, dtype=torch.int32, device=dev)
     det_nt = torch.tensor([bank.objects[o].num_templates for o in det_obj], dtype=torch.int32, device=dev)
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
-    sims = torch.empty(9, B, bank.max_templates, dtype=torch.float32, device=dev)  # k-slice partials; slice 0 = scores
+    sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
     call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),

@@ -44,6 +44,9 @@ class FeatureBasedObjectRepre:
     template_cameras_cam_from_model: List[Any] = field(default_factory=list)
     template_descs: Optional[torch.Tensor] = None        # [T, W]
     template_desc_opts: Optional[TemplateDescOpts] = None
+    # not in the reference: the static activation scales of the fp8 extractor the bank was built with ([depth][4] nested
+    # list).  Stored as a plain list, which the reference's loader skips (it copies tensors and its own named entries only).
+    extractor_fp8_act_scales: Optional[Any] = None
 
 
 def get_object_repre_dir_path(base_dir: str, repre_type: str, dataset: str, lid: int) -> str:
@@ -62,6 +65,8 @@ def save_object_repre(repre: FeatureBasedObjectRepre, repre_dir: str) -> None:
     obj["template_desc_opts"] = repre.template_desc_opts._asdict() if repre.template_desc_opts is not None else None
     obj["feat_raw_projectors"] = [projector_util.projector_to_tensordict(p) for p in repre.feat_raw_projectors]
     obj["feat_vis_projectors"] = [projector_util.projector_to_tensordict(p) for p in repre.feat_vis_projectors]
+    if repre.extractor_fp8_act_scales is not None:
+        obj["extractor_fp8_act_scales"] = torch.as_tensor(repre.extractor_fp8_act_scales, dtype=torch.float32).tolist()
     os.makedirs(repre_dir, exist_ok=True)
     torch.save(obj, os.path.join(repre_dir, "repre.pth"))
 
@@ -83,6 +88,8 @@ def load_object_repre(repre_dir: str, tensor_device: str = "cuda", load_fields: 
     out["template_cameras_cam_from_model"] = list(obj.get("template_cameras_cam_from_model", [])) if want("template_cameras_cam_from_model") else []
     if want("template_desc_opts") and obj.get("template_desc_opts") is not None:
         out["template_desc_opts"] = TemplateDescOpts(**dict(obj["template_desc_opts"]))
+    if obj.get("extractor_fp8_act_scales") is not None:
+        out["extractor_fp8_act_scales"] = obj["extractor_fp8_act_scales"]
     return FeatureBasedObjectRepre(**out)
 
 

@@ -1,0 +1,200 @@
+"""The planted synthetic workload of bench.py and of the end-to-end parity tests ("planted
+positives: each query crop's features = a known template's patch features + noise, so retrieval has a verifiable
+answer and decision margins"), plus the index-agreement statistics both report.
+
+With random-init ViT weights and noise crops a random bank gives every template the same near-zero score: top-5 lists
+and nearest neighbours are then decided by rounding noise and no two arithmetic modes can be compared.  Here the bank is
+made FROM the crops: the projected fp32 features of detection b are written (with graded noise) into five consecutive
+templates t_b .. t_b+4 of its object, their vertices come from a known pose (R_b, t_b) through a smooth depth surface,
+and every other template is a random mixture of patches of all detections.  The expected answer of the pipeline is then
+known -- templates t_b .. t_b+4 in that order, correspondences that satisfy the planted pose -- and the margins are set by
+the noise levels, not by chance.
+
+Everything here is data generation and bookkeeping around the product path (it runs the extractor it is handed and the
+device bank builder); nothing imports oracle/.
+"""
+
+import math
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import bank_builder, feature_util, ops, projector_util, repre_util, synthetic
+
+PLANT_NOISE = (0.05, 0.2, 0.35, 0.5, 0.65)  # noise of templates t_b + r, in units of the feature std: graded scores
+
+
+@dataclass
+class PlantedWorkload:
+    crops: torch.Tensor            # [B, 3, S, S] f32 in [0, 1], cuda
+    masks: torch.Tensor            # [B, S, S] u8, cuda
+    det_obj: List[int]             # object index per detection, ascending
+    repres: List[repre_util.FeatureBasedObjectRepre]
+    targets: torch.Tensor          # [B] planted template id (object-local) of each detection; t .. t+4 are its graded copies
+    K: torch.Tensor                # [3, 3] crop camera intrinsics (f64)
+    R: torch.Tensor                # [B, 3, 3] planted model->camera rotations (f64)
+    t: torch.Tensor                # [B, 3] planted translations (f64)
+
+
+def _random_rotations(n: int, g: torch.Generator) -> torch.Tensor:
+    q = torch.randn(n, 4, generator=g, dtype=torch.float64)
+    q = q / q.norm(dim=1, keepdim=True)
+    w, x, y, z = q.unbind(1)
+    return torch.stack([
+        1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w),
+        2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+        2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], 1).reshape(n, 3, 3)
+
+
+def planted_vertices(points: torch.Tensor, K: torch.Tensor, R: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """Model-space 3D point seen at each pixel: depth from a smooth surface, X_model = R^T (z K^-1 [u, v, 1] - t)."""
+    p = points.to(torch.float64).cpu()
+    u, v = p[:, 0], p[:, 1]
+    S = 2.0 * float(K[0, 2])
+    z = float(t[2]) + 40.0 * torch.sin(u * (2.0 * math.pi / S)) * torch.cos(v * (2.0 * math.pi / S)) + 15.0 * torch.cos(u * (5.0 / S) + v * (3.0 / S))
+    xc = torch.stack([(u - K[0, 2]) / K[0, 0] * z, (v - K[1, 2]) / K[1, 1] * z, z], 1)
+    return ((xc - t[None, :]) @ R).to(torch.float32)  # rows: R^T (xc - t)
+
+
+def query_features(extractor, crops: torch.Tensor, masks: torch.Tensor, cell: float = 14.0):
+    """Raw (un-projected) patch features of every detection inside its mask, through the product kernels.
+    -> (features [sumQ, D], points [sumQ, 2], counts per detection)."""
+    B, _, H, W = crops.shape
+    grid = feature_util.generate_grid_points((W, H), cell).to(crops.device)
+    pts, img, counts = [], [], []
+    for b in range(B):
+        p = feature_util.filter_points_by_mask(grid, masks[b])
+        pts.append(p)
+        img.append(torch.full((p.shape[0],), b, dtype=torch.int32, device=p.device))
+        counts.append(int(p.shape[0]))
+    pts, img = torch.cat(pts).contiguous(), torch.cat(img).contiguous()
+    feats = []
+    for b0 in range(0, B, 32):  # the extractor's workspace is per batch shape: keep it at <= 32 crops
+        b1 = min(B, b0 + 32)
+        fmap, _ = extractor.forward_tokens(crops[b0:b1])
+        gh, gw = extractor.num_patches
+        sel = (img >= b0) & (img < b1)
+        feats.append(ops.sample_bilinear(fmap.reshape(b1 - b0, gh, gw, fmap.shape[-1]).permute(0, 3, 1, 2), pts[sel].contiguous(),
+                                         (img[sel] - b0).contiguous(), (W, H)))
+    return torch.cat(feats), pts, counts
+
+
+def build_planted_workload(extractor, batch: int, size: int, num_objects: int, templates_per_object: int, feat_dim: int = 256,
+                           num_words: int = 2048, seed: int = 0, crop_seed: int = 0, min_patches: int = 300, max_patches: int = 450,
+                           noise: Sequence[float] = PLANT_NOISE, mask: Optional[torch.Tensor] = None) -> PlantedWorkload:
+    """`extractor`: the extractor whose features are planted (use precision="fp32": the reference's arithmetic)."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    crops = synthetic.make_crops(batch, size, seed=crop_seed).to(dev)
+    m = synthetic.make_disc_mask(size) if mask is None else mask
+    masks = m.unsqueeze(0).repeat(batch, 1, 1).to(dev)
+    det_obj = sorted(i % num_objects for i in range(batch))
+    g = torch.Generator().manual_seed(seed)
+    gd = torch.Generator(device=dev).manual_seed(seed)
+    raw, pts, counts = query_features(extractor, crops, masks)
+    D = raw.shape[1]
+    # PCA stand-in: random orthonormal rows (the projector the engine applies to the query side)
+    comps = torch.linalg.qr(torch.randn(D, feat_dim, generator=g))[0].T.contiguous()
+    proj = projector_util.projector_from_tensordict({"pca_projector": {
+        "components": comps, "mean": torch.randn(D, generator=g) * 0.1, "whiten": torch.tensor(False)}})
+    qf = proj.transform(raw)                       # [sumQ, feat_dim] on the device
+    sigma = float(qf.std())
+    q_off = [0]
+    for c in counts:
+        q_off.append(q_off[-1] + c)
+    # a template holds a subset of a detection's patches: 300..450 of the 517 inside the disc mask at 518 px,
+    # the same proportions at smaller crops
+    q_min = min(counts)
+    max_patches, min_patches = min(max_patches, int(0.87 * q_min)), min(min_patches, int(0.58 * q_min))
+    if min_patches < 1:
+        raise ValueError(f"a detection has only {q_min} query patches")
+
+    K = torch.tensor([[1.2 * size, 0.0, size / 2.0], [0.0, 1.2 * size, size / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    R = _random_rotations(batch, g)
+    t = torch.stack([torch.randn(batch, generator=g, dtype=torch.float64) * 20.0, torch.randn(batch, generator=g, dtype=torch.float64) * 20.0,
+                     900.0 + 200.0 * torch.rand(batch, generator=g, dtype=torch.float64)], 1)
+
+    T = templates_per_object
+    n_obj_det = [det_obj.count(o) for o in range(num_objects)]
+    if any(T < 8 * (n + 1) for n in n_obj_det):
+        raise ValueError("too few templates per object to plant five per detection")
+    targets = torch.zeros(batch, dtype=torch.int64)
+    repres = []
+    b_first = 0
+    for o in range(num_objects):
+        n_det = n_obj_det[o]
+        pcounts = torch.randint(min_patches, max_patches + 1, (T,), generator=g)
+        off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(pcounts, 0)])
+        n_f = int(off[-1])
+        # every template starts as a random mixture of patches of all detections (same distribution as the queries)
+        src = torch.randint(0, qf.shape[0], (n_f,), generator=gd, device=dev)
+        feats = qf[src] + 0.5 * sigma * torch.randn(n_f, feat_dim, generator=gd, device=dev)
+        verts = torch.randn(n_f, 3, generator=gd, device=dev) * 50.0
+        stride = T // (n_det + 1)
+        for j in range(n_det):
+            b = b_first + j
+            t_b = 4 + j * stride
+            targets[b] = t_b
+            qb, pb = qf[q_off[b]:q_off[b + 1]], pts[q_off[b]:q_off[b + 1]]
+            for r, nz in enumerate(noise):
+                tpl = t_b + r
+                P = int(pcounts[tpl])
+                sub = torch.randperm(counts[b], generator=g)[:P].sort().values.to(dev)
+                rows = slice(int(off[tpl]), int(off[tpl]) + P)
+                feats[rows] = qb[sub] + nz * sigma * torch.randn(P, feat_dim, generator=gd, device=dev)
+                verts[rows] = planted_vertices(pb[sub], K, R[b], t[b]).to(dev)
+        f2t = torch.repeat_interleave(torch.arange(T, dtype=torch.int32), pcounts).to(dev)
+        words = feats[torch.randperm(n_f, generator=g)[:num_words].to(dev)].clone()
+        opts = repre_util.TemplateDescOpts()
+        descs, idfs, f2c = bank_builder.calc_tfidf_descriptors(feats, f2t, words, T, opts)
+        repres.append(repre_util.FeatureBasedObjectRepre(
+            vertices=verts, feat_vectors=feats, feat_to_template_ids=f2t, feat_to_cluster_ids=f2c,
+            feat_to_vertex_ids=torch.arange(n_f, dtype=torch.int32, device=dev), feat_cluster_centroids=words,
+            feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj]))
+        b_first += n_det
+    return PlantedWorkload(crops, masks, det_obj, repres, targets, K, R, t)
+
+
+# ---------------------------------------------------------------------------------------------------- agreement statistics
+def _np(x):
+    import numpy as np
+    return x.detach().cpu().numpy() if isinstance(x, torch.Tensor) else np.asarray(x)
+
+
+def parity_stats(got: List[List[Dict]], ref: List[List[Dict]]) -> Dict:
+    """Index agreement of two runs of the path over the same detections (each a list of the reference's per-template
+    dicts, corresp_util.py:142-163).  Counts are over detections / (detection, template slot) pairs:
+      templates_equal ........ the top-n template id lists are identical, in order
+      top1_equal ............. the best template is the same
+      corresp_equal .......... slots (of detections with identical template lists) whose coord_2d_ids AND nn_vertex_ids
+                               are identical index for index, in order
+      corresp_overlap ........ mean Jaccard overlap of the (query patch, object feature) pair sets of those slots"""
+    import numpy as np
+    n = len(got)
+    tpl_eq = top1 = slots = slots_eq = 0
+    overlap = []
+    for a, b in zip(got, ref):
+        ia, ib = [int(x["template_id"]) for x in a], [int(x["template_id"]) for x in b]
+        top1 += int(len(ia) > 0 and len(ib) > 0 and ia[0] == ib[0])
+        if ia != ib:
+            continue
+        tpl_eq += 1
+        for x, y in zip(a, b):
+            qa, qb = _np(x["coord_2d_ids"]).astype(np.int64), _np(y["coord_2d_ids"]).astype(np.int64)
+            va, vb = _np(x["nn_vertex_ids"]).astype(np.int64), _np(y["nn_vertex_ids"]).astype(np.int64)
+            slots += 1
+            slots_eq += int(np.array_equal(qa, qb) and np.array_equal(va, vb))
+            sa, sb = set(zip(qa.tolist(), va.tolist())), set(zip(qb.tolist(), vb.tolist()))
+            overlap.append(len(sa & sb) / max(1, len(sa | sb)))
+    return {"detections": n, "templates_equal": tpl_eq, "top1_equal": top1, "slots_compared": slots, "corresp_equal": slots_eq,
+            "corresp_overlap": round(float(np.mean(overlap)), 4) if overlap else None}
+
+
+def planted_stats(got: List[List[Dict]], targets: Sequence[int], n_planted: int = 5) -> Dict:
+    """Against the planted answer: detections whose top-n list is exactly t_b .. t_b+n-1, and whose best is t_b."""
+    exact = top1 = 0
+    for a, t in zip(got, targets):
+        ids = [int(x["template_id"]) for x in a]
+        top1 += int(len(ids) > 0 and ids[0] == int(t))
+        exact += int(ids == [int(t) + r for r in range(n_planted)])
+    return {"detections": len(got), "planted_top1": top1, "planted_top5_in_order": exact}

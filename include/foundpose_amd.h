@@ -7,7 +7,8 @@
  * root).  Conventions:
  *   - every pointer is a DEVICE pointer unless it says "host"; the caller owns all memory (no allocation
  *     inside the library), including scratch; all work is enqueued on `stream` (a hipStream_t), nothing
- *     synchronises; the library keeps no mutable global state besides the thread-local error string
+ *     synchronises; the library keeps no mutable global state besides the thread-local error string and idempotent
+ *     per-device caches (which kernels already had their dynamic-LDS limit raised on a device, its CU count)
  *   - return value: 0 = ok, 1 = invalid argument, 2 = unsupported, 3 = HIP failure; fp_last_error() gives text
  *   - indices on the device are int32; distances/scores fp32; L2 distances are SQUARED (faiss convention)
  *   - canonical ordering of every top-k: best value first, ties broken by the lowest index
@@ -25,7 +26,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 7
+#define FP_ABI_VERSION 8
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -59,12 +60,17 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
 /* Template retrieval: cosine similarity of each detection's descriptor against the template descriptors of
  * its object + top-n (tfidf_matching, utils/template_util.py:167-174).  Detections are grouped by object:
  * det_seg_off [num_obj+1] over rows of desc_n, obj_tpl_off [num_obj+1] over rows of bank_n (both
- * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims
- * [9, num_det, max_templates] (8 k-slice partial scores + candidate keys of the split top-n).  Canonical fp32 summation order of a score:
+ * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims:
+ * FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) floats -- the finished scores [num_det, max_templates] (left there
+ * for the caller) followed by the candidate keys of the fused top-n.  Canonical fp32 summation order of a score:
  * num_words % 128 == 0: 8 contiguous k-slices, each an fma chain visiting every 16-block of k as
- * [0,4,8,12,1,5,...,15], slice sums added in slice order; num_words % 16 == 0: one such chain; else k ascending.  out_scores/out_ids [num_det, n_top]; ids are
- * object-local template ids.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of torch.topk on
- * a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows <= 20000 templates). */
+ * [0,4,8,12,1,5,...,15], slice sums added in slice order; num_words % 16 == 0: one such chain; else k ascending.
+ * The order depends on num_words only -- never on the batch: more than 32 detections of one object are served in
+ * 32-detection chunks by the same kernel.  out_scores/out_ids [num_det, n_top]; ids are object-local template ids,
+ * -1 / -inf past the object's template count.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of
+ * torch.topk on a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows of any length,
+ * n_top <= 64). */
+#define FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) (2 * (size_t)(num_det) * (size_t)(max_templates) + 16 * (size_t)(num_det) + 2)
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
                    int max_det_per_obj,
                    const float* bank_n, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,

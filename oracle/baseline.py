@@ -12,6 +12,9 @@ from typing import Dict, List
 
 import torch
 
+import numpy as np
+
+from . import match as om
 from . import vit as ov
 
 
@@ -20,8 +23,10 @@ def _l2(q: torch.Tensor, db: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def run_detection(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor, bank: Dict, top_n: int = 5, top_k: int = 300):
-    """One detection end to end; returns (times dict with the reference's keys, list of corresp dicts)."""
+def run_detection(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor, bank: Dict, top_n: int = 5, top_k: int = 300,
+                  return_features: bool = False):
+    """One detection end to end; returns (times dict with the reference's keys, list of corresp dicts)
+    [+ (query_points, projected query_features) with return_features]."""
     t: Dict[str, float] = {}
     S = image.shape[-1]
     t0 = time.perf_counter()
@@ -56,4 +61,36 @@ def run_detection(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor,
         _, sel = torch.topk(-cd, k=k, sorted=True)
         out.append({"template_id": int(tid), "coord_2d_ids": sel, "nn_vertex_ids": ids[q2o[sel]], "nn_dists": cd[sel]})
     t["corresp"] = time.perf_counter() - t0
+    if return_features:
+        return t, out, (qp, qf)
     return t, out
+
+
+def exact_matching(query_points, query_features, small: Dict, fetch_template, top_n: int = 5, top_k: int = 300, topk_mode: str = "torch"):
+    """establish_correspondences (utils/corresp_util.py:73-169) in the oracle's pinned arithmetic (oracle/match.py:
+    fixed-order fp32 chains, the reference's torch.topk tie order) on a bank that is too large to copy to the host as a
+    whole: `small` holds feat_cluster_centroids / feat_cluster_idfs / template_descs / template_desc_opts, and
+    fetch_template(tid) -> (features [P, d] of that template, index of its first feature row in the object)."""
+    qp = np.ascontiguousarray(np.asarray(query_points, np.float32))
+    qf = np.ascontiguousarray(np.asarray(query_features, np.float32))
+    tids, tscores, _ = om.tfidf_matching(qf, small, top_n, topk_mode)
+    out: List[Dict] = []
+    for c, tid in enumerate(tids):
+        feats, first = fetch_template(int(tid))
+        q_ids, o_ids, dists, scores, _ = om.cyclic_buddies(qp, qf, np.ascontiguousarray(np.asarray(feats, np.float32)), top_k, topk_mode)
+        out.append({"template_id": int(tid), "template_score": np.float32(tscores[c]), "coord_2d_ids": q_ids,
+                    "nn_vertex_ids": first + o_ids, "nn_dists": dists, "coord_conf": scores})
+    return out
+
+
+@torch.no_grad()
+def oracle_a_features(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor, pca_components=None, pca_mean=None):
+    """Oracle A's query side of one detection: fp32 extractor (blocks 0..layer only -- the later blocks the reference
+    also runs do not feed the hooked output), mask-filtered grid points, bilinear samples, PCA.  -> (points, features)."""
+    S = image.shape[-1]
+    fmap = ov.extractor_forward(sd, arch, image.unsqueeze(0), layer, True)["feature_maps"][0]
+    qp = ov.filter_points_by_mask(ov.generate_grid_points((S, S), 14.0), mask)
+    qf = ov.sample_feature_map_at_points(fmap, qp, (S, S)).contiguous()
+    if pca_components is not None:
+        qf = ov.pca_transform(qf, pca_components, pca_mean).contiguous()
+    return qp, qf

@@ -40,8 +40,7 @@ def _fq_act(x: torch.Tensor, scale: float) -> torch.Tensor:
 
 
 def _fq_weight(w: torch.Tensor) -> torch.Tensor:
-    """fp8 mode: a block matrix quantised per output channel (scale = 448 / row amax) from its bf16 values."""
-    w = _q(w, "bf16")
+    """fp8 mode: a block matrix quantised per output channel (scale = 448 / row amax) from its fp32 checkpoint values."""
     sw = 448.0 / w.abs().amax(dim=1, keepdim=True).clamp_min(1e-12)
     return (w * sw).clamp(-448, 448).to(torch.float8_e4m3fn).to(torch.float32) / sw
 

@@ -25,3 +25,5 @@ def test_bench_two_ranks_dry_run():
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["warmup"] == 1 and d["scaling"] == "weak" and d["higher_is_better"] is True
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 0.02 * d["value"]  # whole-job rate
     assert "cpu_baseline" not in d and "roofline" in d      # the CPU baseline is timed at N = 1 only
+    assert d["ranks_seen"] == 2                              # both ranks' records arrived in the gather
+    assert d["config"]["tie_order"] == "torch" and d["parity"]["planted"]["planted_top1"] == 8

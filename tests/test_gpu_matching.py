@@ -141,14 +141,13 @@ def test_strict_template_order_with_duplicate_templates():
         bank_n, q_n = ops.normalize_rows(cu(bank)), ops.normalize_rows(cu(q))
         seg, tpl = cu(np.array([0, Bq], np.int32)), cu(np.array([0, T], np.int32))
         nt = cu(np.full(Bq, T, np.int32))
-        sims = torch.empty(9, Bq, T, device="cuda")
+        from foundpose_amd._lib import cosine_scratch_floats
+        sims = torch.empty(cosine_scratch_floats(Bq, T), device="cuda")
         for mode in (0, 1):
             sc = torch.empty(Bq, 5, device="cuda")
             ids = torch.empty(Bq, 5, dtype=torch.int32, device="cuda")
             call("fp_cosine_topk", ptr(q_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream())
-            s_cpu = sims[0].cpu()
-            for sl in range(1, 8 if W % 128 == 0 else 1):
-                s_cpu = s_cpu + sims[sl].cpu()  # slice partials added in slice order
+            s_cpu = sims[:Bq * T].reshape(Bq, T).cpu()  # the finished scores stay at the head of the scratch
             for b in range(Bq):
                 if mode == 1:
                     ref = torch.topk(s_cpu[b], 5, sorted=True)[1]
@@ -330,7 +329,8 @@ def _cosine_topk(desc_n, bank_n, n_top, tie_mode=0):
     seg = torch.tensor([0, B], dtype=torch.int32, device="cuda")
     off = torch.tensor([0, T], dtype=torch.int32, device="cuda")
     nt = torch.full((B,), T, dtype=torch.int32, device="cuda")
-    sims = torch.zeros(9, B, T, device="cuda")
+    from foundpose_amd._lib import cosine_scratch_floats
+    sims = torch.zeros(cosine_scratch_floats(B, T), device="cuda")
     sc, ids = torch.empty(B, n_top, device="cuda"), torch.empty(B, n_top, dtype=torch.int32, device="cuda")
     call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, B, ptr(bank_n), ptr(off), 1, T, W, n_top, ptr(sims), ptr(sc), ptr(ids),
          tie_mode, stream())
@@ -340,8 +340,8 @@ def _cosine_topk(desc_n, bank_n, n_top, tie_mode=0):
 def test_full_size_retrieval_planted_and_kernel_agreement():
     """T = 10 000 templates x 2048 words, 32 detections:
     * a query that IS a bank row comes back first with score 1 (size-independent planted property),
-    * the LDS-streaming kernel (<= 32 detections per object) and the register-direct kernel (taken for 33..64
-      detections) produce bit-identical scores and ids for the same queries,
+    * scores and ids do not depend on the batch: the same 32 queries inside a 64-detection call (two 32-detection
+      chunks of the fused kernel) come back bit-identical,
     * the top-5 equals a sort of the oracle's canonical chain scores on a sample of rows."""
     bank_n = _full_size_bank()
     T, W = bank_n.shape
@@ -354,7 +354,7 @@ def test_full_size_retrieval_planted_and_kernel_agreement():
     sc, ids, _ = _cosine_topk(desc_n, bank_n, 5)
     assert torch.equal(ids[:, 0].cpu(), planted.to(torch.int32))
     assert float((sc[:16, 0] - 1).abs().max()) < 1e-6
-    # same 32 queries inside a 64-detection call -> the other kernel
+    # same 32 queries inside a 64-detection call
     sc2, ids2, _ = _cosine_topk(torch.cat([desc_n, desc_n.flip(0)]), bank_n, 5)
     assert torch.equal(ids2[:32], ids) and torch.equal(sc2[:32], sc)
     assert torch.equal(ids2[32:], ids.flip(0)) and torch.equal(sc2[32:], sc.flip(0))
@@ -365,6 +365,55 @@ def test_full_size_retrieval_planted_and_kernel_agreement():
         vals, idx = clib.topk_canonical(ref, 5, True)
         assert np.array_equal(idx.astype(np.int32), ids[b].cpu().numpy())
         assert np.array_equal(vals, sc[b].cpu().numpy())
+
+
+@pytest.mark.parametrize("T,B", [(10000, 128), (50000, 128), (50000, 37)])
+def test_config5_sized_retrieval_batch_invariant_and_strict(T, B):
+    """BASELINE config 5 sizes (50k templates, 128 detections of one object per GPU): every score equals the score the
+    same query gets alone (one arithmetic whatever the batch), the canonical top-5 equals the oracle's sort of the
+    device's own scores, and the strict order equals torch.topk run on those scores on the CPU -- with duplicated
+    templates, so exact score ties exist at every rank."""
+    W = 2048
+    g = torch.Generator(device="cuda").manual_seed(T + B)
+    from foundpose_amd import ops
+    bank = torch.rand(T, W, generator=g, device="cuda") * (torch.rand(T, W, generator=g, device="cuda") < 0.02)
+    bank[:, 0] += 1e-3
+    bank[T // 2:] = bank[: T - T // 2]  # every descriptor appears twice: ties between ids t and t + T/2
+    bank_n = ops.normalize_rows(bank)
+    del bank
+    desc_n = ops.normalize_rows(torch.rand(B, W, generator=g, device="cuda") * (torch.rand(B, W, generator=g, device="cuda") < 0.3))
+    sc0, ids0, sims0 = _cosine_topk(desc_n, bank_n, 5, tie_mode=0)
+    sc1, ids1, sims1 = _cosine_topk(desc_n, bank_n, 5, tie_mode=1)
+    S = sims0[:B * T].reshape(B, T)
+    assert torch.equal(S, sims1[:B * T].reshape(B, T))
+    for b in (0, 31, 32, B - 1):  # alone == inside the batch
+        _, _, s_one = _cosine_topk(desc_n[b:b + 1].contiguous(), bank_n, 5)
+        assert torch.equal(s_one[:T], S[b]), b
+    ref = clib.dot_rows(bank_n.cpu().numpy(), desc_n[B // 2].cpu().numpy(), perm16=True)  # the oracle's chain
+    assert np.array_equal(ref, S[B // 2].cpu().numpy())
+    S_cpu = S.cpu()
+    for b in range(B):
+        vals, idx = clib.topk_canonical(S_cpu[b].numpy(), 5, True)
+        assert np.array_equal(idx.astype(np.int32), ids0[b].cpu().numpy()), b
+        assert np.array_equal(vals, sc0[b].cpu().numpy()), b
+        tv, ti = torch.topk(S_cpu[b], 5, sorted=True)  # the reference's own call (template_util.py:172)
+        assert ids1[b].cpu().tolist() == ti.tolist(), b
+        assert torch.equal(sc1[b].cpu(), tv), b
+
+
+def test_retrieval_more_than_8_templates_canonical():
+    """n_top > 8 leaves the candidate lists of the fused kernel: same scores, canonical order by selection passes."""
+    bank_n = _full_size_bank(T=3000, seed=3)
+    from foundpose_amd import ops
+    desc_n = ops.normalize_rows(torch.rand(5, bank_n.shape[1], generator=torch.Generator(device="cuda").manual_seed(2), device="cuda"))
+    sc, ids, sims = _cosine_topk(desc_n, bank_n, 12)
+    S = sims[:5 * 3000].reshape(5, 3000).cpu()
+    for b in range(5):
+        vals, idx = clib.topk_canonical(S[b].numpy(), 12, True)
+        assert np.array_equal(idx.astype(np.int32), ids[b].cpu().numpy())
+        assert np.array_equal(vals, sc[b].cpu().numpy())
+    sc5, ids5, _ = _cosine_topk(desc_n, bank_n, 5)
+    assert torch.equal(ids5, ids[:, :5]) and torch.equal(sc5, sc[:, :5])
 
 
 def test_full_size_strict_and_canonical_agree_without_ties():

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from foundpose_amd import synthetic
+from foundpose_amd import _lib, synthetic
 from foundpose_amd.vit_config import ARCHS
 from oracle import vit as ov
 from tests.helpers import TINY, load_golden
@@ -401,7 +401,7 @@ def test_gemm_fp8_loud_failures():
 
 @pytest.mark.parametrize("ffn", ["mlp", "swiglu"])
 def test_extractor_fp8_mode_vs_oracle_c(ffn):
-    """precision="fp8": e4m3 block GEMMs with static activation scales calibrated on the first batch.  Checked against
+    """precision="fp8": e4m3 block GEMMs with static activation scales from an explicit calibration call.  Checked against
     "oracle C" (oracle/vit.py fp8_act=: bf16 activations + e4m3 fake quantisation at the same points with the same
     scales) at bf16-level tolerance, and against the fp32 oracle at the fp8 noise level."""
     from foundpose_amd.vit_config import VitArch
@@ -412,6 +412,9 @@ def test_extractor_fp8_mode_vs_oracle_c(ffn):
     mk = lambda: feature_util.make_feature_extractor(name, seed=77, precision="fp8", arch=arch).to("cuda")
     ex = mk()
     imgs = synthetic.make_crops(3, 56, seed=5)
+    with pytest.raises(_lib.FoundPoseNativeError, match="static activation scales"):
+        ex(imgs.cuda())  # no implicit calibration on whatever batch comes first
+    ex.calibrate_fp8(imgs.cuda())
     out = ex(imgs.cuda())
     scales = ex.act_scales
     assert scales.shape == (3, 4) and bool((scales > 0).all())
@@ -427,6 +430,8 @@ def test_extractor_fp8_mode_vs_oracle_c(ffn):
     ex2 = mk()
     ex2.calibrate_fp8(act_scales=scales)
     assert torch.equal(ex2(imgs.cuda())["feature_maps"].cpu(), fm)
+    ex3 = feature_util.make_feature_extractor(name, seed=77, precision="fp8", arch=arch, act_scales=scales).to("cuda")  # scales as part of the model
+    assert torch.equal(ex3(imgs.cuda())["feature_maps"].cpu(), fm)
     assert torch.equal(ex.act_scales, scales) and torch.isfinite(ex(synthetic.make_crops(2, 56, seed=6).cuda())["feature_maps"]).all()
 
 

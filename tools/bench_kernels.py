@@ -58,17 +58,20 @@ def main():
         print(f"attn B={B} N={N} H={H}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
     if "cos" in what:
         from foundpose_amd._lib import call, ptr, stream
-        T, W, Bq = 10000, 2048, 32
-        bank_n = ops.normalize_rows(torch.rand(T, W, device=dev))
-        desc_n = ops.normalize_rows(torch.rand(Bq, W, device=dev))
-        seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
-        tpl = torch.tensor([0, T], dtype=torch.int32, device=dev)
-        nt = torch.full((Bq,), T, dtype=torch.int32, device=dev)
-        sims = torch.empty(9, Bq, T, device=dev)
-        sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
-        ms = timeit(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5,
-                                 ptr(sims), ptr(sc), ptr(ids), 0, stream()), iters=50)
-        print(f"cosine_topk T={T} W={W} B={Bq}: {ms*1e3:8.1f} us  {(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes only)", flush=True)
+        for T, W, Bq in ((10000, 2048, 32), (800, 2048, 32), (50000, 2048, 128)):
+            bank_n = ops.normalize_rows(torch.rand(T, W, device=dev))
+            desc_n = ops.normalize_rows(torch.rand(Bq, W, device=dev))
+            seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
+            tpl = torch.tensor([0, T], dtype=torch.int32, device=dev)
+            nt = torch.full((Bq,), T, dtype=torch.int32, device=dev)
+            from foundpose_amd._lib import cosine_scratch_floats
+            sims = torch.empty(cosine_scratch_floats(Bq, T), device=dev)
+            sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
+            for mode in (0, 1):
+                ms = timeit(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, 5,
+                                         ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)
+                passes = (Bq + 31) // 32
+                print(f"cosine_topk T={T} W={W} B={Bq} tie_mode={mode}: {ms*1e3:8.1f} us  {passes*(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes x {passes} pass(es))", flush=True)
     if "ln" in what:
         x = torch.randn(M, D, device=dev)
         w, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
