@@ -195,8 +195,8 @@ def main():
             "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",
             "value": round(det_per_s, 2), "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.precision, "data": "synthetic (seeded noise crops, disc masks, random-init ViT weights, planted bank: each crop's fp32 features "
-                                             "sit with graded noise in 5 consecutive templates, the rest are random patch mixtures)",
+            "dtype": args.precision, "data": "synthetic (seeded crops assembled from 682 noise patch textures, disc masks, random-init ViT weights, planted bank: each crop's "
+                                             "fp32 features sit with graded noise in 5 consecutive templates, the rest are random texture sets; words = 3 instances per texture)",
             "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block), "
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
                                    f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}, "

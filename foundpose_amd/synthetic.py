@@ -68,6 +68,32 @@ def make_crops(batch: int, size: int, seed: int = 0) -> torch.Tensor:
     return torch.rand(batch, 3, size, size, generator=g, dtype=torch.float32)
 
 
+def make_dictionary_crops(batch: int, size: int, mask: torch.Tensor, dict_size: int = 682, patch: int = 14, seed: int = 0,
+                          pixel_noise: float = 0.02, dict_seed: int = 4242) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Crops assembled from a dictionary of `dict_size` noise patch textures: the patches whose centre lies inside `mask`
+    are DISTINCT textures (a random draw without replacement), the others random ones, plus a little pixel noise.
+    Real object surfaces repeat local structure across views -- that repetition is what gives descriptors clusters for
+    the visual words to sit on; iid noise crops have none (every patch is equidistant from every other, and the 3
+    nearest of 2048 words are decided by rounding).
+    -> (crops [B, 3, S, S] f32 in [0, 1], texture id of every patch [B, S/patch, S/patch] i64)."""
+    g = torch.Generator().manual_seed(dict_seed)
+    n = size // patch
+    textures = torch.rand(dict_size, 3, patch, patch, generator=g, dtype=torch.float32)
+    inside = mask[patch // 2::patch, patch // 2::patch][:n, :n].bool().reshape(-1)
+    n_in = int(inside.sum())
+    if n_in > dict_size:
+        raise ValueError(f"{n_in} patches inside the mask need a dictionary of at least that many textures (got {dict_size})")
+    g = torch.Generator().manual_seed(seed)
+    crops = torch.full((batch, 3, size, size), 0.5, dtype=torch.float32)
+    ids = torch.empty(batch, n * n, dtype=torch.int64)
+    for b in range(batch):
+        ids[b] = torch.randint(0, dict_size, (n * n,), generator=g)
+        ids[b, inside] = torch.randperm(dict_size, generator=g)[:n_in]
+        crops[b, :, : n * patch, : n * patch] = textures[ids[b]].reshape(n, n, 3, patch, patch).permute(2, 0, 3, 1, 4).reshape(3, n * patch, n * patch)
+    crops += pixel_noise * torch.randn(crops.shape, generator=g)
+    return crops.clamp_(0.0, 1.0), ids.reshape(batch, n, n)
+
+
 def make_disc_mask(size: int, rel_radius: float = 0.35) -> torch.Tensor:
     """uint8 [S,S]: centred disc of radius rel_radius*S (Q ~ 0.385*Np grid points)."""
     ys, xs = torch.meshgrid(torch.arange(size), torch.arange(size), indexing="ij")

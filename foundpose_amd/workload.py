@@ -2,13 +2,18 @@
 positives: each query crop's features = a known template's patch features + noise, so retrieval has a verifiable
 answer and decision margins"), plus the index-agreement statistics both report.
 
-With random-init ViT weights and noise crops a random bank gives every template the same near-zero score: top-5 lists
-and nearest neighbours are then decided by rounding noise and no two arithmetic modes can be compared.  Here the bank is
-made FROM the crops: the projected fp32 features of detection b are written (with graded noise) into five consecutive
-templates t_b .. t_b+4 of its object, their vertices come from a known pose (R_b, t_b) through a smooth depth surface,
-and every other template is a random mixture of patches of all detections.  The expected answer of the pipeline is then
-known -- templates t_b .. t_b+4 in that order, correspondences that satisfy the planted pose -- and the margins are set by
-the noise levels, not by chance.
+With random-init ViT weights, iid noise crops and a random bank nothing has a margin: every patch feature is equidistant
+from every other (measured: nearest other patch at 30.5, mean pairwise 34.3 -- tools/feature_stats.py), so the three
+nearest of 2048 visual words, the tf-idf histograms built on them and the top-5 template list are decided by rounding,
+and no two arithmetic modes can be compared.  Two things give the workload the structure real data has:
+  * crops are assembled from a dictionary of 682 patch textures (synthetic.make_dictionary_crops; distinct inside the
+    mask): a texture's feature is nearly the same wherever it appears, so features cluster, and the 2048 visual words are
+    three instances of every texture -- the tfidf_knn_k = 3 nearest words of a patch are its own texture's, with a margin;
+  * the bank is made FROM the crops: the projected fp32 features of detection b are written, with graded noise and as
+    nested, shrinking subsets, into five consecutive templates t_b .. t_b+4 of its object, their vertices come from a
+    known pose (R_b, t_b) through a smooth depth surface; every other template is a random set of textures.
+The expected answer of the pipeline is then known -- templates t_b .. t_b+4 in that order, correspondences that satisfy the
+planted pose -- and the margins are set by the construction, not by chance.
 
 Everything here is data generation and bookkeeping around the product path (it runs the extractor it is handed and the
 device bank builder); nothing imports oracle/.
@@ -22,7 +27,9 @@ import torch
 
 from . import bank_builder, feature_util, ops, projector_util, repre_util, synthetic
 
-PLANT_NOISE = (0.05, 0.2, 0.35, 0.5, 0.65)  # noise of templates t_b + r, in units of the feature std: graded scores
+PLANT_NOISE = (0.05, 0.15, 0.25, 0.35, 0.45)  # feature noise of templates t_b + r, in units of the feature std
+PLANT_PATCHES = (0.87, 0.81, 0.75, 0.69, 0.63)  # their patch counts as fractions of the detection's query patches (nested subsets)
+WORDS_PER_TEXTURE = 3   # = tfidf_knn_k of the shipped options: a patch's k nearest words are the instances of its texture
 
 
 @dataclass
@@ -81,12 +88,14 @@ def query_features(extractor, crops: torch.Tensor, masks: torch.Tensor, cell: fl
 
 
 def build_planted_workload(extractor, batch: int, size: int, num_objects: int, templates_per_object: int, feat_dim: int = 256,
-                           num_words: int = 2048, seed: int = 0, crop_seed: int = 0, min_patches: int = 300, max_patches: int = 450,
-                           noise: Sequence[float] = PLANT_NOISE, mask: Optional[torch.Tensor] = None) -> PlantedWorkload:
+                           num_words: int = 2048, seed: int = 0, crop_seed: int = 0, noise: Sequence[float] = PLANT_NOISE,
+                           patch_frac: Sequence[float] = PLANT_PATCHES, mask: Optional[torch.Tensor] = None) -> PlantedWorkload:
     """`extractor`: the extractor whose features are planted (use precision="fp32": the reference's arithmetic)."""
     dev = torch.device("cuda", torch.cuda.current_device())
-    crops = synthetic.make_crops(batch, size, seed=crop_seed).to(dev)
     m = synthetic.make_disc_mask(size) if mask is None else mask
+    n_tex = num_words // WORDS_PER_TEXTURE
+    crops_h, tex = synthetic.make_dictionary_crops(batch, size, m, n_tex, extractor.patch_size, seed=crop_seed)
+    crops = crops_h.to(dev)
     masks = m.unsqueeze(0).repeat(batch, 1, 1).to(dev)
     det_obj = sorted(i % num_objects for i in range(batch))
     g = torch.Generator().manual_seed(seed)
@@ -102,12 +111,34 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
     q_off = [0]
     for c in counts:
         q_off.append(q_off[-1] + c)
-    # a template holds a subset of a detection's patches: 300..450 of the 517 inside the disc mask at 518 px,
-    # the same proportions at smaller crops
     q_min = min(counts)
-    max_patches, min_patches = min(max_patches, int(0.87 * q_min)), min(min_patches, int(0.58 * q_min))
-    if min_patches < 1:
+    if int(patch_frac[-1] * q_min) < 1:
         raise ValueError(f"a detection has only {q_min} query patches")
+    # texture of every query patch (points are cell centres) and one instance of every texture seen: the visual words
+    ps = extractor.patch_size
+    cell = (pts[:, 1] / ps).long() * tex.shape[2] + (pts[:, 0] / ps).long()
+    det_of = torch.repeat_interleave(torch.arange(batch, device=dev), torch.tensor(counts, device=dev))
+    q_tex = tex.reshape(batch, -1).to(dev)[det_of, cell]                      # [sumQ]
+    order = torch.argsort(q_tex, stable=True)
+    st = q_tex[order]
+    start = torch.ones_like(st, dtype=torch.bool)
+    start[1:] = st[1:] != st[:-1]
+    grp_first = torch.cummax(torch.where(start, torch.arange(st.shape[0], device=dev), torch.zeros_like(st)), 0).values
+    rank = torch.arange(st.shape[0], device=dev) - grp_first                  # instance number of a row within its texture
+    seen_rows = order[start]                                                  # one instance of each texture present
+    # words: WORDS_PER_TEXTURE instances of every texture (from different crops); a texture seen fewer times gets jittered
+    # copies of its first instance, one never seen gets filler words far from every feature
+    words = 4.0 * sigma * torch.randn(num_words, feat_dim, generator=gd, device=dev)
+    first_of = torch.full((n_tex,), -1, dtype=torch.int64, device=dev)
+    first_of[st[start]] = seen_rows
+    have = first_of >= 0
+    for r in range(WORDS_PER_TEXTURE):
+        rows_r = order[rank == r]
+        w_r = words[r * n_tex:(r + 1) * n_tex]
+        w_r[have] = qf[first_of[have]] + 0.02 * sigma * torch.randn(int(have.sum()), feat_dim, generator=gd, device=dev)
+        w_r[q_tex[rows_r]] = qf[rows_r]
+    words = words.contiguous()
+    real_words = torch.cat([words[r * n_tex:(r + 1) * n_tex][have] for r in range(WORDS_PER_TEXTURE)])  # without the filler
 
     K = torch.tensor([[1.2 * size, 0.0, size / 2.0], [0.0, 1.2 * size, size / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
     R = _random_rotations(batch, g)
@@ -116,35 +147,40 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
 
     T = templates_per_object
     n_obj_det = [det_obj.count(o) for o in range(num_objects)]
-    if any(T < 8 * (n + 1) for n in n_obj_det):
+    if any(T < 8 * (n + 1) for n in n_obj_det):  # noqa
         raise ValueError("too few templates per object to plant five per detection")
+    lo, hi = max(1, int(0.58 * q_min)), max(1, int(0.87 * q_min))   # 300..450 patches per template at the 518 px disc mask
     targets = torch.zeros(batch, dtype=torch.int64)
     repres = []
     b_first = 0
     for o in range(num_objects):
         n_det = n_obj_det[o]
-        pcounts = torch.randint(min_patches, max_patches + 1, (T,), generator=g)
+        pcounts = torch.randint(lo, hi + 1, (T,), generator=g)
+        stride = T // (n_det + 1)
+        for j in range(n_det):  # patch counts of the planted templates: graded fractions of the detection's patches
+            for r, fr in enumerate(patch_frac):
+                pcounts[4 + j * stride + r] = max(1, int(fr * counts[b_first + j]))
         off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(pcounts, 0)])
         n_f = int(off[-1])
-        # every template starts as a random mixture of patches of all detections (same distribution as the queries)
-        src = torch.randint(0, qf.shape[0], (n_f,), generator=gd, device=dev)
-        feats = qf[src] + 0.5 * sigma * torch.randn(n_f, feat_dim, generator=gd, device=dev)
+        # every other template: a random set of textures, each as a noisy copy of one of its words (so every real word is
+        # some feature's nearest word and its idf = log(T / #templates) stays finite, template_util.py:94-102)
+        src = torch.randint(0, real_words.shape[0], (n_f,), generator=gd, device=dev)
+        feats = real_words[src] + 0.3 * sigma * torch.randn(n_f, feat_dim, generator=gd, device=dev)
         verts = torch.randn(n_f, 3, generator=gd, device=dev) * 50.0
-        stride = T // (n_det + 1)
         for j in range(n_det):
             b = b_first + j
             t_b = 4 + j * stride
             targets[b] = t_b
             qb, pb = qf[q_off[b]:q_off[b + 1]], pts[q_off[b]:q_off[b + 1]]
+            perm = torch.randperm(counts[b], generator=g)
             for r, nz in enumerate(noise):
                 tpl = t_b + r
                 P = int(pcounts[tpl])
-                sub = torch.randperm(counts[b], generator=g)[:P].sort().values.to(dev)
+                sub = perm[:P].sort().values.to(dev)   # nested: template r+1 holds a subset of template r's patches
                 rows = slice(int(off[tpl]), int(off[tpl]) + P)
                 feats[rows] = qb[sub] + nz * sigma * torch.randn(P, feat_dim, generator=gd, device=dev)
                 verts[rows] = planted_vertices(pb[sub], K, R[b], t[b]).to(dev)
         f2t = torch.repeat_interleave(torch.arange(T, dtype=torch.int32), pcounts).to(dev)
-        words = feats[torch.randperm(n_f, generator=g)[:num_words].to(dev)].clone()
         opts = repre_util.TemplateDescOpts()
         descs, idfs, f2c = bank_builder.calc_tfidf_descriptors(feats, f2t, words, T, opts)
         repres.append(repre_util.FeatureBasedObjectRepre(
