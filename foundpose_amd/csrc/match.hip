@@ -13,6 +13,7 @@
 #include "common.hpp"
 #include "kernels.hpp"
 #include "stl_order.hpp"
+#include "stl_wave.hpp"
 
 namespace {
 
@@ -169,6 +170,12 @@ typedef __attribute__((address_space(3))) void cos_lds_void;
 typedef __attribute__((address_space(1))) const void cos_gbl_cvoid;
 constexpr int COS_NMAX = 8;          // candidates kept per thread / emitted per (workgroup, detection)
 constexpr int COS_RED_PITCH = 68;    // floats per 16-lane group of a wave's score tile (64 + 4: de-phases the groups across banks)
+#ifndef FP_COS_SLOTS
+#define FP_COS_SLOTS 3               // ring depth per wave, 4-KiB chunks (measurement builds: 2 / 4)
+#endif
+constexpr int COS_SLOTS = FP_COS_SLOTS;
+constexpr int COS_RED_BUFS = COS_SLOTS <= 3 ? 2 : 1;  // a 4-slot ring leaves LDS for one reduction buffer (second barrier per block)
+constexpr int COS_RING_BYTES = 8 * COS_SLOTS * 4096;
 
 template <int NQ>
 __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
@@ -181,8 +188,8 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
   if (nd <= 0) return;  // block-uniform: no detection rows, nothing to emit
   const int wslice = a.W >> 3, nch = wslice >> 6;  // 64-word chunks per slice (1..4)
   const int i = lane & 15, g = lane >> 4;
-  char* ring = smem + wave * (3 * 4096);
-  float* red = reinterpret_cast<float*>(smem + 8 * 3 * 4096);
+  char* ring = smem + wave * (COS_SLOTS * 4096);
+  float* red = reinterpret_cast<float*>(smem + COS_RING_BYTES);
   constexpr int RED_SLICE = NQ * 4 * COS_RED_PITCH;  // floats per (buffer, slice)
 
   const int nblk = (T + 15) >> 4;
@@ -206,6 +213,9 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
   const float* slice_base = a.bank_n + (size_t)tb * a.W + wave * wslice;
   int it_blk = first, it_ch = 0, it_slot = 0;
   auto issue = [&]() {
+#ifdef FP_COS_NO_DMA
+    return;
+#endif
     const int t0 = it_blk * 16;
 #pragma unroll
     for (int q4 = 0; q4 < 4; ++q4) {
@@ -215,11 +225,11 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
       __builtin_amdgcn_global_load_lds((cos_gbl_cvoid*)src, (cos_lds_void*)(ring + it_slot * 4096 + q4 * 1024), 16, 0, 2 /* nt */);
     }
     if (++it_ch == nch) { it_ch = 0; it_blk += stride; }
-    it_slot = it_slot == 2 ? 0 : it_slot + 1;
+    it_slot = it_slot == COS_SLOTS - 1 ? 0 : it_slot + 1;
   };
-  if (total > 0) issue();
-  if (total > 1) issue();
-  if (total > 2) issue();
+#pragma unroll
+  for (int p = 0; p < COS_SLOTS; ++p)
+    if (total > p) issue();
 
   // reduce-phase role of this thread: detection rd (of the launch's NQ*16), template rt of the block
   const int rd = tid >> 4, rt = tid & 15;
@@ -239,15 +249,20 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
       if (ch < nch) {
         const int cc = task * nch + ch;
         // loads return in order: chunk cc has landed once at most the later chunks' DMAs are outstanding
-        if (cc + 2 < total) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (cc + 1 < total) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        const int ahead = total - 1 - cc < COS_SLOTS - 1 ? total - 1 - cc : COS_SLOTS - 1;  // chunks issued after this one
+#ifndef FP_COS_NO_DMA  // (measurement builds: the kernel without its bank stream)
+        if (ahead >= 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
         const char* cs = ring + slot * 4096 + i * 256;
         f32x4 av[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) av[j] = *reinterpret_cast<const f32x4*>(cs + (((4 * j + g) ^ i) << 4));
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the slot is handed back
-        if (cc + 3 < total) issue();
+        if (cc + COS_SLOTS < total) issue();
+#ifndef FP_COS_NO_MFMA  // (measurement builds, tools/cos_ablate.sh: the kernel without its matrix work)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // two alternating accumulator chains (NQ = 2)
 #pragma unroll
@@ -259,9 +274,20 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
 #pragma unroll
           for (int q = 0; q < NQ; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[j][3], qv[ch * 4 + j][q].w, acc[q], 0, 0, 0);
         }
-        slot = slot == 2 ? 0 : slot + 1;
+#else
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int q = 0; q < NQ; ++q) acc[q] += av[j] * f32x4{qv[ch * 4 + j][q].x, qv[ch * 4 + j][q].y, qv[ch * 4 + j][q].z, qv[ch * 4 + j][q].w};
+#endif
+        slot = slot == COS_SLOTS - 1 ? 0 : slot + 1;
       }
     }
+#ifdef FP_COS_NO_REDUCE  // (measurement builds: no slice reduction, no score store, no candidate lists)
+    if (acc[0][0] == 1234.5f) a.sims[tid] = acc[0][1];
+    blk += stride;
+    continue;
+#endif
     // ---- the block's eight slice sums meet in LDS: D[template 4g + r][detection q*16 + i] of this wave's slice
     float* mine = red + (buf * 8 + wave) * RED_SLICE;
 #pragma unroll
@@ -287,7 +313,8 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
         }
       }
     }
-    buf ^= 1;
+    if (COS_RED_BUFS == 2) buf ^= 1;
+    else __syncthreads();
     blk += stride;
   }
   // ---- the 16 lanes of a detection merge their lists: n_top candidate keys per (workgroup, detection)
@@ -411,12 +438,25 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __res
 // after each.  Element moves inside the heap are libstdc++'s, so the surviving order among ties is too.  Short rows
 // (n*64 > len) take nth_element + sort on one lane, as ATen does.
 constexpr int STRICT_SEG = 16384;  // floats per staged segment (64 KiB)
+
+// The n-element heap of the replay, element j in the registers of lane j: reading heap[j] is a v_readlane, writing it a
+// predicated move -- a pop_heap costs ~100 cycles instead of the ~1000 of dependent LDS round trips.
+struct LaneHeap {
+  float v;
+  int idx;
+  int lane;
+  __device__ __forceinline__ stl_order::Elem get(int i) const {
+    return stl_order::Elem{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), i)), __builtin_amdgcn_readlane(idx, i)};
+  }
+  __device__ __forceinline__ void set(int i, const stl_order::Elem& e) {
+    if (lane == i) { v = e.v; idx = e.idx; }
+  }
+};
+
 __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
                                                                int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float* seg = reinterpret_cast<float*>(smem_raw);
-  __shared__ stl_order::Elem heap_s[64];
-  volatile stl_order::Elem* heap_v = heap_s;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int len = row_len ? row_len[row] : n_default;
   const float* r = vals + (size_t)row * ld;
@@ -433,24 +473,36 @@ __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __re
     }
     return;
   }
+  LaneHeap heap{0.f, 0, lane};
   for (int s0 = 0; s0 < len; s0 += STRICT_SEG) {
     const int s1 = min(len, s0 + STRICT_SEG);
     __syncthreads();  // the previous segment has no readers left
-    for (int j = s0 + tid * 4; j < s1; j += 1024) {
-      if (j + 4 <= s1 && ((ld & 3) == 0)) {
-        *reinterpret_cast<float4*>(seg + (j - s0)) = *reinterpret_cast<const float4*>(r + j);
-      } else {
-        for (int e = 0; e < 4 && j + e < s1; ++e) seg[j - s0 + e] = r[j + e];
+    // the scores were written by other XCDs a moment ago: every load is a trip to the Infinity Cache, so a thread puts
+    // eight 16-B loads in flight before it stores the first one (one load at a time cost 10 round trips per row)
+    if ((ld & 3) == 0) {
+      for (int j0 = s0 + tid * 4; j0 < s1; j0 += 8 * 1024) {
+        float4 t[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * 1024;
+          t[u] = j + 4 <= s1 ? *reinterpret_cast<const float4*>(r + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int j = j0 + u * 1024;
+          if (j + 4 <= s1) *reinterpret_cast<float4*>(seg + (j - s0)) = t[u];
+        }
       }
+      for (int j = (s1 & ~3) + tid; j < s1; j += 256) seg[j - s0] = r[j];  // ragged end of the row
+    } else {
+      for (int j = s0 + tid; j < s1; j += 256) seg[j - s0] = r[j];
     }
     __syncthreads();
-    if (tid < 64) {
+    if (tid < 64) {  // wave 0 replays; the other waves only stage
       int c0 = s0;
-      if (s0 == 0) {  // std::make_heap over the first k elements
-        if (lane == 0) {
-          for (int j = 0; j < k; ++j) heap_s[j] = stl_order::Elem{seg[j], j};
-          stl_order::make_heap_(heap_s, k);
-        }
+      if (s0 == 0) {  // std::make_heap over the first k elements (k <= 64 = one per lane)
+        if (lane < k) { heap.v = seg[lane]; heap.idx = lane; }
+        stl_order::make_heap_acc(heap, k);
         c0 = k;
       }
       for (; c0 < s1; c0 += 256) {
@@ -462,38 +514,31 @@ __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __re
           ok[e] = j < s1;
           v[e] = ok[e] ? seg[j - s0] : 0.f;
         }
-        stl_order::Elem top{heap_v[0].v, 0};
-        unsigned long long m[4];
+        stl_order::Elem top = heap.get(0);
         bool any = false;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          m[e] = __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
-          any |= m[e] != 0;
-        }
+        for (int e = 0; e < 4; ++e) any |= __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top)) != 0;
         if (!any) continue;  // wave-uniform: nothing in these 256 elements beats the root
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          unsigned long long me = e == 0 ? m[0] : __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
+          unsigned long long me = __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
           while (me) {
             const int l = __builtin_ctzll(me);
-            const float vl = __shfl(v[e], l, 64);
-            if (lane == 0) {
-              stl_order::Elem x{vl, c0 + 64 * e + l};
-              stl_order::pop_heap_(heap_s, k, &x);  // __pop_heap(first, middle, i): the old root leaves, *i enters
-            }
-            top.v = heap_v[0].v;
+            const stl_order::Elem x{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), l)), c0 + 64 * e + l};
+            stl_order::adjust_heap_acc(heap, 0, k, x);  // __pop_heap(first, middle, i): the old root leaves, *i enters
+            top = heap.get(0);
             me = __ballot(ok[e] && lane > l && stl_order::gt(stl_order::Elem{v[e], 0}, top));
           }
         }
       }
     }
   }
-  __syncthreads();
-  if (tid == 0) stl_order::sort_heap_(heap_s, k);
-  __syncthreads();
-  if (tid < n_top) {
-    out_idx[(size_t)row * n_top + tid] = tid < k ? heap_s[tid].idx : -1;
-    out_val[(size_t)row * n_top + tid] = tid < k ? heap_s[tid].v : -INFINITY;
+  if (tid < 64) {
+    stl_order::sort_heap_acc(heap, k);
+    if (lane < n_top) {
+      out_idx[(size_t)row * n_top + lane] = lane < k ? heap.idx : -1;
+      out_val[(size_t)row * n_top + lane] = lane < k ? heap.v : -INFINITY;
+    }
   }
 }
 
@@ -586,6 +631,8 @@ FP_DEVICE float point_dist(float x1, float y1, float x2, float y2) {
 __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   __shared__ unsigned long long keys[2048];
   __shared__ int q2o_s[2048];
+  __shared__ unsigned short lpos_s[2048], rpos_s[2048];  // strict mode: stopper ranks of the wave-parallel partition
+  __shared__ stl_order::Elem tmp_s[2048];                // strict mode: target of the final stable placement
   const int pair = blockIdx.x, tid = threadIdx.x;
   const int det = pair / a.n_slots;
   const int q0 = a.q_off[det], Q = a.q_off[det + 1] - q0;
@@ -612,15 +659,15 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   }
   __syncthreads();
   if (a.tie_mode == 1) {
-    // strict mode: the reference's torch.topk(-cycle_dists, k) order, ties included -- one lane replays
-    // libstdc++'s nth_element + sort (or partial_sort) on (value, index) pairs held in LDS
+    // strict mode: the reference's torch.topk(-cycle_dists, k) order, ties included -- one wave replays
+    // libstdc++'s nth_element + sort (or partial_sort) on (value, index) pairs held in LDS (stl_wave.hpp)
     stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(keys);
     for (int i = tid; i < Q; i += 256) {
       const unsigned long long key = keys[i];  // each thread converts only the slots it reads itself
       el[i] = stl_order::Elem{-__uint_as_float((unsigned)(key >> 32)), i};
     }
     __syncthreads();
-    if (tid == 0) stl_order::topk_torch_largest(el, Q, kk);
+    if (tid < 64) stl_wave::topk_torch_largest(el, Q, kk, lpos_s, rpos_s, tmp_s, tid);
     __syncthreads();
     for (int i = tid; i < kk; i += 256) {  // back to (distance bits, query id) keys in output order
       const stl_order::Elem e = el[i];
@@ -831,10 +878,10 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     const int gx = per < 1 ? 1 : (per > nblk ? nblk : per);
     a.n_top = n_top;
     if (!want_cand) a.cand = nullptr;
-    const size_t lds = 8 * 3 * 4096 + (size_t)2 * 8 * nq * 4 * COS_RED_PITCH * 4;
+    const size_t lds = COS_RING_BYTES + (size_t)COS_RED_BUFS * 8 * nq * 4 * COS_RED_PITCH * 4;
     static FpDeviceOnce attr1, attr2;
-    fp_allow_dynamic_lds(attr1, &cosine_fused_kernel<1>, 8 * 3 * 4096 + 2 * 8 * 1 * 4 * COS_RED_PITCH * 4);
-    fp_allow_dynamic_lds(attr2, &cosine_fused_kernel<2>, 8 * 3 * 4096 + 2 * 8 * 2 * 4 * COS_RED_PITCH * 4);
+    fp_allow_dynamic_lds(attr1, &cosine_fused_kernel<1>, COS_RING_BYTES + COS_RED_BUFS * 8 * 1 * 4 * COS_RED_PITCH * 4);
+    fp_allow_dynamic_lds(attr2, &cosine_fused_kernel<2>, COS_RING_BYTES + COS_RED_BUFS * 8 * 2 * 4 * COS_RED_PITCH * 4);
     dim3 grid(gx, num_obj, chunks);
     if (nq == 1) hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);

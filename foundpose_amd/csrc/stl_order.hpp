@@ -44,43 +44,77 @@ FP_HD int lg2(int n) {  // floor(log2(n)), n >= 1
   return r;
 }
 
-// ---- heap primitives (max-heap w.r.t. `gt` as "less": the root is the WORST of the kept elements)
-FP_HD void push_heap_(Elem* a, int hole, int top, Elem value) {
+// ---- heap primitives (max-heap w.r.t. `gt` as "less": the root is the WORST of the kept elements).  Written over an
+// accessor (get / set by index) so the same moves run on an array in memory and on a heap whose element j lives in the
+// registers of lane j of a wavefront (match.hip: the strict top-n keeps its n-element heap there).
+struct PtrAcc {
+  Elem* p;
+  FP_HD Elem get(int i) const { return p[i]; }
+  FP_HD void set(int i, const Elem& e) const { p[i] = e; }
+};
+
+template <class A>
+FP_HD void push_heap_acc(A& a, int hole, int top, Elem value) {
   int parent = (hole - 1) / 2;
-  while (hole > top && gt(a[parent], value)) {
-    a[hole] = a[parent];
+  while (hole > top && gt(a.get(parent), value)) {
+    a.set(hole, a.get(parent));
     hole = parent;
     parent = (hole - 1) / 2;
   }
-  a[hole] = value;
+  a.set(hole, value);
 }
 
-FP_HD void adjust_heap_(Elem* a, int hole, int len, Elem value) {
+template <class A>
+FP_HD void adjust_heap_acc(A& a, int hole, int len, Elem value) {
   const int top = hole;
   int child = hole;
   while (child < (len - 1) / 2) {
     child = 2 * (child + 1);
-    if (gt(a[child], a[child - 1])) --child;
-    a[hole] = a[child];
+    if (gt(a.get(child), a.get(child - 1))) --child;
+    a.set(hole, a.get(child));
     hole = child;
   }
   if ((len & 1) == 0 && child == (len - 2) / 2) {
     child = 2 * (child + 1);
-    a[hole] = a[child - 1];
+    a.set(hole, a.get(child - 1));
     hole = child - 1;
   }
-  push_heap_(a, hole, top, value);
+  push_heap_acc(a, hole, top, value);
 }
 
-FP_HD void make_heap_(Elem* a, int len) {
+template <class A>
+FP_HD void make_heap_acc(A& a, int len) {
   if (len < 2) return;
   int parent = (len - 2) / 2;
   while (true) {
-    const Elem value = a[parent];
-    adjust_heap_(a, parent, len, value);
+    const Elem value = a.get(parent);
+    adjust_heap_acc(a, parent, len, value);
     if (parent == 0) return;
     --parent;
   }
+}
+
+template <class A>
+FP_HD void sort_heap_acc(A& a, int len) {
+  while (len > 1) {
+    --len;
+    const Elem value = a.get(len);  // __pop_heap(first, last, last): the root moves to the end, the old end re-enters
+    a.set(len, a.get(0));
+    adjust_heap_acc(a, 0, len, value);
+  }
+}
+
+FP_HD void push_heap_(Elem* a, int hole, int top, Elem value) {
+  PtrAcc acc{a};
+  push_heap_acc(acc, hole, top, value);
+}
+FP_HD void adjust_heap_(Elem* a, int hole, int len, Elem value) {
+  PtrAcc acc{a};
+  adjust_heap_acc(acc, hole, len, value);
+}
+FP_HD void make_heap_(Elem* a, int len) {
+  PtrAcc acc{a};
+  make_heap_acc(acc, len);
 }
 
 // pop the root of heap a[0, len) into *result (result may be outside the heap)
@@ -97,10 +131,8 @@ FP_HD void heap_select_(Elem* a, int middle, int last) {
 }
 
 FP_HD void sort_heap_(Elem* a, int len) {
-  while (len > 1) {
-    --len;
-    pop_heap_(a, len, &a[len]);
-  }
+  PtrAcc acc{a};
+  sort_heap_acc(acc, len);
 }
 
 FP_HD void partial_sort_(Elem* a, int middle, int last) {
