@@ -363,6 +363,101 @@ def gen_lift(ref):
     print("lift_3d.npz", v_model.shape)
 
 
+WRAP = dict(T=12, d=64, pmin=20, pmax=30, W=32, raw=96, tpl=5, bank_seed=31, q_seed=33)
+
+
+def build_wrapper_inputs():
+    """Deterministic inputs of the row-R / wrapper fixture (shared by the generator and the tests)."""
+    c = WRAP
+    bank = synthetic.make_bank_features(c["T"], c["d"], c["pmin"], c["pmax"], seed=c["bank_seed"])
+    centroids = synthetic.pick_centroids(bank["feat_vectors"], c["W"], seed=c["bank_seed"] + 1)
+    pts, feats = synthetic.make_planted_query(bank, c["tpl"], 37, seed=c["q_seed"], noise=0.05)
+    g = torch.Generator().manual_seed(c["q_seed"] + 1)
+    raw_train = torch.randn(400, c["raw"], generator=g) * (torch.arange(1, c["raw"] + 1, dtype=torch.float32) ** -0.5)
+    raw_query = torch.randn(pts.shape[0], c["raw"], generator=g)
+    return bank, centroids, pts.contiguous(), feats.contiguous(), raw_train, raw_query
+
+
+def gen_wrappers(ref):
+    """Row R and the standalone wrappers: a `repre.pth` written by the reference's own save_object_repre (a data file:
+    tensors, option dicts, camera dicts) and the outputs of the reference's find_nearest_object_features, calc_tfidf,
+    tfidf_matching, cyclic_buddies_matching, KNN(metric="cosine"), PCAProjector.transform and establish_correspondences
+    on the representation its load_object_repre reads back."""
+    import importlib
+    structs = importlib.import_module("utils.structs")
+    c = WRAP
+    bank, centroids, pts, feats, raw_train, raw_query = build_wrapper_inputs()
+    T = c["T"]
+    opts = ref.repre_util.TemplateDescOpts()
+    words_index = ref.knn_util.KNN(k=1, metric="l2")
+    words_index.fit(centroids)
+    f2c = words_index.search(bank["feat_vectors"])[1][:, 0].to(torch.int32)
+    descs, idfs = ref.template_util.calc_tfidf_descriptors(
+        feat_vectors=bank["feat_vectors"], feat_to_word_ids=f2c, feat_to_template_ids=bank["feat_to_template_ids"], feat_words=centroids,
+        num_templates=T, tfidf_knn_k=opts.tfidf_knn_k, tfidf_soft_assign=opts.tfidf_soft_assign, tfidf_soft_sigma_squared=opts.tfidf_soft_sigma_squared)
+    proj = ref.projector_util.PCAProjector(n_components=c["d"])
+    proj.fit(raw_train)
+    g = torch.Generator().manual_seed(77)
+    cams = []
+    for t in range(T):
+        Tw = np.eye(4)
+        Tw[:3, :3] = np.linalg.qr(torch.randn(3, 3, generator=g).numpy().astype(np.float64))[0]
+        Tw[:3, 3] = [10.0 * t, -5.0, 400.0 + t]
+        cams.append(structs.PinholePlaneCameraModel(width=420, height=420, f=(600.0 + t, 601.0), c=(210.0, 209.5), T_world_from_eye=Tw))
+    repre = ref.repre_util.FeatureBasedObjectRepre(
+        vertices=bank["vertices"], feat_vectors=bank["feat_vectors"], feat_opts=ref.repre_util.FeatureOpts(extractor_name="dinov2_vits14-reg"),
+        feat_to_vertex_ids=bank["feat_to_vertex_ids"], feat_to_template_ids=bank["feat_to_template_ids"], feat_to_cluster_ids=f2c,
+        feat_cluster_centroids=centroids, feat_cluster_idfs=idfs, feat_raw_projectors=[proj], feat_vis_projectors=[],
+        template_cameras_cam_from_model=cams, template_descs=descs, template_desc_opts=opts)
+    rdir = os.path.join(OUT, "repre_ref")
+    os.makedirs(rdir, exist_ok=True)
+    ref.repre_util.save_object_repre(repre, rdir)
+    loaded = ref.repre_util.load_object_repre(rdir, tensor_device="cpu")
+
+    vw = ref.knn_util.KNN(k=opts.tfidf_knn_k, metric=opts.tfidf_knn_metric)
+    vw.fit(loaded.feat_cluster_centroids)
+    word_ids, word_dists = ref.template_util.find_nearest_object_features(query_features=feats, knn_index=vw)
+    tfidf_hard = ref.template_util.calc_tfidf(word_ids, word_dists, loaded.feat_cluster_idfs, soft_assignment=False, soft_sigma_squared=10.0)
+    tfidf_soft = ref.template_util.calc_tfidf(word_ids, word_dists, loaded.feat_cluster_idfs, soft_assignment=True, soft_sigma_squared=10.0)
+    tm_ids, tm_scores = ref.template_util.tfidf_matching(feats, loaded, 5, vw)
+    tpl_rows = torch.nonzero(loaded.feat_to_template_ids == c["tpl"]).flatten()
+    obj_feats = loaded.feat_vectors[tpl_rows]
+    q_index, o_index = ref.knn_util.KNN(k=1, metric="l2"), ref.knn_util.KNN(k=1, metric="l2")
+    q_index.fit(feats)
+    o_index.fit(obj_feats)
+    cb = ref.corresp_util.cyclic_buddies_matching(query_points=pts, query_features=feats, query_knn_index=q_index,
+                                                  object_features=obj_feats, object_knn_index=o_index, top_k=10, debug=False)
+    cos = ref.knn_util.KNN(k=3, metric="cosine")
+    cos.fit(loaded.feat_vectors)
+    cos_d, cos_i = cos.search(feats)
+    projected = ref.projector_util.project_features(raw_query, loaded.feat_raw_projectors)
+    tpl_idx = []
+    for t in range(T):
+        idx = ref.knn_util.KNN(k=1, metric="l2")
+        idx.fit(loaded.feat_vectors[torch.nonzero(loaded.feat_to_template_ids == t).flatten()])
+        tpl_idx.append(idx)
+    corresp = ref.corresp_util.establish_correspondences(
+        query_points=pts, query_features=feats, object_repre=loaded, template_matching_type="tfidf", feat_matching_type="cyclic_buddies",
+        top_n_templates=5, top_k_buddies=300, visual_words_knn_index=vw, template_knn_indices=tpl_idx, debug=True)
+    out = {
+        "input_checksum": checksum(bank["feat_vectors"], centroids, pts, feats, raw_train, raw_query),
+        "word_ids": t2n(word_ids).astype(np.int64), "word_dists": t2n(word_dists), "tfidf_hard": t2n(tfidf_hard), "tfidf_soft": t2n(tfidf_soft),
+        "tm_ids": t2n(tm_ids).astype(np.int64), "tm_scores": t2n(tm_scores),
+        "cb_query_ids": t2n(cb[0]).astype(np.int64), "cb_object_ids": t2n(cb[1]).astype(np.int64), "cb_dists": t2n(cb[2]), "cb_scores": t2n(cb[3]),
+        "cos_dists": t2n(cos_d), "cos_ids": t2n(cos_i).astype(np.int64), "projected": t2n(projected),
+        "template_ids": np.array([int(cc["template_id"]) for cc in corresp], np.int64),
+        "template_scores": np.array([float(cc["template_score"]) for cc in corresp], np.float32),
+        "cam0_f": np.asarray(loaded.template_cameras_cam_from_model[3].f, np.float64), "cam0_T": np.asarray(loaded.template_cameras_cam_from_model[3].T_world_from_eye, np.float64),
+    }
+    for i, cc in enumerate(corresp):
+        out[f"coord_2d_ids_{i}"] = t2n(cc["coord_2d_ids"]).astype(np.int64)
+        out[f"nn_vertex_ids_{i}"] = t2n(cc["nn_vertex_ids"]).astype(np.int64)
+        out[f"coord_3d_{i}"] = t2n(cc["coord_3d"]).astype(np.float32)
+        out[f"coord_conf_{i}"] = t2n(cc["coord_conf"]).astype(np.float32)
+    np.savez_compressed(os.path.join(OUT, "wrappers.npz"), **out)
+    print("wrappers.npz templates", out["template_ids"], "repre.pth bytes", os.path.getsize(os.path.join(rdir, "repre.pth")))
+
+
 def main():
     if not ref_shim.reference_available():
         sys.exit("reference not present; fixtures can only be generated in the build container")
@@ -374,6 +469,7 @@ def main():
     gen_hot_section(ref)
     gen_crop(ref)
     gen_lift(ref)
+    gen_wrappers(ref)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,87 @@
+"""The drop-in functions with the reference's public signatures against outputs of the reference's
+own functions, captured in tests/golden/wrappers.npz on the representation the reference wrote to and read back from
+tests/golden/repre_ref/repre.pth.  Index work must be identical; fp32 values within the stated tolerances."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd import corresp_util, knn_util, projector_util, repre_util, template_util
+from oracle.make_golden import WRAP, build_wrapper_inputs
+from tests.helpers import GOLDEN, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def case():
+    g = load_golden("wrappers")
+    repre = repre_util.load_object_repre(os.path.join(GOLDEN, "repre_ref"))  # the file the reference wrote
+    _, _, pts, feats, _, raw_query = build_wrapper_inputs()
+    return g, repre, pts, feats, raw_query
+
+
+def test_find_nearest_object_features_and_calc_tfidf(case):
+    g, repre, pts, feats, _ = case
+    vw = knn_util.KNN(k=repre.template_desc_opts.tfidf_knn_k, metric=repre.template_desc_opts.tfidf_knn_metric)
+    vw.fit(repre.feat_cluster_centroids)
+    ids, dists = template_util.find_nearest_object_features(query_features=feats, knn_index=vw)
+    assert ids.dtype == torch.int64 and not ids.is_cuda  # CPU in -> CPU out, like the reference
+    assert np.array_equal(ids.numpy(), g["word_ids"])
+    np.testing.assert_allclose(dists.numpy(), g["word_dists"], rtol=2e-6, atol=1e-6)
+    hard = template_util.calc_tfidf(ids, dists, repre.feat_cluster_idfs, soft_assignment=False, soft_sigma_squared=10.0)
+    soft = template_util.calc_tfidf(ids, dists, repre.feat_cluster_idfs, soft_assignment=True, soft_sigma_squared=10.0)
+    np.testing.assert_allclose(hard.numpy(), g["tfidf_hard"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(soft.numpy(), g["tfidf_soft"], rtol=0, atol=1e-6)
+
+
+def test_tfidf_matching_and_template_matching(case):
+    g, repre, pts, feats, _ = case
+    ids, scores = template_util.tfidf_matching(feats, repre, 5)
+    assert ids.tolist() == g["tm_ids"].tolist()
+    np.testing.assert_allclose(scores.numpy(), g["tm_scores"], rtol=0, atol=2e-6)
+    ids2, _ = template_util.template_matching(feats, repre, 5, "tfidf")
+    assert ids2.tolist() == g["tm_ids"].tolist()
+    with pytest.raises(ValueError, match="Unknown matching type"):
+        template_util.template_matching(feats, repre, 5, "nearest")
+
+
+def test_cyclic_buddies_matching_standalone(case):
+    g, repre, pts, feats, _ = case
+    rows = torch.nonzero(repre.feat_to_template_ids == WRAP["tpl"]).flatten()
+    obj_feats = repre.feat_vectors[rows]
+    q_ids, o_ids, dists, scores = corresp_util.cyclic_buddies_matching(
+        query_points=pts, query_features=feats, query_knn_index=None, object_features=obj_feats, object_knn_index=None, top_k=10, debug=False)
+    assert q_ids.tolist() == g["cb_query_ids"].tolist()      # the reference's torch.topk order, ties included
+    assert o_ids.tolist() == g["cb_object_ids"].tolist()
+    assert np.array_equal(dists.numpy(), g["cb_dists"])
+    np.testing.assert_allclose(scores.numpy(), g["cb_scores"], rtol=0, atol=1e-7, equal_nan=True)
+
+
+def test_knn_cosine_metric(case):
+    g, repre, pts, feats, _ = case
+    cos = knn_util.KNN(k=3, metric="cosine")
+    cos.fit(repre.feat_vectors)
+    d, i = cos.search(feats)
+    assert np.array_equal(i.numpy(), g["cos_ids"])
+    np.testing.assert_allclose(d.numpy(), g["cos_dists"], rtol=0, atol=3e-6)
+
+
+def test_projector_from_reference_tensordict(case):
+    g, repre, pts, feats, raw_query = case
+    got = projector_util.project_features(raw_query.cuda(), repre.feat_raw_projectors)
+    assert got.is_cuda
+    np.testing.assert_allclose(got.cpu().numpy(), g["projected"], rtol=0, atol=2e-5 * np.abs(g["projected"]).max())
+
+
+def test_establish_correspondences_on_the_loaded_repre(case):
+    g, repre, pts, feats, _ = case
+    got = corresp_util.establish_correspondences(pts, feats, repre, "tfidf", "cyclic_buddies", 5, 300)
+    assert [int(c["template_id"]) for c in got] == g["template_ids"].tolist()
+    np.testing.assert_allclose([float(c["template_score"]) for c in got], g["template_scores"], rtol=0, atol=2e-6)
+    for i, c in enumerate(got):
+        assert np.array_equal(c["coord_2d_ids"].cpu().numpy(), g[f"coord_2d_ids_{i}"])
+        assert np.array_equal(c["nn_vertex_ids"].cpu().numpy(), g[f"nn_vertex_ids_{i}"])
+        assert np.array_equal(c["coord_3d"].cpu().numpy(), g[f"coord_3d_{i}"])
+        np.testing.assert_allclose(c["coord_conf"].cpu().numpy(), g[f"coord_conf_{i}"], rtol=0, atol=1e-7, equal_nan=True)
