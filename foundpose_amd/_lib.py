@@ -13,9 +13,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 8
+ABI_VERSION = 9
 
-vp, i32, i64, f32 = C.c_void_p, C.c_int, C.c_int64, C.c_float
+vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
 
 class VitBlock(C.Structure):
@@ -50,6 +50,7 @@ _PROTOS = {
     "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp],
     "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32,
                           vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "fp_pnp_ransac": [vp, vp, vp, vp, i32, i32, i32, i32, f64, f64, i32, i32, u64, vp, vp, vp, vp, vp, vp, vp],
     "fp_sample_bilinear": [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
     "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],

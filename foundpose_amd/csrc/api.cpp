@@ -170,6 +170,23 @@ int fp_pca_project(const float* x, int n, int D, const float* components, int d,
   return f32_tile_launch(mean_proj ? F32_EPI_SUB_VEC : F32_EPI_STORE, a, n, d, 1, ST(stream));
 }
 
+int fp_pnp_ransac(const float* coord_2d, const float* coord_3d, const int32_t* counts, const double* cameras, int num_pairs, int n_slots,
+                  int k_max, int ransac_iters, double inlier_thresh, double confidence, int lm_iters, int min_corresp, uint64_t seed,
+                  int32_t* out_success, double* out_R, double* out_t, int32_t* out_num_inliers, uint8_t* out_inlier_mask,
+                  double* out_ransac_pose, fp_stream_t stream) {
+  FP_REQUIRE(coord_2d && coord_3d && counts && cameras && out_success && out_R && out_t && out_num_inliers && out_inlier_mask,
+             "fp_pnp_ransac: null pointer");
+  FP_REQUIRE(num_pairs >= 0 && n_slots >= 1 && num_pairs % n_slots == 0, "fp_pnp_ransac: num_pairs must be a multiple of n_slots");
+  PnpArgs a;
+  memset(&a, 0, sizeof(a));
+  a.coord_2d = coord_2d; a.coord_3d = coord_3d; a.counts = counts; a.cam = cameras;
+  a.n_slots = n_slots; a.k_max = k_max; a.iters = ransac_iters; a.lm_iters = lm_iters; a.min_corresp = min_corresp;
+  a.thresh = inlier_thresh; a.conf = confidence; a.seed = seed;
+  a.success = out_success; a.R = out_R; a.t = out_t; a.n_inliers = out_num_inliers; a.inlier_mask = out_inlier_mask;
+  a.ransac_pose = out_ransac_pose;
+  return launch_pnp_ransac(a, num_pairs, ST(stream));
+}
+
 // ------------------------------------------------------------------ ViT building blocks
 int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
                 fp_stream_t stream) {

@@ -154,3 +154,21 @@ int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_de
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
 int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
                      int* out_ids, int tie_mode, hipStream_t st);
+
+// ---------------------------------------------------------------- pnp.hip
+struct PnpArgs {
+  const float* coord_2d;   // [pairs, k_max, 2] pixels
+  const float* coord_3d;   // [pairs, k_max, 3] model space
+  const int* counts;       // [pairs] valid correspondences per pair
+  const double* cam;       // [pairs / n_slots, 4] fx, fy, cx, cy of each detection's (crop) camera
+  int n_slots, k_max, iters, lm_iters, min_corresp;
+  double thresh, conf;
+  unsigned long long seed;
+  int* success;            // [pairs]
+  double* R;               // [pairs, 9] row-major model -> camera
+  double* t;               // [pairs, 3]
+  int* n_inliers;          // [pairs] RANSAC inliers of the winning model (= the reference's `quality`)
+  unsigned char* inlier_mask;  // [pairs, k_max]
+  double* ransac_pose;     // [pairs, 12] the winning model before refinement (R | t), may be null
+};
+int launch_pnp_ransac(const PnpArgs& a, int num_pairs, hipStream_t st);

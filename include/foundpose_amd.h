@@ -26,7 +26,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 8
+#define FP_ABI_VERSION 9
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -95,6 +95,23 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
                       void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
                       float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d, int tie_mode,
                       fp_stream_t stream);
+
+/* Coarse pose of every (detection, template slot) pair from its 2D-3D correspondences: estimate_pose
+ * (utils/pnp_util.py:20-84 = cv2.solvePnPRansac(..., SOLVEPNP_ITERATIVE) + cv2.solvePnPRefineLM on the inliers), the call
+ * scripts/infer.py:552-580 makes once per retrieved template.  Inputs are fp_cyclic_buddies' padded outputs: coord_2d
+ * [num_pairs, k_max, 2], coord_3d [num_pairs, k_max, 3], counts [num_pairs]; cameras [num_pairs / n_slots, 4] f64 =
+ * (fx, fy, cx, cy) of each detection's crop camera.  RANSAC over `ransac_iters` P3P hypotheses (3 points + 1 to choose
+ * among the solutions), inlier = reprojection error <= inlier_thresh px, the first model with the most inliers inside the
+ * adaptively shortened budget (confidence) wins, then <= lm_iters Levenberg-Marquardt iterations on its inliers (20 for
+ * the refinement inside solvePnPRansac, +20 with pnp_refine_lm).  Pairs with fewer than min_corresp (6, infer.py:556)
+ * correspondences or without a model fail (success 0).  Outputs: success, R [.,9] row-major and t [.,3] (model ->
+ * camera, f64), the RANSAC inlier count (the reference's `quality`), the inlier mask [., k_max], and (may be null) the
+ * winning model before refinement [., 12].  cv2's own arithmetic and random stream are not reproduced (cv2 is not
+ * available to pin them): same scheme, different minimal solver and sampler -- see csrc/pnp.hip. */
+int fp_pnp_ransac(const float* coord_2d, const float* coord_3d, const int32_t* counts, const double* cameras, int num_pairs, int n_slots,
+                  int k_max, int ransac_iters, double inlier_thresh, double confidence, int lm_iters, int min_corresp, uint64_t seed,
+                  int32_t* out_success, double* out_R, double* out_t, int32_t* out_num_inliers, uint8_t* out_inlier_mask,
+                  double* out_ransac_pose, fp_stream_t stream);
 
 /* sample_feature_map_at_points (utils/feature_util.py:100-131): bilinear grid_sample, zeros padding,
  * align_corners=False.  fmap addressed by element strides (image, channel, y, x); point_img (may be null)
