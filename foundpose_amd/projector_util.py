@@ -47,7 +47,10 @@ class PCAProjector(Projector):
         if n < 2 or self.n_components > min(n, D):
             raise ValueError(f"cannot fit {self.n_components} components on {n} samples of {D} dims")
         mean = x.mean(dim=0)
-        xc_t = (x - mean).t().contiguous()                      # [D, n]: rows = dims, the GEMM's K runs over samples
+        xc = x - mean
+        if n % 4:  # the tile kernel wants K % 4 == 0: all-zero (centred) samples add nothing to the Gram matrix
+            xc = torch.cat([xc, torch.zeros(4 - n % 4, D, dtype=xc.dtype, device=xc.device)])
+        xc_t = xc.t().contiguous()                              # [D, n]: rows = dims, the GEMM's K runs over samples
         cov = ops.gemm_f32(xc_t, xc_t) / float(n - 1)           # exact-fp32 MFMA chains, k ascending
         evals, evecs = torch.linalg.eigh(cov.double().cpu())    # ascending
         evals = evals.flip(0).clamp_min(0.0)

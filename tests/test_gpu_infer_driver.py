@@ -1,0 +1,89 @@
+"""The driver end to end on a synthetic scene (/root/reference/scripts/infer.py:55-100, 290-816,
+utils/infer_pose_util.py:24-151, utils/eval_util.py:231-355, scripts/prepare_bop_submission.py:63-99): options JSON in the
+reference's format, CNOS-format detections with RLE masks, a `repre.pth` bank on disk, frames -> `estimated-poses.json` and
+the BOP19 csv, with the pose of each instance checked against the pose its bank was planted with."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd import bank_builder, crop_util, feature_util, infer, infer_pose_util, repre_util, workload
+
+pytestmark = pytest.mark.gpu
+NAME = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1"
+
+
+def test_infer_driver_synthetic_scene(tmp_path):
+    g = torch.Generator().manual_seed(0)
+    H, W = 480, 640
+    image = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy()
+    cam = crop_util.PinholePlaneCameraModel(W, H, (600.0, 600.0), (320.0, 240.0), np.eye(4))
+    boxes_xywh = [[100, 80, 180, 160], [380, 220, 150, 190]]
+    masks = np.zeros((2, H, W), np.uint8)
+    for b, (x, y, w, h) in enumerate(boxes_xywh):
+        masks[b, y + 10:y + h - 10, x + 10:x + w - 10] = 1
+    dets = [{"scene_id": 1, "image_id": 3, "category_id": 1, "bbox": boxes_xywh[b], "score": 0.9 - 0.1 * b, "time": 0.25,
+             "segmentation": infer_pose_util.binary_mask_to_rle(masks[b])} for b in range(2)]
+    dets.append({"scene_id": 1, "image_id": 3, "category_id": 2, "bbox": [0, 0, 10, 10], "score": 0.5, "time": 0.25,
+                 "segmentation": infer_pose_util.binary_mask_to_rle(np.zeros((H, W), np.uint8))})  # another object: ignored
+    det_path = tmp_path / "cnos.json"
+    det_path.write_text(json.dumps(dets))
+    opts_path = tmp_path / "opts.json"
+    opts_path.write_text(json.dumps({"infer_opts": {
+        "version": "v1", "object_dataset": "synth", "repre_version": "v1", "object_lids": [1], "crop_rel_pad": 0.2, "crop_size": [224, 224],
+        "use_detections": True, "extractor_name": NAME, "grid_cell_size": 14.0, "match_template_type": "tfidf", "match_top_n_templates": 5,
+        "match_feat_matching_type": "cyclic_buddies", "match_top_k_buddies": 300, "pnp_type": "opencv", "pnp_ransac_iter": 400,
+        "pnp_inlier_thresh": 10.0, "final_pose_type": "best_coarse", "num_preds_factor": 2, "vis_results": False}}))
+    opts = infer.load_opts(str(opts_path))
+    assert opts.crop_size == (224, 224) and opts.pnp_refine_lm is True and opts.pnp_required_ransac_conf == 0.99
+
+    # ---- the bank: the two instances' own crops as templates 3 and 7 (vertices from planted poses in their crop cameras)
+    ex = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    img_f = torch.from_numpy(image).cuda().float() / 255.0
+    boxes_xyxy = [[x, y, x + w, y + h] for x, y, w, h in boxes_xywh]
+    crops, crop_masks, cams = crop_util.crop_detections(img_f, torch.from_numpy(masks).cuda(), boxes_xyxy, cam, (224, 224), 0.2)
+    T = 12
+    tpl = torch.rand(T, 3, 224, 224, generator=g).cuda()
+    tmask = torch.zeros(T, 224, 224, dtype=torch.uint8).cuda()
+    tmask[:, 40:190, 30:200] = 1
+    slots = [3, 7]
+    for b, s in enumerate(slots):
+        tpl[s], tmask[s] = crops[b], crop_masks[b]
+    feats, f2t, pts = bank_builder.extract_template_features(ex, tpl, tmask)
+    verts = torch.randn(feats.shape[0], 3, generator=g).cuda() * 50.0
+    R = workload._random_rotations(2, g)
+    t = torch.tensor([[10.0, -20.0, 900.0], [-30.0, 15.0, 1100.0]], dtype=torch.float64)
+    for b, s in enumerate(slots):
+        rows = f2t == s
+        K = torch.tensor([[cams[b].f[0], 0, cams[b].c[0]], [0, cams[b].f[1], cams[b].c[1]], [0, 0, 1.0]], dtype=torch.float64)
+        verts[rows] = workload.planted_vertices(pts[rows], K, R[b], t[b]).cuda()
+    repre = bank_builder.build_object_repre(feats, f2t, verts, T, pca_components=128, cluster_num=64, cluster_iters=10)
+    repre.feat_opts = repre_util.FeatureOpts(extractor_name=NAME)
+    rdir = repre_util.get_object_repre_dir_path(str(tmp_path / "object_repre"), opts.repre_version, opts.object_dataset, 1)
+    repre_util.save_object_repre(repre, rdir)
+
+    # ---- the driver
+    frames = lambda lid: iter([{"scene_id": 1, "im_id": 3, "image": image, "camera": cam}])
+    out_dir = str(tmp_path / "inference")
+    paths = infer.infer(opts, frames, infer_pose_util.load_detections_in_bop_format(str(det_path)), {1: repre_util.load_object_repre(rdir)}, out_dir, extractor=ex)
+    est = json.load(open(os.path.join(out_dir, "1", "estimated-poses.json")))
+    assert len(est) == 2
+    for e in est:
+        assert set(e) == {"scene_id", "img_id", "obj_id", "inst_id", "hypothesis_id", "score", "R", "t", "time", "cnos_time"}
+        assert all(isinstance(e[k], str) for k in ("scene_id", "img_id", "obj_id", "inst_id", "hypothesis_id", "score"))
+        assert (e["scene_id"], e["img_id"], e["obj_id"], e["hypothesis_id"]) == ("1", "3", "1", "0") and e["cnos_time"] == 0.25
+        assert np.array(e["R"]).shape == (3, 3) and np.array(e["t"]).shape == (3, 1) and float(e["score"]) > 0.9
+        assert set(e["time"]) == {"prep", "feat_extract_and_corresp", "pose_coarse"}
+    for e in est:  # instances are ordered by detection score -> inst_id b is box b
+        b = int(e["inst_id"])
+        T_m2c = np.eye(4)
+        T_m2c[:3, :3], T_m2c[:3, 3] = R[b].numpy(), t[b].numpy()
+        want = np.linalg.inv(cam.T_world_from_eye) @ cams[b].T_world_from_eye @ T_m2c   # planted pose in the ORIGINAL camera
+        assert np.abs(np.array(e["R"]) - want[:3, :3]).max() < 1e-4
+        assert np.linalg.norm(np.array(e["t"]).ravel() - want[:3, 3]) / np.linalg.norm(want[:3, 3]) < 1e-4
+    csv = open(paths[-1]).read().splitlines()
+    assert paths[-1].endswith("coarse_synth-estimated-poses.csv") and csv[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(csv) == 3
+    row = csv[1].split(",")
+    assert row[:3] == ["1", "3", "1"] and len(row[4].split(" ")) == 9 and len(row[5].split(" ")) == 3 and float(row[6]) > 0.25
