@@ -249,7 +249,14 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   }
   const int N = a.n_tok, D = a.dim;
   const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
-  const int q0 = qt * 256 + wave * (32 * QB);
+  // The last query tile of an (image, head) pair is usually short (1374 tokens = 5 x 256 + 94).  With two 32-query blocks
+  // per wave only 2 of its 4 waves would have queries, each doing a full tile's work: the block would cost as much as a
+  // full one for 37 % of the queries.  When <= 128 queries remain every wave takes ONE 32-query block instead (the QC = 1
+  // instantiation of the tile loop): the same arithmetic per query, half the work per wave, the tail block ends in about
+  // half the time.  Block-uniform.
+  const bool short_tail = QB == 2 && qt == (N + 255) / 256 - 1 && N - qt * 256 <= 128;
+  const int nqb = short_tail ? 1 : QB;
+  const int q0 = qt * 256 + wave * (32 * nqb);
   const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
 
   // ---- staging: wave w issues row groups 2w, 2w+1 (8 keys x 128 B each) of K and of V
@@ -284,7 +291,7 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   bf16x8 qf[QB][4];
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
-    const int q = q0 + qb * 32 + l31;
+    const int q = q0 + (qb < nqb ? qb : 0) * 32 + l31;
     const int qc = q < N ? q : N - 1;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
@@ -311,32 +318,33 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   __syncthreads();
   // one key tile; RAGGED (the last tile when N % 64 != 0) is a separate instantiation so that the full tiles carry no
   // masking code at all (inlined into one loop the compiler if-converts the mask into 120 selects per tile)
-  auto tile = [&](int kt, auto ragged) {
+  auto tile = [&](int kt, auto ragged, auto qblocks) {
     constexpr bool RAGGED = decltype(ragged)::value;
+    constexpr int QC = decltype(qblocks)::value;  // 32-query blocks this wave computes (QB, or 1 in a short tail tile)
     const int key0 = kt * 64;
     const char* Ks = KV[kt & 1][0];
     const char* Vs = KV[kt & 1][1];
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);  // the other stage was last read one iteration ago
     if (active) {
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
-      f32x16 sacc[QB][2];
+      f32x16 sacc[QC][2];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
 #pragma unroll
-        for (int qb = 0; qb < QB; ++qb)
+        for (int qb = 0; qb < QC; ++qb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[qb][ks][r] = 0.f;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
           const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
+          for (int qb = 0; qb < QC; ++qb)
             sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
         }
       }
-      bf16x8 pf[QB][4];
+      bf16x8 pf[QC][4];
 #pragma unroll
-      for (int qb = 0; qb < QB; ++qb) {
+      for (int qb = 0; qb < QC; ++qb) {
         if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
           const int lim = N - key0 - 4 * kh;
 #pragma unroll
@@ -398,7 +406,7 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 512));
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
 #pragma unroll
-          for (int qb = 0; qb < QB; ++qb)
+          for (int qb = 0; qb < QC; ++qb)
             oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kstep], oacc[qb][dt], 0, 0, 0);
         }
     }
@@ -408,12 +416,21 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
     }
   };
   const int nfull = N / 64;
-  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
-  if (nfull < nkt) tile(nfull, std::true_type{});
+  auto run = [&](auto qblocks) {
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, qblocks);
+    if (nfull < nkt) tile(nfull, std::true_type{}, qblocks);
+  };
+  if constexpr (QB == 2) {
+    if (short_tail) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+  } else {
+    run(std::integral_constant<int, QB>{});
+  }
 
   if (active) {
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
+      if (qb >= nqb) break;
       const int q = q0 + qb * 32 + l31;
       const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
       const float inv = 1.f / l_tot;
