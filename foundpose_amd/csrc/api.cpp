@@ -71,6 +71,12 @@ int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, con
     return launch_unpack_best(best, m, out_d2, out_idx, ST(stream));
   }
   FP_REQUIRE(out_d2, "fp_knn_l2: out_d2 is required for k > 1");
+  if (k <= 8) {  // fused: every distance tile emits its k best per row, a merge over the n-tiles finishes the row
+    const int nt = (n + 127) / 128;
+    a.row_best = reinterpret_cast<unsigned long long*>(scratch); a.row_stride = k;
+    TRY(f32_tile_launch(F32_EPI_DIST_TOPK, a, m, n, 1, ST(stream)));
+    return launch_knn_merge(a.row_best, m, nt * k, k, out_d2, out_idx, ST(stream));
+  }
   float* dist = reinterpret_cast<float*>(scratch);
   a.out = dist; a.ldo = n;
   TRY(f32_tile_launch(F32_EPI_DIST_STORE, a, m, n, 1, ST(stream)));

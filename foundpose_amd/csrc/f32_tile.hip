@@ -177,6 +177,61 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
         if (a.row_best && l31 == 0 && i < a_cnt && v != ~0ull) atomicMin(row_best + i, v);
       }
     }
+  } else if constexpr (EPI == F32_EPI_DIST_TOPK) {
+    // k nearest columns of every row INSIDE this tile (k = a.row_stride <= 8): the 128 x 128 distances go to LDS (free after
+    // the main loop), two threads scan a row's two halves keeping k sorted (d2, column) keys, one shuffle merges them,
+    // and the tile emits k keys per row -- 24 B instead of the 512 B of the row's distances.  A merge over the n-tiles'
+    // candidates finishes the row (launch_knn_merge).  Replaces "store [m, n] distances + k selection passes over them".
+    float* dt = smem;  // [128][129]
+    const float* an = a.a_sqnorm + a_off;
+    const float* bn = a.b_sqnorm + b_off;
+#pragma unroll
+    for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+      for (int tn = 0; tn < 2; ++tn) {
+        const int jl = wn * 64 + tn * 32 + l31, j = n0 + jl;
+        const bool jv = j < b_cnt;
+        const float bnj = jv ? bn[j] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int il = wm * 64 + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh, i = m0 + il;
+          float d2 = fmaf(-2.f, acc[tm][tn][r], (i < a_cnt ? an[i] : 0.f) + bnj);
+          d2 = d2 < 0.f ? 0.f : d2;
+          dt[il * LDS_STRIDE + jl] = (jv && i < a_cnt) ? d2 : INFINITY;
+        }
+      }
+    __syncthreads();
+    constexpr int KMAX = 8;
+    const int k = a.row_stride;
+    const int row = tid >> 1, half = tid & 1;
+    unsigned long long best[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
+    auto insert = [&](unsigned long long key) {
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) {
+        const unsigned long long lo = key < best[s] ? key : best[s];
+        key = key < best[s] ? best[s] : key;
+        best[s] = lo;
+      }
+    };
+    for (int c = 0; c < 64; ++c) {
+      const int jl = half * 64 + ((c + 32 * half) & 63);  // the halves walk 32 columns apart: different LDS banks
+      const float d2 = dt[row * LDS_STRIDE + jl];
+      insert(d2 == INFINITY ? ~0ull : pack_dist_idx(d2, (unsigned)(n0 + jl)));
+    }
+    unsigned long long other[KMAX];
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s) other[s] = __shfl_xor(best[s], 1, 64);
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k) insert(other[s]);
+    if (half == 0 && m0 + row < a_cnt) {
+      unsigned long long* o = a.row_best + ((size_t)(m0 + row) * gridDim.x + blockIdx.x) * k;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s)
+        if (s < k) o[s] = best[s];
+    }
   } else {
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
@@ -253,6 +308,7 @@ int f32_tile_launch(int epi, const F32TileArgs& a, int max_m, int max_n, int pai
     case F32_EPI_LS_RESID: return launch<F32_EPI_LS_RESID>(a, max_m, max_n, pairs, st);
     case F32_EPI_TOKENS: return launch<F32_EPI_TOKENS>(a, max_m, max_n, pairs, st);
     case F32_EPI_SWIGLU: return launch<F32_EPI_SWIGLU>(a, max_m, max_n, pairs, st);
+    case F32_EPI_DIST_TOPK: return launch<F32_EPI_DIST_TOPK>(a, max_m, max_n, pairs, st);
   }
   fp_set_error("f32_tile: unknown epilogue %d", epi);
   return FP_ERR_INVALID;

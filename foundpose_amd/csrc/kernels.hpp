@@ -14,6 +14,7 @@ enum : int {
   F32_EPI_LS_RESID = 6,     // out += gamma[j] * (acc + bias[j])
   F32_EPI_TOKENS = 7,       // patch-embed scatter into the token sequence (+ pos-embed)
   F32_EPI_SWIGLU = 8,       // columns interleaved (x1_j, x2_j): out[:, j] = silu(acc_2j + b_2j) * (acc_2j+1 + b_2j+1)
+  F32_EPI_DIST_TOPK = 9,    // per row the k smallest (d2, column) keys of this tile -> row_best[row, n_tile, k] (k = row_stride <= 8)
 };
 
 struct F32TileArgs {
@@ -137,6 +138,7 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
 int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
 int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st);
+int launch_knn_merge(const unsigned long long* cand, int rows, int ncand, int k, float* out_d2, int* out_idx, hipStream_t st);
 int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st);
 
 struct CosineArgs {

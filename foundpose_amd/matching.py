@@ -88,14 +88,6 @@ def match_batch(
         raise ValueError("query_features rows do not match sum(q_counts)")
     q_max = max(1, max(q_counts) if B else 1)
     n, K = top_n_templates, top_k_buddies
-    q_off = torch.tensor(q_off_h, dtype=torch.int32, device=dev)
-
-    q_sqn = ops.sqnorm_rows(qf)
-
-    # ---- per object group: nearest visual words (k-NN, k = tfidf_knn_k) and tf-idf descriptors
-    W = bank.num_words
-    desc = torch.empty(B, W, dtype=torch.float32, device=dev)
-    desc_n = torch.empty(B, W, dtype=torch.float32, device=dev)
     groups = []  # (obj, first_det, end_det)
     i = 0
     while i < B:
@@ -104,6 +96,25 @@ def match_batch(
             j += 1
         groups.append((det_obj[i], i, j))
         i = j
+    det_seg_h = [0] * (bank.num_objects + 1)
+    for obj, d0, d1 in groups:
+        det_seg_h[obj + 1] = d1 - d0
+    for k_ in range(bank.num_objects):
+        det_seg_h[k_ + 1] += det_seg_h[k_]
+    # ---- every small host table of the batch in ONE upload: q_off [B+1] | det_seg [num_obj+1] | det_nt [B] | tpl_base [B] | feat_base [B]
+    tabs_h = q_off_h + det_seg_h + [bank.objects[o].num_templates for o in det_obj] + [bank.objects[o].tpl_base for o in det_obj] \
+        + [bank.objects[o].feat_base for o in det_obj]
+    tabs = torch.tensor(tabs_h, dtype=torch.int32, device=dev)
+    o1 = B + 1
+    o2 = o1 + bank.num_objects + 1
+    q_off, det_seg, det_nt, tpl_base, feat_base = tabs[:o1], tabs[o1:o2], tabs[o2:o2 + B], tabs[o2 + B:o2 + 2 * B], tabs[o2 + 2 * B:o2 + 3 * B]
+
+    q_sqn = ops.sqnorm_rows(qf)
+
+    # ---- per object group: nearest visual words (k-NN, k = tfidf_knn_k) and tf-idf descriptors, written in place
+    W = bank.num_words
+    desc = torch.empty(B, W, dtype=torch.float32, device=dev)
+    desc_n = torch.empty(B, W, dtype=torch.float32, device=dev)
     word_ids_all = []
     for obj, d0, d1 in groups:
         o = bank.objects[obj]
@@ -111,23 +122,14 @@ def match_batch(
         if o.opts.tfidf_knn_metric != "l2":
             raise ValueError(f"Metric {o.opts.tfidf_knn_metric} is not supported on this path.")
         w_d2, w_ids = ops.knn_l2(qf[r0:r1], o.words, o.opts.tfidf_knn_k, q_sqn[r0:r1], o.words_sqn)
-        seg = (q_off[d0:d1 + 1] - r0).contiguous()
-        dsc, dsc_n = ops.tfidf_build(w_ids, w_d2, seg, o.idf, o.opts.tfidf_soft_assign,
-                                     o.opts.tfidf_soft_sigma_squared, sqrt_dists=True)
-        desc[d0:d1] = dsc
-        desc_n[d0:d1] = dsc_n
+        seg = q_off[d0:d1 + 1] if r0 == 0 else (q_off[d0:d1 + 1] - r0)
+        ops.tfidf_build(w_ids, w_d2, seg, o.idf, o.opts.tfidf_soft_assign, o.opts.tfidf_soft_sigma_squared, sqrt_dists=True,
+                        out=(desc[d0:d1], desc_n[d0:d1]))
         if keep_debug:
             word_ids_all.append(w_ids)
 
     # ---- template retrieval: cosine vs the object's template descriptors, top-n
-    det_seg_h = [0] * (bank.num_objects + 1)
-    for obj, d0, d1 in groups:
-        det_seg_h[obj + 1] = d1 - d0
-    for k_ in range(bank.num_objects):
-        det_seg_h[k_ + 1] += det_seg_h[k_]
     # detections are sorted by object, so object o's detections are rows det_seg_h[o]:det_seg_h[o+1]
-    det_seg = torch.tensor(det_seg_h, dtype=torch.int32, device=dev)
-    det_nt = torch.tensor([bank.objects[o].num_templates for o in det_obj], dtype=torch.int32, device=dev)
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
     sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
@@ -135,19 +137,17 @@ def match_batch(
     call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
          ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
 
-    # ---- cyclic best buddies against the retrieved templates + correspondence assembly
-    tpl_base = torch.tensor([bank.objects[o].tpl_base for o in det_obj], dtype=torch.int32, device=dev)
-    feat_base = torch.tensor([bank.objects[o].feat_base for o in det_obj], dtype=torch.int32, device=dev)
+    # ---- cyclic best buddies against the retrieved templates + correspondence assembly (the kernel pads its records itself)
     t_glob = torch.where(t_ids >= 0, t_ids + tpl_base[:, None], t_ids).contiguous()
     pairs = B * n
     scratch = torch.empty(pairs * (q_max + bank.p_max), dtype=torch.int64, device=dev)
-    counts = torch.zeros(B, n, dtype=torch.int32, device=dev)
-    q_ids = torch.full((B, n, K), -1, dtype=torch.int32, device=dev)
-    feat_ids = torch.full((B, n, K), -1, dtype=torch.int32, device=dev)
-    dists = torch.zeros(B, n, K, dtype=torch.float32, device=dev)
-    conf = torch.zeros(B, n, K, dtype=torch.float32, device=dev)
-    c2d = torch.zeros(B, n, K, 2, dtype=torch.float32, device=dev)
-    c3d = torch.zeros(B, n, K, 3, dtype=torch.float32, device=dev)
+    counts = torch.empty(B, n, dtype=torch.int32, device=dev)
+    q_ids = torch.empty(B, n, K, dtype=torch.int32, device=dev)
+    feat_ids = torch.empty(B, n, K, dtype=torch.int32, device=dev)
+    dists = torch.empty(B, n, K, dtype=torch.float32, device=dev)
+    conf = torch.empty(B, n, K, dtype=torch.float32, device=dev)
+    c2d = torch.empty(B, n, K, 2, dtype=torch.float32, device=dev)
+    c3d = torch.empty(B, n, K, 3, dtype=torch.float32, device=dev)
     call("fp_cyclic_buddies", ptr(qf), ptr(q_sqn), ptr(qp), ptr(q_off), B, q_max, ptr(bank.feats), ptr(bank.feat_sqn),
          ptr(bank.tpl_off), bank.p_max, ptr(bank.vertices), ptr(t_glob), ptr(feat_base), n, bank.feat_dim, K, K,
          ptr(scratch), ptr(counts), ptr(q_ids), ptr(feat_ids), ptr(dists), ptr(conf), ptr(c2d), ptr(c3d), tie_mode, stream())

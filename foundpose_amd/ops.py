@@ -54,7 +54,7 @@ def knn_l2(q: torch.Tensor, db: torch.Tensor, k: int, q_sqnorm: Optional[torch.T
     d2 = torch.empty(m, k_eff, dtype=torch.float32, device=q.device)
     idx = torch.empty(m, k_eff, dtype=torch.int32, device=q.device)
     if m > 0:
-        per_row = 8 if k_eff == 1 else n * 4
+        per_row = 8 if k_eff == 1 else (((n + 127) // 128) * k_eff * 8 if k_eff <= 8 else n * 4)
         chunk = max(1, min(m, _KNN_SCRATCH_BYTES // per_row))
         scratch = torch.empty(chunk * per_row, dtype=torch.uint8, device=q.device)
         for r0 in range(0, m, chunk):
@@ -69,13 +69,19 @@ def knn_l2(q: torch.Tensor, db: torch.Tensor, k: int, q_sqnorm: Optional[torch.T
 
 
 def tfidf_build(word_ids: torch.Tensor, word_d2: torch.Tensor, seg_off: torch.Tensor, idf: torch.Tensor,
-                soft_assign: bool, soft_sigma_squared: float, sqrt_dists: bool, eps: float = 1e-8):
-    """-> (desc [S, W], desc_n [S, W]) for S = len(seg_off) - 1 point sets."""
+                soft_assign: bool, soft_sigma_squared: float, sqrt_dists: bool, eps: float = 1e-8, out=None):
+    """-> (desc [S, W], desc_n [S, W]) for S = len(seg_off) - 1 point sets (written into `out` = (desc, desc_n) if given:
+    contiguous row slices of larger buffers)."""
     require_cuda(word_ids, word_d2, seg_off, idf)
     num_segs = seg_off.shape[0] - 1
     W = idf.shape[0]
-    desc = torch.empty(num_segs, W, dtype=torch.float32, device=idf.device)
-    desc_n = torch.empty_like(desc)
+    if out is not None:
+        desc, desc_n = out
+        if desc.shape != (num_segs, W) or desc_n.shape != (num_segs, W) or not desc.is_contiguous() or not desc_n.is_contiguous():
+            raise ValueError("tfidf_build: `out` must be two contiguous [num_segs, num_words] fp32 tensors")
+    else:
+        desc = torch.empty(num_segs, W, dtype=torch.float32, device=idf.device)
+        desc_n = torch.empty_like(desc)
     call("fp_tfidf_build", ptr(word_ids), ptr(word_d2), word_ids.shape[1], ptr(seg_off), num_segs, ptr(idf), W,
          int(soft_assign), float(soft_sigma_squared), int(sqrt_dists), ptr(desc), ptr(desc_n), eps, stream())
     return desc, desc_n

@@ -42,8 +42,9 @@ int fp_sqnorm_rows(const float* x, int64_t n, int d, float* out, fp_stream_t str
 int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, fp_stream_t stream);
 
 /* Exact brute-force L2 k-NN: KNN.fit + KNN.search with metric "l2" (utils/knn_util.py:38-106).
- * q [m,d], db [n,d], precomputed squared norms of both.  k == 1 needs scratch of m*8 bytes,
- * k > 1 needs scratch of m*n*4 bytes.  out_d2 [m,k] (squared), out_idx [m,k] int32. */
+ * q [m,d], db [n,d], precomputed squared norms of both.  Scratch: k == 1: m*8 bytes; 2 <= k <= 8: m * ceil(n/128) * k * 8
+ * bytes (per-tile candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared), out_idx [m,k] int32,
+ * ascending, ties -> lowest index, (inf, -1) past the database size. */
 int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n,
               int d, int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream);
 
