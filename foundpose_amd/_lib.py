@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -22,7 +22,7 @@ class VitBlock(C.Structure):
     _fields_ = [(n, vp) for n in (
         "ln1_w", "ln1_b", "ln2_w", "ln2_b", "ls1", "ls2",
         "qkv_w", "proj_w", "fc1_w", "fc2_w",
-        "qkv_b", "proj_b", "fc1_b", "fc2_b", "qkv_s", "proj_s", "fc1_s", "fc2_s")] + [("act_scale", f32 * 4)]
+        "qkv_b", "proj_b", "fc1_b", "fc2_b", "qkv_s", "proj_s", "fc1_s", "fc2_s")] + [("act_scale", f32 * 4), ("qkv_colsum", vp), ("fc1_colsum", vp)]
 
 
 class VitModel(C.Structure):
@@ -30,14 +30,14 @@ class VitModel(C.Structure):
         ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
         ("ffn_swiglu", i32), ("weight_dtype", i32),
         ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
-        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("ln_fold", i32),
     ]
 
 
 class VitWorkspace(C.Structure):
     _fields_ = [
         ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp), ("a8", vp),
-        ("ld_y", i32), ("ld_h", i32), ("ld_qkv", i32), ("m_pad", i32), ("m_patch_pad", i32),
+        ("ld_y", i32), ("ld_h", i32), ("ld_qkv", i32), ("m_pad", i32), ("m_patch_pad", i32), ("xb", vp), ("stats", vp),
     ]
 
 
@@ -58,6 +58,8 @@ _PROTOS = {
     "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],
     "fp_gemm_bf16": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
+    "fp_gemm_bf16_ln": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp],
+    "fp_ln_finalize": [vp, i32, i32, i32, i32, f32, vp, vp],
     "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, vp],
     "fp_quantize_fp8": [vp, i32, i64, f32, vp, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],

@@ -232,6 +232,34 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   return gemm_bf16_launch(epilogue, a, ST(stream));
 }
 
+int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, void* out, int ldo,
+                    int epilogue, const float* colsum, const float* ln_row, void* xb, int ld_xb, float* stats, fp_stream_t stream) {
+  FP_REQUIRE(A && W && out && bias, "fp_gemm_bf16_ln: null pointer");
+  const int tile = (epilogue >> 8) & 0xfff;
+  epilogue &= 0xff;
+  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_bf16_ln: bad tile override %d", tile);
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.out = out; a.ldo = ldo; a.tile_override = tile;
+  if (epilogue == GEMM_EPI_RESID_F32) {  // producer: x += acc + bias, plus bf16(x) and the partial row sums
+    FP_REQUIRE((xb == nullptr) == (stats == nullptr), "fp_gemm_bf16_ln: xb and stats go together");
+    FP_REQUIRE(!xb || (N % 128 == 0 && ld_xb >= N && ld_xb % 4 == 0), "fp_gemm_bf16_ln: N must be a multiple of 128 and ld_xb cover the row");
+    a.xb = reinterpret_cast<__bf16*>(xb); a.ld_xb = ld_xb; a.stats_out = reinterpret_cast<float2*>(stats);
+  } else {                               // consumer: epi(rstd * (acc - mean * colsum) + bias)
+    FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_SWIGLU_BF16,
+               "fp_gemm_bf16_ln: epilogue %d has no folded-LayerNorm form", epilogue);
+    FP_REQUIRE(colsum && ln_row, "fp_gemm_bf16_ln: colsum and ln_row are required");
+    a.colsum = colsum; a.ln_stats = reinterpret_cast<const float2*>(ln_row); a.ln_eps = 1e-6f;
+  }
+  return gemm_bf16_launch(epilogue, a, ST(stream));
+}
+
+int fp_ln_finalize(const float* stats, int parts, int stats_stride, int rows, int dim, float eps, float* ln_row, fp_stream_t stream) {
+  FP_REQUIRE(stats && ln_row && parts >= 1 && dim >= 1, "fp_ln_finalize: bad arguments");
+  return ln_finalize_launch(reinterpret_cast<const float2*>(stats), parts, stats_stride, rows, dim, eps, reinterpret_cast<float2*>(ln_row), ST(stream));
+}
+
 #ifdef FP_GEMM_TIMELINE
 // Measurement build only (tools/build_variant.sh -DFP_GEMM_TIMELINE, tools/gemm_timeline.py): the same GEMM writing four
 // shader-clock stamps per workgroup into a caller-owned buffer of dbg_len >= 4 * grid u64 slots.
@@ -365,8 +393,47 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   at.qkv = ws->qkv; at.ld_qkv = ldq; at.out = ws->y; at.ld_out = ldy;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
 
+  // LayerNorm folded into the GEMMs (bf16 blocks): see fp_vit_model.ln_fold.  The chain starts from the token embedding.
+  const bool fold = m->ln_fold && bf && !f8;
+  int ln_parts = 1;
+  float2* stats = reinterpret_cast<float2*>(ws->stats);
+  if (fold) {
+    FP_REQUIRE(ws->xb && ws->stats, "fp_vit_forward: ln_fold needs workspace xb and stats");
+    FP_REQUIRE(D % 128 == 0, "fp_vit_forward: ln_fold needs dim %% 128 == 0");
+    ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
+    if (layer >= 0) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st));
+  }
+  float2* ln_row = stats + (size_t)ln_parts * ws->m_pad;  // (rstd, mean * rstd) per row, behind the partial-sum slots
+  auto finalize = [&]() -> int { return ln_finalize_launch(stats, ln_parts, ws->m_pad, Mtok, D, 1e-6f, ln_row, st); };
+  auto gemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
+                  const float* colsum, bool produce) -> int {
+    GemmBf16Args g;
+    memset(&g, 0, sizeof(g));
+    g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
+    g.M = ws->m_pad; g.N = N; g.K = K; g.M_valid = Mtok; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+    if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
+    if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; }
+    return gemm_bf16_launch(epi, g, st);
+  };
+
   for (int i = 0; i <= layer; ++i) {
     const fp_vit_block& b = m->blocks[i];
+    if (fold) {
+      // x += ls1 * proj(attn(ln1(x))): qkv reads bf16(x) and normalises in its epilogue; proj refreshes bf16(x) + row sums
+      FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
+      TRY(finalize());
+      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
+      TRY(attn_launch(at, FP_DTYPE_BF16, st));
+      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, GEMM_EPI_RESID_F32, nullptr, true));
+      // x += ls2 * fc2(act(fc1(ln2(x))))
+      TRY(finalize());
+      if (m->ffn_swiglu)
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false));
+      else
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false));
+      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, ws->x, D, GEMM_EPI_RESID_F32, nullptr, i < layer));
+      continue;
+    }
     // x += ls1 * proj(attn(ln1(x)))
     ln.weight = b.ln1_w; ln.bias = b.ln1_b;
     if (f8) {

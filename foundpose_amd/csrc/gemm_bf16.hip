@@ -72,6 +72,17 @@ FP_DEVICE f32x2 gelu_pk(f32x2 x) {
   return x * phi;
 }
 
+// Sum over aligned groups of 32 lanes with DPP moves; the total is valid in the LAST lane of each group (lane & 31 == 31).
+FP_DEVICE float row32_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8 -> every lane: its row of 16
+  // row_bcast15 into rows 1 and 3 (row_mask 0xA): lane 15 of the row before -> lanes 16..31 / 48..63 hold the 32-lane total
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, true));
+  return v;
+}
+
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32.
 // F8: the operands are OCP fp8 (e4m3) instead of bf16.  An fp8 row of K elements is addressed as a bf16 row of K/2
 // elements (the host passes K/2, lda/2, ldw/2), so a K-tile is the same 128-B-per-row LDS image holding 128 k-values and
@@ -89,6 +100,7 @@ template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT =
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr bool RESID = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_RESID_F32;  // fp32 residual read-modify-write epilogues
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   // DMA issue is asymmetric on the 8-wave tile: only the waves of row wm == 0 fetch (every SIMD hosts one wave of each
   // row).  A global/buffer_load..lds blocks its wave for ~60-180 issue cycles; when all eight waves issue their pieces
@@ -155,6 +167,23 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     };
 #pragma unroll
     for (int q = 0; q < PIECES; ++q) stage_piece(q, kb, smem);
+
+    // Folded LayerNorm (consumer side): (rstd, mean * rstd) of the TM rows this lane will finish (ln_finalize's table).
+    // Loaded here, behind the first K-tile's DMA, so the round trip hides under the main loop (fetched in the epilogue it
+    // cost ~3.5 us per band).
+    float ln_rs[TM], ln_mrs[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { ln_rs[i] = 1.f; ln_mrs[i] = 0.f; }
+    if constexpr (!F8 && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)) {
+      if (a.ln_stats) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const float2 st = a.ln_stats[m0 + wm * (BM / WM) + i * 32 + l31];
+          ln_rs[i] = st.x;
+          ln_mrs[i] = st.y;
+        }
+      }
+    }
 
     {
       // ---- main loop: one barrier per K-tile, the next tile's DMA issued in four slices ahead of each k-step's MFMAs
@@ -230,10 +259,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     // so does the fp32 LayerScale + residual read-modify-write (residual rows read and written as whole rows:
     // proj 152 -> 141 us, fc2 386 -> 374 us).  Only the small fp32 bias / patch-embed outputs stay register-direct.
     constexpr bool USE_SLAB = EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 ||
-                              EPI == GEMM_EPI_SWIGLU_BF16 || EPI == GEMM_EPI_LS_RESID_F32;
+                              EPI == GEMM_EPI_SWIGLU_BF16 || RESID;
     static_assert(!F8 || USE_SLAB, "the fp8 kernels exist for the slab epilogues only");
     if constexpr (USE_SLAB) {
-    constexpr bool OUT_F32 = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
+    constexpr bool OUT_F32 = RESID || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
     constexpr int ESZ = OUT_F32 ? 4 : (F8OUT ? 1 : 2);
     constexpr int OUT_COLS = EPI == GEMM_EPI_SWIGLU_BF16 ? BN / 2 : BN;  // SwiGLU folds column pairs
     constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = OUT_COLS * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
@@ -243,6 +272,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     // barrier that publishes band tm+1 also retires the readers of band tm-1's slab -> one barrier per band, not two
     constexpr bool TWO_SLABS = 2 * SLAB_ROWS * SLAB_STRIDE <= 2 * STAGE;
     constexpr int SLAB_BYTES = SLAB_ROWS * SLAB_STRIDE;
+    // LayerNorm folded into this GEMM (bf16 only): A is the raw residual stream in bf16, W carries the gain, and the
+    // epilogue applies out = rstd_r * (acc - mean_r * colsum_n) + bias_n before the non-linearity
+    constexpr bool LN_FOLD_OK = !F8 && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16);
+    const bool fold = LN_FOLD_OK && a.ln_stats != nullptr;
     float4 bias[TN][4], gam[TN][4];
   #pragma unroll
     for (int tn = 0; tn < TN; ++tn)
@@ -251,6 +284,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         const int n = n0 + wn * (BN / WN) + tn * 32 + 8 * g + 4 * kh;
         bias[tn][g] = *reinterpret_cast<const float4*>(a.bias + n);
         if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || F8) gam[tn][g] = *reinterpret_cast<const float4*>(a.gamma + n);
+        if constexpr (LN_FOLD_OK) {
+          if (fold) gam[tn][g] = *reinterpret_cast<const float4*>(a.colsum + n);  // (gam is free in these epilogues)
+        }
       }
     __syncthreads();  // every wave is done with the operand tiles in LDS
   #pragma unroll
@@ -262,24 +298,25 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       constexpr int PASSES = (SLAB_CHUNKS + NT - 1) / NT;
       static_assert(SLAB_CHUNKS % NT == 0, "slab chunks must divide evenly over the block");
       float4 ext[PASSES];
-      size_t orow[PASSES];
-      bool ok[PASSES];
+      int orow_i[PASSES];  // output row (< 2^31), -1: a padding row (kept as one 32-bit value per pass: the epilogue is register-bound)
   #pragma unroll
       for (int it = 0; it < PASSES; ++it) {
         const int id = tid + it * NT;
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
         const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
-        ok[it] = gm_row < a.M_valid;
-        orow[it] = gm_row;
+        const bool okr = gm_row < a.M_valid;
+        int orow = gm_row;
         if constexpr (EPI == GEMM_EPI_TOKENS_F32) {
           const int b = gm_row / a.tok_np, pidx = gm_row - b * a.tok_np;
-          orow[it] = (size_t)b * a.tok_n + a.tok_skip + pidx;
-          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(a.pos + (size_t)pidx * a.ldo + n0 + c * 4);
+          orow = b * a.tok_n + a.tok_skip + pidx;
+          if (okr) ext[it] = *reinterpret_cast<const float4*>(a.pos + (size_t)pidx * a.ldo + n0 + c * 4);
         }
-        if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
-          if (ok[it]) ext[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + orow[it] * a.ldo + n0 + c * 4);
+        if constexpr (RESID) {
+          if (okr) ext[it] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.out) + (size_t)orow * a.ldo + n0 + c * 4);
         }
+        orow_i[it] = okr ? orow : -1;
       }
+      const float rs = ln_rs[tm], mrs = ln_mrs[tm];  // folded LayerNorm: rstd of this lane's row and mean * rstd
       // (a) registers -> slab (final values except for the operand that needs a global read)
       char* slab = smem + (TWO_SLABS ? (tm & 1) * SLAB_BYTES : 0);
       char* srow = slab + (wm * 32 + l31) * SLAB_STRIDE;
@@ -291,6 +328,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
+          if constexpr (LN_FOLD_OK) {
+            if (fold) {  // rstd * acc - (mean * rstd) * colsum + bias
+              const float4 cs = gam[tn][g];
+              v0 = fmaf(rs, acc[tm][tn][4 * g + 0], fmaf(-mrs, cs.x, bs.x)); v1 = fmaf(rs, acc[tm][tn][4 * g + 1], fmaf(-mrs, cs.y, bs.y));
+              v2 = fmaf(rs, acc[tm][tn][4 * g + 2], fmaf(-mrs, cs.z, bs.z)); v3 = fmaf(rs, acc[tm][tn][4 * g + 3], fmaf(-mrs, cs.w, bs.w));
+            }
+          }
           if constexpr (F8 && EPI != GEMM_EPI_LS_RESID_F32) {  // dequantise before the non-linearity
             const float4 gm = gam[tn][g];
             v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
@@ -318,20 +362,33 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       for (int it = 0; it < PASSES; ++it) {
         const int id = tid + it * NT;
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
-        if (!ok[it]) continue;
+        if (orow_i[it] < 0) continue;
+        const size_t orow_it = (size_t)orow_i[it];
         const char* sp = slab + r * SLAB_STRIDE + c * 16;
         if constexpr (F8OUT) {
           const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 16;
-          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
+          *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.out) + orow_it * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
         } else if constexpr (!OUT_F32) {
           const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 8;
-          *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow[it] * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
+          *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow_it * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
         } else {
           float4 v = *reinterpret_cast<const float4*>(sp);
-          if constexpr (EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_TOKENS_F32) {
+          if constexpr (RESID || EPI == GEMM_EPI_TOKENS_F32) {
             v.x += ext[it].x; v.y += ext[it].y; v.z += ext[it].z; v.w += ext[it].w;
           }
-          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow[it] * a.ldo + n0 + c * 4) = v;
+          *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow_it * a.ldo + n0 + c * 4) = v;
+          if constexpr (EPI == GEMM_EPI_RESID_F32 && !F8) {
+            if (a.xb) {  // the next GEMM's A operand + this tile's share of the row's LayerNorm statistics
+              *reinterpret_cast<uint2*>(a.xb + orow_it * a.ld_xb + n0 + c * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+              // partial sums over 128-column groups -- 32 lanes x float4, the same tree whatever the tile width, so a row's
+              // statistics (and everything downstream) do not depend on which tile shape the batch size selects.  DPP adds
+              // (VALU rate): the ds_bpermute chain of __shfl_xor cost 24 k cycles per tile here.
+              float s1 = (v.x + v.y) + (v.z + v.w), s2 = fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+              s1 = row32_sum(s1);
+              s2 = row32_sum(s2);
+              if ((c & 31) == 31) a.stats_out[(size_t)(n0 / 128 + (c >> 5)) * a.M + orow_it] = make_float2(s1, s2);
+            }
+          }
         }
       }
       if (!TWO_SLABS && tm + 1 < TM) __syncthreads();
@@ -485,6 +542,7 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
     case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16>(a, st);
     case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16>(a, st);
     case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
+    case GEMM_EPI_RESID_F32: return launch<GEMM_EPI_RESID_F32>(a, st);
     case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
     case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);
     case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16>(a, st);

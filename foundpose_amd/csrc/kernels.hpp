@@ -88,6 +88,7 @@ enum : int {
   GEMM_EPI_LS_RESID_F32 = 3,  // out(f32) += gamma * (acc + bias)      (LayerScale + residual)
   GEMM_EPI_TOKENS_F32 = 4,    // patch-embed rows scattered into the token sequence (+ bias + pos-embed)
   GEMM_EPI_BIAS_F32 = 5,      // out(f32) = acc + bias
+  GEMM_EPI_RESID_F32 = 7,     // out(f32) += acc + bias (LayerScale already folded into W and bias) + the LayerNorm-fold outputs (xb, stats)
   GEMM_EPI_SWIGLU_BF16 = 6,   // SwiGLU FFN: columns interleaved (x1_j, x2_j) -> out(bf16)[:, j] = silu(x1_j) * x2_j, [M, N/2]
 };
 
@@ -104,6 +105,15 @@ struct GemmBf16Args {
   unsigned rast_r, rast_gn;
   float out_scale;            // fp8 kernels: > 0 -> the GELU / SwiGLU result leaves as e4m3(value * out_scale) bytes
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
+  // ---- LayerNorm folded into the GEMMs around it (bf16 ViT blocks, vit forward only):
+  // producer (LS_RESID): besides the fp32 residual stream it writes xb = bf16(x) -- the next GEMM's A operand -- and per
+  // row the partial sums (sum x, sum x^2) of every 128-column group into stats[(column / 128) * M + row]
+  __bf16* xb; int ld_xb;
+  float2* stats_out;
+  // consumer (BIAS / GELU / SwiGLU epilogues; W carries the LayerNorm gain, bias the LayerNorm shift):
+  //   out = epi(rstd_r * (acc - mean_r * colsum_n) + bias_n);  ln_stats [M] = (rstd_r, mean_r * rstd_r) from ln_finalize_launch
+  const float2* ln_stats; int ln_parts; float ln_eps;
+  const float* colsum;        // [N] fp32 sums of the rows of W
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
@@ -132,6 +142,10 @@ struct LayerNormArgs {
   int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi
 };
 int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
+// x [rows, dim] fp32 -> xb = bf16(x) [rows, ld_xb] and stats[0 * stats_stride + row] = (sum x, sum x^2), slots 1..parts-1 zero
+// partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
+int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st);
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
                     int out_dtype, hipStream_t st);

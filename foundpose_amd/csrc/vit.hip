@@ -87,38 +87,95 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
 
 // images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
 // column = c*P*P + py*P + px (the flattening of the conv weight [D,3,P,P]); columns >= 3*P*P are zero.
-// One thread moves one P-pixel run of a patch (a row of the patch in one channel): P contiguous floats in, P contiguous
-// outputs, so the div/mod address arithmetic is paid once per run instead of once per element (120 -> ~40 us at 32 x 518^2).
+// A patch row is 14 pixels wide: whichever side a thread walks, the other side is touched in 28/56-byte pieces (one
+// thread per element: 120 us; one thread per 14-pixel run: 117 us -- the access pattern, not the instruction count, is the
+// cost).  So one workgroup takes one ROW OF PATCHES (image b, patch row gy): the 3 x P image rows it covers are read as
+// whole rows (coalesced), normalised once, and parked in LDS; the gw output rows then leave as whole 16-byte chunks.
 template <typename T>
-__global__ void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld) {
-  const int nseg = 3 * P + 1;  // 3*P pixel runs + one run of zero padding per output row
-  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const int gw = W / P, gh = H / P, np = gw * gh;
-  if (e >= (long long)B * np * nseg) return;
-  const int seg = (int)(e % nseg);
-  const long long row = e / nseg;
-  T* orow = out + row * ld;
-  if (seg == 3 * P) {
-    for (int col = 3 * P * P; col < ld; ++col) orow[col] = (T)0.f;
-    return;
-  }
-  const int b = (int)(row / np), pi = (int)(row % np);
-  const int gy = pi / gw, gx = pi - gy * gw;
-  const int c = seg / P, py = seg - c * P;
-  const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
-  const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
-  const float* src = img + (((size_t)b * 3 + c) * H + gy * P + py) * W + gx * P;
-  T* dst = orow + c * P * P + py * P;
-  if constexpr (sizeof(T) == 2) {
-    if ((P & 1) == 0 && (W & 1) == 0 && (ld & 1) == 0) {  // float2 in, packed bf16 pairs out (alignment: P, W, ld even)
-      for (int px = 0; px < P; px += 2) {
-        const float2 x = *reinterpret_cast<const float2*>(src + px);
-        *reinterpret_cast<unsigned*>(dst + px) = pack_bf16x2((x.x - mean) / stdv, (x.y - mean) / stdv);  // T.Normalize: sub then div
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* strip = reinterpret_cast<T*>(smem_raw);  // [3 * P][W] normalised pixels of this row of patches
+  const int gw = W / P, gh = H / P;
+  const int b = blockIdx.x / gh, gy = blockIdx.x - b * gh, tid = threadIdx.x;
+  // (eight loads in flight per thread before the first LDS store: one load per iteration made the strip load a chain of
+  // 126 HBM round trips per workgroup -- 117 us for the launch, whatever the access pattern)
+  const int total = 3 * P * W;
+  const float* img_b = img + (size_t)b * 3 * H * W;
+  for (int base = tid; base < total; base += 256 * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256;
+      v[u] = 0.f;
+      if (idx < total) {
+        const int r = idx / W, x = idx - r * W, c = r / P, py = r - c * P;
+        v[u] = img_b[((size_t)c * H + gy * P + py) * W + x];
       }
-      return;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * 256;
+      if (idx < total) {
+        const int c = idx / (W * P);
+        const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+        const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+        strip[idx] = (T)((v[u] - mean) / stdv);  // T.Normalize: sub then div
+      }
     }
   }
-  for (int px = 0; px < P; ++px) dst[px] = (T)((src[px] - mean) / stdv);
+  __syncthreads();
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
+  const int chunks = ld / V, ncols = 3 * P * P;
+  for (int id = tid; id < gw * chunks; id += 256) {
+    const int gx = id / chunks, ch = id - gx * chunks;
+    T v[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) {
+      const int col = ch * V + e;
+      T val = (T)0.f;
+      if (col < ncols) {
+        const int r = col / P, px = col - r * P;  // r = c * P + py
+        val = strip[r * W + gx * P + px];
+      }
+      v[e] = val;
+    }
+    *reinterpret_cast<uint4*>(out + ((size_t)(b * gh + gy) * gw + gx) * ld + ch * V) = *reinterpret_cast<const uint4*>(v);
+  }
+}
+
+// Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
+// LayerScale GEMM has produced yet.  One wave per row; slot 0 of the partial-sum table gets the whole row, the others zero.
+__global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, int rows, int dim, __bf16* __restrict__ xb, int ld_xb,
+                                                            float2* __restrict__ stats, int stats_stride, int parts) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* xr = x + (size_t)row * dim;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const float4 v = *reinterpret_cast<const float4*>(xr + c);
+    *reinterpret_cast<uint2*>(xb + (size_t)row * ld_xb + c) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    s1 += (v.x + v.y) + (v.z + v.w);
+    s2 += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
+  }
+  s1 = wave_sum(s1);
+  s2 = wave_sum(s2);
+  if (lane < parts) stats[(size_t)lane * stats_stride + row] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
+}
+
+// Folded LayerNorm: the residual GEMM's column tiles leave `parts` partial sums per row; one thread per row adds them in
+// slot order and leaves (rstd, mean * rstd), the two numbers the next GEMM's epilogue needs.
+__global__ void ln_finalize_kernel(const float2* __restrict__ partial, int parts, int stride, int rows, float inv_dim, float eps, float2* __restrict__ out) {
+  const int row = blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  float s1 = 0.f, s2 = 0.f;
+  for (int p = 0; p < parts; ++p) {
+    const float2 v = partial[(size_t)p * stride + row];
+    s1 += v.x;
+    s2 += v.y;
+  }
+  const float mu = s1 * inv_dim;
+  const float rs = rsqrtf(fmaxf(s2 * inv_dim - mu * mu, 0.f) + eps);
+  out[row] = make_float2(rs, mu * rs);
 }
 
 __global__ void prefix_tokens_kernel(const float* __restrict__ prefix, int n_prefix, int dim, float* __restrict__ tokens, int batch, int n_tok) {
@@ -162,14 +219,34 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
                     int out_dtype, hipStream_t st) {
   FP_REQUIRE(height % patch == 0 && width % patch == 0, "patchify: image %dx%d is not a multiple of the patch size %d", height, width, patch);
   FP_REQUIRE(ld_out >= 3 * patch * patch, "patchify: ld_out too small");
-  const long long total = (long long)batch * (height / patch) * (width / patch) * (3 * patch + 1);  // one thread per pixel run
-  if (total == 0) return FP_OK;
-  const unsigned grid = (unsigned)((total + 255) / 256);
+  const unsigned grid = (unsigned)(batch * (height / patch));  // one workgroup per row of patches
+  if (grid == 0) return FP_OK;
+  const size_t esz = out_dtype == FP_DTYPE_BF16 ? 2 : 4, lds = (size_t)3 * patch * width * esz;
+  FP_REQUIRE(ld_out % (16 / esz) == 0, "patchify: ld_out must keep 16-byte rows");
+  FP_REQUIRE(lds <= 160 * 1024, "patchify: a row of patches (3 x %d x %d pixels) does not fit LDS", patch, width);
+  static FpDeviceOnce attr_b, attr_f;
+  fp_allow_dynamic_lds(attr_b, &patchify_kernel<__bf16>, 160 * 1024);
+  fp_allow_dynamic_lds(attr_f, &patchify_kernel<float>, 160 * 1024);
   if (out_dtype == FP_DTYPE_BF16)
-    hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out);
+    hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out);
   else
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out);
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out);
   FP_CHECK_LAUNCH("patchify");
+  return FP_OK;
+}
+
+int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st) {
+  if (rows == 0) return FP_OK;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, partial, parts, stride, rows, 1.f / (float)dim, eps, out);
+  FP_CHECK_LAUNCH("ln_finalize");
+  return FP_OK;
+}
+
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st) {
+  FP_REQUIRE(dim % 4 == 0 && ld_xb % 4 == 0 && parts >= 1 && parts <= 64, "rowstats_cast: dim / ld_xb must be multiples of 4, parts in [1, 64]");
+  if (rows == 0) return FP_OK;
+  hipLaunchKernelGGL(rowstats_cast_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts);
+  FP_CHECK_LAUNCH("rowstats_cast");
   return FP_OK;
 }
 

@@ -43,7 +43,7 @@ def _interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: 
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
                  precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
-                 act_scales: Optional[torch.Tensor] = None) -> None:
+                 act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True) -> None:
         super().__init__()
         self.use_graph = use_graph  # replay the forward's launch sequence as one hipGraph (static buffers per batch shape)
         if arch is not None:  # non-hub architecture (unit tests use a tiny one)
@@ -78,6 +78,10 @@ class DinoFeatureExtractor(torch.nn.Module):
         if self.act_scales is not None and (precision != "fp8" or tuple(self.act_scales.shape) != (self.arch.depth, 4)):
             raise ValueError(f"act_scales is the [depth, 4] scale table of precision='fp8' (got {tuple(self.act_scales.shape)}, precision {precision})")
         self.precision = precision
+        # bf16 mode: the two LayerNorms of every block folded into the GEMMs around them (fp_vit_model.ln_fold): gain into the
+        # qkv / fc1 matrices, shift into their biases, LayerScale into the proj / fc2 matrices -- no LayerNorm kernel runs
+        # inside the blocks (they were 6.5 % of a step).  fold_layernorm=False keeps the kernel-per-LayerNorm sequence.
+        self.fold_layernorm = bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0"  # FP_LN_FOLD=0: A/B switch
         self._sd = state_dict if state_dict is not None else synthetic.make_vit_state_dict(self.arch, seed)
         self._device: Optional[torch.device] = None
         self._w: Dict[str, torch.Tensor] = {}
@@ -140,9 +144,48 @@ class DinoFeatureExtractor(torch.nn.Module):
         vec("norm.weight")
         vec("norm.bias")
         blocks = (_lib.VitBlock * a.depth)()
+        fold = self.fold_layernorm
+
+        def f32(key):
+            return sd[key].to(dev, torch.float32)
+
+        def folded_in(wkey, bkey, nkey, wmat=None, bvec=None):
+            """LayerNorm (gain g, shift s) in front of a Linear (W, b): W' = W diag(g) in bf16, b' = b + W s, colsum of W'."""
+            W = f32(wkey) if wmat is None else wmat
+            bb = f32(bkey) if bvec is None else bvec
+            g, sh = f32(nkey + ".weight"), f32(nkey + ".bias")
+            Wf = padded((W * g[None, :]).to(wdt))
+            return Wf, (bb + W @ sh).contiguous(), Wf.float().sum(dim=1).contiguous()
+
+        def folded_out(wkey, bkey, gkey):
+            """LayerScale gamma behind a Linear: W'' = diag(gamma) W in bf16, b'' = gamma * b."""
+            gm = f32(gkey)
+            return padded((f32(wkey) * gm[:, None]).to(wdt)), (gm * f32(bkey)).contiguous()
+
         for i in range(a.depth):
             p = f"blocks.{i}."
             b = blocks[i]
+            if fold:
+                b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
+                b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))
+                b.ls1, b.ls2 = ptr(vec(p + "ls1.gamma")), ptr(vec(p + "ls2.gamma"))
+                w[p + "qkv.wf"], w[p + "qkv.bf"], w[p + "qkv.cs"] = folded_in(p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1")
+                w[p + "proj.wf"], w[p + "proj.bf"] = folded_out(p + "attn.proj.weight", p + "attn.proj.bias", p + "ls1.gamma")
+                if a.ffn == "mlp":
+                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2")
+                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.fc2.weight", p + "mlp.fc2.bias", p + "ls2.gamma")
+                else:  # SwiGLU: rows of w12 interleaved (x1_j, x2_j), see below
+                    w12, b12 = f32(p + "mlp.w12.weight"), f32(p + "mlp.w12.bias")
+                    hdn = w12.shape[0] // 2
+                    w12i = torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1)
+                    b12i = torch.stack([b12[:hdn], b12[hdn:]], 1).reshape(-1)
+                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(None, None, p + "norm2", w12i, b12i)
+                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.w3.weight", p + "mlp.w3.bias", p + "ls2.gamma")
+                b.qkv_w, b.qkv_b, b.qkv_colsum = ptr(w[p + "qkv.wf"]), ptr(w[p + "qkv.bf"]), ptr(w[p + "qkv.cs"])
+                b.proj_w, b.proj_b = ptr(w[p + "proj.wf"]), ptr(w[p + "proj.bf"])
+                b.fc1_w, b.fc1_b, b.fc1_colsum = ptr(w[p + "fc1.wf"]), ptr(w[p + "fc1.bf"]), ptr(w[p + "fc1.cs"])
+                b.fc2_w, b.fc2_b = ptr(w[p + "fc2.wf"]), ptr(w[p + "fc2.bf"])
+                continue
             b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
             b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))
             b.ls1, b.ls2 = ptr(vec(p + "ls1.gamma")), ptr(vec(p + "ls2.gamma"))
@@ -169,6 +212,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
         m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
         m.ld_w_dim, m.ld_w_hidden = (a.dim + pad, a.hidden + pad) if pad else (0, 0)  # fp8: set by _to_fp8
+        m.ln_fold = int(fold)
         self._w, self._model, self._blocks, self._device = w, m, blocks, dev
         self._grids.clear()
         self._ws.clear()
@@ -207,6 +251,10 @@ class DinoFeatureExtractor(torch.nn.Module):
                 p8 = self._ld_pad8
                 bufs.append(torch.zeros(m_pad, max(a.dim, a.hidden) + p8, dtype=torch.uint8, device=dev))
             ws = _lib.VitWorkspace()
+            if self.fold_layernorm:  # bf16 copy of the residual stream + partial row sums per 128-column tile
+                bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=torch.bfloat16, device=dev))
+                bufs.append(torch.zeros(a.dim // 128 + 1, m_pad, 2, dtype=torch.float32, device=dev))
+                ws.xb, ws.stats = ptr(bufs[-2]), ptr(bufs[-1])
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
             ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
             ws.ld_y, ws.ld_h = (a.dim + self._ld_pad, a.hidden + self._ld_pad) if self._ld_pad else (0, 0)

@@ -135,6 +135,41 @@ def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma=None, 
     return out
 
 
+def gemm_bf16_resid_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: torch.Tensor, emit: bool = True, tile: int = 0, m_valid: Optional[int] = None):
+    """Producer of the folded-LayerNorm chain (epilogue 7): x (fp32, in place) += a @ w.T + bias; with emit also
+    -> (xb = bf16(x) [M, N], stats [N / 128, M, 2] partial (sum, sum of squares) per 128-column group)."""
+    require_cuda(a, w, bias, x)
+    M, K = a.shape
+    N = w.shape[0]
+    xb = torch.zeros(M, N, dtype=torch.bfloat16, device=a.device) if emit else None
+    stats = torch.zeros(N // 128, M, 2, dtype=torch.float32, device=a.device) if emit else None
+    call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(x), x.stride(0),
+         7 | (tile << 8), None, None, ptr(xb), N, ptr(stats), stream())
+    return xb, stats
+
+
+def ln_finalize(stats: torch.Tensor, dim: int, eps: float = 1e-6) -> torch.Tensor:
+    """stats [parts, M, 2] -> ln_row [M, 2] = (rstd, mean * rstd)."""
+    require_cuda(stats)
+    parts, M = stats.shape[0], stats.shape[1]
+    out = torch.empty(M, 2, dtype=torch.float32, device=stats.device)
+    call("fp_ln_finalize", ptr(stats), parts, M, M, dim, eps, ptr(out), stream())
+    return out
+
+
+def gemm_bf16_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, colsum: torch.Tensor, ln_row: torch.Tensor, epilogue: int = 0, out=None,
+                 tile: int = 0, m_valid: Optional[int] = None) -> torch.Tensor:
+    """Consumer of the folded-LayerNorm chain: out(bf16) = epi(rstd * (a @ w.T) - mean * rstd * colsum + bias), epilogue 0 / 1 (GELU) / 6 (SwiGLU)."""
+    require_cuda(a, w, bias, colsum, ln_row)
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=torch.bfloat16, device=a.device)
+    call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(out), out.stride(0),
+         epilogue | (tile << 8), ptr(colsum), ptr(ln_row), None, 0, None, stream())
+    return out
+
+
 def quantize_fp8(x: torch.Tensor, scale: float) -> torch.Tensor:
     """e4m3(clamp(x * scale, +-448)) -> torch.float8_e4m3fn tensor of x's shape (x fp32 or bf16, contiguous)."""
     require_cuda(x)

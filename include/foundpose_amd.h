@@ -26,7 +26,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 9
+#define FP_ABI_VERSION 10
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -141,6 +141,8 @@ typedef struct {
    * act_scale[0..3] quantise the inputs of qkv, proj, fc1, fc2 (static per-tensor scales from a calibration batch) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s;
   float act_scale[4];
+  /* fp_vit_model.ln_fold only: fp32 [N] sums of the rows of the (gain-folded, bf16-rounded) qkv_w / fc1_w */
+  const float *qkv_colsum, *fc1_colsum;
 } fp_vit_block;
 
 typedef struct {
@@ -159,6 +161,12 @@ typedef struct {
   int ld_w_dim, ld_w_hidden;  /* row strides (elements) of the block matrices with K = dim (qkv, proj, fc1) and with
                                  K = hidden (fc2); 0 = dense (dim / hidden).  A stride that is not a multiple of 2 KiB
                                  keeps the 8 rows of a staging instruction off one L2 channel */
+  int ln_fold;             /* FP_BF16 only.  1: the two LayerNorms of a block are folded into the GEMMs around them -- no
+                              LayerNorm kernel runs inside the blocks.  qkv_w / fc1_w then hold W * diag(ln weight) (bf16),
+                              qkv_b / fc1_b hold b + W ln_bias, *_colsum the row sums of those matrices; proj_w / fc2_w hold
+                              diag(LayerScale) W and proj_b / fc2_b hold LayerScale * b (ls1 / ls2 are then unused); the
+                              residual GEMMs (proj, fc2) also emit bf16(x) and per-row (sum x, sum x^2), and the qkv / fc1
+                              epilogues compute rstd * (acc - mean * colsum) + bias.  Needs workspace xb / stats. */
 } fp_vit_model;
 
 typedef struct {
@@ -172,6 +180,9 @@ typedef struct {
   int ld_y, ld_h, ld_qkv; /* row strides (elements) of y, h and qkv; 0 = dense (D / hidden / 3D) */
   int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
   int m_patch_pad; /* multiple of 128, >= B*Np */
+  void* xb;      /* ln_fold only: [m_pad, D] bf16 copy of the residual stream (row stride ld_y), the A operand of qkv / fc1 */
+  float* stats;  /* ln_fold only: [D / 128 + 1, m_pad, 2] fp32: partial row sums (sum x, sum x^2) per 128-column group of the
+                    producer, then one slot of (rstd, mean * rstd) per row */
 } fp_vit_workspace;
 
 /* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token
@@ -197,6 +208,18 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
  * tuning bits: epilogue | (128 << 8) or | (256 << 8) forces that block tile (default: chosen from the shape) */
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
+/* The GEMMs of a block with the LayerNorm folded in (fp_vit_model.ln_fold), exported for unit tests and benchmarks.
+ * epilogue 7 (producer, proj / fc2 with LayerScale folded into W and bias): out(f32) += acc + bias; if xb != NULL also
+ *   xb[M, ld_xb] = bf16(out) and stats[(col / 128) * M + row] = (sum, sum of squares) of the row over that 128-column
+ *   group (float2 per slot, N / 128 slots of M rows).
+ * epilogues 0 / 1 / 6 (consumer, qkv / fc1 with the LayerNorm gain folded into W, the shift into bias):
+ *   out = epi(ln_row[r].x * acc - ln_row[r].y * colsum[n] + bias[n]), ln_row [M, 2] = (rstd, mean * rstd) per row from
+ *   fp_ln_finalize, colsum [N] = row sums of W.  Tuning bits as in fp_gemm_bf16. */
+int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, void* out, int ldo,
+                    int epilogue, const float* colsum, const float* ln_row, void* xb, int ld_xb, float* stats, fp_stream_t stream);
+/* stats [parts, stats_stride, 2] partial row sums over `dim` columns in total -> ln_row [rows, 2] = (rstd, mean * rstd). */
+int fp_ln_finalize(const float* stats, int parts, int stats_stride, int rows, int dim, float eps, float* ln_row, fp_stream_t stream);
+
 /* fp8 GEMM (BASELINE config 5, "ViT-g/14 fp8"): A [M, K] and W [N, K] hold OCP e4m3 bytes (fp_quantize_fp8), products
  * and accumulation in fp32 on the block-scaled MFMA with unit scales (v_mfma_scale_f32_32x32x64_f8f6f4, twice the bf16
  * rate).  out = epilogue((acc + bias[n]) * col_scale[n]): col_scale = 1 / (activation scale x weight scale of channel

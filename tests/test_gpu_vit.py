@@ -439,3 +439,59 @@ def test_fp8_mode_loud_failures():
     from foundpose_amd import feature_util
     with pytest.raises(NotImplementedError, match="multiples of 256"):
         feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", precision="fp8")
+
+
+@pytest.mark.parametrize("version,size,layer", [("vits14-reg", 224, 9), ("vitl14-reg", 518, 3)])
+def test_layernorm_fold_vs_kernel_sequence(version, size, layer):
+    """bf16 mode with the block LayerNorms folded into the GEMMs (default) vs the LayerNorm-kernel sequence: two bf16
+    evaluations of the same network whose rounding points differ -- they agree at the bf16 level, and each is as close to the
+    fp32 oracle as the other."""
+    from foundpose_amd import feature_util
+    name = f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1"
+    arch = ARCHS[version]
+    imgs = synthetic.make_crops(3, size, seed=4)
+    sd = synthetic.make_vit_state_dict(arch, seed=21)
+    fold = feature_util.make_feature_extractor(name, state_dict=sd, precision="bf16").to("cuda")
+    plain = feature_util.make_feature_extractor(name, state_dict=sd, precision="bf16", fold_layernorm=False).to("cuda")
+    assert fold.fold_layernorm and not plain.fold_layernorm
+    a, b = fold(imgs.cuda())["feature_maps"].cpu(), plain(imgs.cuda())["feature_maps"].cpu()
+    ref = ov.extractor_forward(sd, arch, imgs, layer, True)["feature_maps"]
+    ea, eb, d = rel_err(a, ref), rel_err(b, ref), rel_err(a, b)
+    print(f"\n{version}@{size} layer {layer}: folded vs fp32 oracle {ea:.4f}, kernel sequence vs fp32 oracle {eb:.4f}, folded vs kernel sequence {d:.4f}")
+    assert d < 2e-2 and ea < 3e-2 and ea < 1.5 * eb + 2e-3
+
+
+@pytest.mark.parametrize("tile,M,D,N2", [(128, 256, 256, 512), (256, 512, 1024, 1024), (128, 384, 384, 1152)])
+def test_folded_layernorm_gemm_pair(tile, M, D, N2):
+    """The two halves of the LayerNorm fold at op level: the residual GEMM (epilogue 7) emits bf16(x) and the row's partial
+    sums next to the fp32 stream; the next GEMM normalises in its epilogue.  Together they must equal
+    Linear(LayerNorm(x_new)) computed the plain way (fp64 on the same bf16 operands), at one bf16 rounding of the result."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + D)
+    h = torch.randn(M, 2 * D, generator=g).to(torch.bfloat16)
+    w_out = (torch.randn(D, 2 * D, generator=g) * 0.05).to(torch.bfloat16)
+    b_out = torch.randn(D, generator=g)
+    x0 = torch.randn(M, D, generator=g) * 3 + 0.7
+    x = x0.clone().cuda()
+    xb, stats = ops.gemm_bf16_resid_ln(h.cuda(), w_out.cuda(), b_out.cuda(), x, tile=tile, m_valid=M - 3)
+    x_ref = x0.double() + h.double() @ w_out.double().T + b_out.double()
+    x_ref[M - 3:] = x0[M - 3:].double()                           # rows past M_valid stay untouched
+    assert rel_err(x.cpu(), x_ref) < 3e-5
+    assert torch.equal(xb[:M - 3].cpu(), x[:M - 3].cpu().to(torch.bfloat16))
+    parts = x[:M - 3].cpu().double().reshape(M - 3, D // 128, 128)
+    assert rel_err(stats[:, :M - 3, 0].cpu().T, parts.sum(-1)) < 1e-5 and rel_err(stats[:, :M - 3, 1].cpu().T, (parts ** 2).sum(-1)) < 1e-5
+    ln_row = ops.ln_finalize(stats, D)
+    mu, var = x_ref[:M - 3].mean(1), x_ref[:M - 3].var(1, unbiased=False)
+    assert rel_err(ln_row[:M - 3, 0].cpu(), 1 / torch.sqrt(var + 1e-6)) < 1e-5
+    # consumer: gain folded into W (rounded to bf16), shift into the bias
+    gain, shift = 1 + 0.1 * torch.randn(D, generator=g), 0.1 * torch.randn(D, generator=g)
+    w_in, b_in = torch.randn(N2, D, generator=g) * 0.05, torch.randn(N2, generator=g)
+    wf = (w_in * gain[None, :]).to(torch.bfloat16)
+    bf, cs = b_in + w_in @ shift, wf.float().sum(1)
+    for epi in (0, 1):
+        out = ops.gemm_bf16_ln(xb, wf.cuda(), bf.cuda(), cs.cuda(), ln_row, epilogue=epi, tile=tile, m_valid=M - 3)[:M - 3].cpu().double()
+        xn = (xb[:M - 3].cpu().double() - mu[:, None]) / torch.sqrt(var + 1e-6)[:, None]     # the same bf16 operand, normalised exactly
+        ref = xn @ wf.double().T + bf.double()
+        if epi == 1:
+            ref = torch.nn.functional.gelu(ref)
+        assert float((out - ref).abs().max()) < 1.5 * 2 ** -8 * float(ref.abs().max()), (epi, tile)
