@@ -329,10 +329,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
           if constexpr (LN_FOLD_OK) {
-            if (fold) {  // rstd * acc - (mean * rstd) * colsum + bias
+            if (fold) {  // rstd * acc - (mean * rstd) * colsum + bias, two columns per v_pk_fma_f32
               const float4 cs = gam[tn][g];
-              v0 = fmaf(rs, acc[tm][tn][4 * g + 0], fmaf(-mrs, cs.x, bs.x)); v1 = fmaf(rs, acc[tm][tn][4 * g + 1], fmaf(-mrs, cs.y, bs.y));
-              v2 = fmaf(rs, acc[tm][tn][4 * g + 2], fmaf(-mrs, cs.z, bs.z)); v3 = fmaf(rs, acc[tm][tn][4 * g + 3], fmaf(-mrs, cs.w, bs.w));
+              const f32x2 rs2 = {rs, rs}, nm2 = {-mrs, -mrs};
+              const f32x2 t01 = __builtin_elementwise_fma(nm2, f32x2{cs.x, cs.y}, f32x2{bs.x, bs.y});
+              const f32x2 t23 = __builtin_elementwise_fma(nm2, f32x2{cs.z, cs.w}, f32x2{bs.z, bs.w});
+              const f32x2 r01 = __builtin_elementwise_fma(rs2, f32x2{acc[tm][tn][4 * g + 0], acc[tm][tn][4 * g + 1]}, t01);
+              const f32x2 r23 = __builtin_elementwise_fma(rs2, f32x2{acc[tm][tn][4 * g + 2], acc[tm][tn][4 * g + 3]}, t23);
+              v0 = r01[0]; v1 = r01[1]; v2 = r23[0]; v3 = r23[1];
             }
           }
           if constexpr (F8 && EPI != GEMM_EPI_LS_RESID_F32) {  // dequantise before the non-linearity
