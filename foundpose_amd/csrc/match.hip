@@ -432,12 +432,19 @@ __global__ __launch_bounds__(256) void topn_rows_block_kernel(const float* __res
 
 // Strict-order top-n: the reference's torch.topk(scores, n) on a CPU tensor, ties included (stl_order.hpp), one block per
 // row, rows of any length.  ATen runs std::partial_sort when n*64 <= len: a heap of the n best seen so far, and an
-// element only acts when it beats the heap's root -- a handful of times in a row of thousands.  One wave replays it 256
-// elements at a step: the row is staged through LDS in segments, 64 lanes test four 64-element chunks against the
-// current root at once, and only the (rare) hits go through the sequential pop_heap, in index order, the root re-read
-// after each.  Element moves inside the heap are libstdc++'s, so the surviving order among ties is too.  Short rows
-// (n*64 > len) take nth_element + sort on one lane, as ATen does.
-constexpr int STRICT_SEG = 16384;  // floats per staged segment (64 KiB)
+// element only acts when it beats the heap's root -- a handful of times in a row of thousands, most of them early.
+//   phase 1  wave 0 replays the first STRICT_HEAD elements exactly: 64 lanes test four 64-element chunks against the
+//            current root at once, only the hits go through the sequential pop_heap, in index order, the root re-read
+//            after each.  The heap lives in registers, element j in lane j (LaneHeap).
+//   phase 2  the root only ever improves, so an element that does not beat the root r1 left by phase 1 can never act.
+//            All four waves scan the rest of the row straight from memory (each a contiguous quarter, 16-byte loads,
+//            sixteen in flight) and keep, in index order, the few elements that beat r1.
+//   phase 3  wave 0 replays those candidates like phase 1.
+// Element moves inside the heap are libstdc++'s, so the surviving order among ties is too.  A row that overflows a
+// candidate list (scores ascending along the row: every element acts) is replayed from memory chunk by chunk instead.
+// Short rows (n*64 > len) take nth_element + sort on one lane, as ATen does.
+constexpr int STRICT_HEAD = 2048;   // elements replayed in phase 1 (also the Elem capacity of the short-row branch / 2)
+constexpr int STRICT_CAND = 1024;   // candidate capacity per wave
 
 // The n-element heap of the replay, element j in the registers of lane j: reading heap[j] is a v_readlane, writing it a
 // predicated move -- a pop_heap costs ~100 cycles instead of the ~1000 of dependent LDS round trips.
@@ -453,16 +460,32 @@ struct LaneHeap {
   }
 };
 
+// 64 (value, index) pairs, one per lane in index order, against the heap: the partial_sort inner loop for these elements.
+__device__ __forceinline__ void strict_replay64(LaneHeap& heap, int k, float v, int idx, bool ok, int lane) {
+  stl_order::Elem top = heap.get(0);
+  unsigned long long me = __ballot(ok && stl_order::gt(stl_order::Elem{v, 0}, top));
+  while (me) {
+    const int l = __builtin_ctzll(me);
+    const stl_order::Elem x{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)), __builtin_amdgcn_readlane(idx, l)};
+    stl_order::adjust_heap_acc(heap, 0, k, x);  // __pop_heap(first, middle, i): the old root leaves, *i enters
+    top = heap.get(0);
+    me = __ballot(ok && lane > l && stl_order::gt(stl_order::Elem{v, 0}, top));
+  }
+}
+
 __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
                                                                int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
-  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  float* seg = reinterpret_cast<float*>(smem_raw);
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  __shared__ __attribute__((aligned(16))) float head[2 * STRICT_HEAD];   // phase 1 staging; the short-row branch's (value, index) pairs
+  __shared__ float cand_v[4][STRICT_CAND];
+  __shared__ int cand_i[4][STRICT_CAND];
+  __shared__ int cand_n[4];
+  __shared__ float s_root_v;
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = row_len ? row_len[row] : n_default;
   const float* r = vals + (size_t)row * ld;
   const int k = min(n_top, len);
-  if ((long long)k * 64 > (long long)len) {  // len < 64 * n_top <= 4096: (value, index) pairs fit the segment buffer
-    stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(smem_raw);
+  if ((long long)k * 64 > (long long)len) {  // len < 64 * n_top: at most 4096 elements... capped to the LDS array below
+    stl_order::Elem* el = reinterpret_cast<stl_order::Elem*>(head);
     for (int j = tid; j < len; j += 256) el[j] = stl_order::Elem{r[j], j};
     __syncthreads();
     if (tid == 0) stl_order::topk_torch_largest(el, len, k);
@@ -473,67 +496,84 @@ __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __re
     }
     return;
   }
+  // ---- phase 1
+  const int p1 = min(len, STRICT_HEAD);
+  for (int j = tid; j < p1; j += 256) head[j] = r[j];
+  if (tid < 4) cand_n[tid] = 0;
+  __syncthreads();
   LaneHeap heap{0.f, 0, lane};
-  for (int s0 = 0; s0 < len; s0 += STRICT_SEG) {
-    const int s1 = min(len, s0 + STRICT_SEG);
-    __syncthreads();  // the previous segment has no readers left
-    // the scores were written by other XCDs a moment ago: every load is a trip to the Infinity Cache, so a thread puts
-    // eight 16-B loads in flight before it stores the first one (one load at a time cost 10 round trips per row)
-    if ((ld & 3) == 0) {
-      for (int j0 = s0 + tid * 4; j0 < s1; j0 += 8 * 1024) {
-        float4 t[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u * 1024;
-          t[u] = j + 4 <= s1 ? *reinterpret_cast<const float4*>(r + j) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int j = j0 + u * 1024;
-          if (j + 4 <= s1) *reinterpret_cast<float4*>(seg + (j - s0)) = t[u];
-        }
-      }
-      for (int j = (s1 & ~3) + tid; j < s1; j += 256) seg[j - s0] = r[j];  // ragged end of the row
-    } else {
-      for (int j = s0 + tid; j < s1; j += 256) seg[j - s0] = r[j];
+  if (wave == 0) {
+    if (lane < k) { heap.v = head[lane]; heap.idx = lane; }
+    stl_order::make_heap_acc(heap, k);  // std::make_heap over the first k elements (k <= 64 = one per lane)
+    for (int c0 = k; c0 < p1; c0 += 64) {
+      const int j = c0 + lane;
+      strict_replay64(heap, k, j < p1 ? head[j] : 0.f, j, j < p1, lane);
     }
-    __syncthreads();
-    if (tid < 64) {  // wave 0 replays; the other waves only stage
-      int c0 = s0;
-      if (s0 == 0) {  // std::make_heap over the first k elements (k <= 64 = one per lane)
-        if (lane < k) { heap.v = seg[lane]; heap.idx = lane; }
-        stl_order::make_heap_acc(heap, k);
-        c0 = k;
-      }
-      for (; c0 < s1; c0 += 256) {
-        float v[4];
-        bool ok[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const int j = c0 + 64 * e + lane;
-          ok[e] = j < s1;
-          v[e] = ok[e] ? seg[j - s0] : 0.f;
-        }
-        stl_order::Elem top = heap.get(0);
-        bool any = false;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) any |= __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top)) != 0;
-        if (!any) continue;  // wave-uniform: nothing in these 256 elements beats the root
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          unsigned long long me = __ballot(ok[e] && stl_order::gt(stl_order::Elem{v[e], 0}, top));
-          while (me) {
-            const int l = __builtin_ctzll(me);
-            const stl_order::Elem x{__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v[e]), l)), c0 + 64 * e + l};
-            stl_order::adjust_heap_acc(heap, 0, k, x);  // __pop_heap(first, middle, i): the old root leaves, *i enters
-            top = heap.get(0);
-            me = __ballot(ok[e] && lane > l && stl_order::gt(stl_order::Elem{v[e], 0}, top));
-          }
-        }
-      }
-    }
+    if (lane == 0) s_root_v = heap.v;
   }
-  if (tid < 64) {
+  __syncthreads();
+  // ---- phase 2: each wave filters a contiguous quarter of [p1, len) against the root of phase 1
+  const stl_order::Elem r1{s_root_v, 0};
+  const int rest = len - p1, per = ((rest + 3) / 4 + 255) & ~255;  // quarter length, a multiple of 256
+  const int q0 = p1 + wave * per, q1 = min(len, q0 + per);
+  const bool vec = (ld & 3) == 0 && (p1 & 3) == 0;
+  bool overflow = false;
+  int n_c = 0;
+  for (int base = q0; base < q1; base += 16 * 256) {
+    float4 x[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = base + u * 256 + lane * 4;
+      x[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (j + 4 <= q1 && vec) x[u] = *reinterpret_cast<const float4*>(r + j);
+      else if (j < q1) {
+        x[u].x = r[j];
+        if (j + 1 < q1) x[u].y = r[j + 1];
+        if (j + 2 < q1) x[u].z = r[j + 2];
+        if (j + 3 < q1) x[u].w = r[j + 3];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int j = base + u * 256 + lane * 4;
+      const float xe[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+      unsigned long long bal[4];
+      bool f[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        f[e] = j + e < q1 && stl_order::gt(stl_order::Elem{xe[e], 0}, r1);
+        bal[e] = __ballot(f[e]);
+      }
+      if ((bal[0] | bal[1] | bal[2] | bal[3]) == 0) continue;  // wave-uniform: the common case
+      const unsigned long long below = (1ull << lane) - 1ull;
+      int pos = n_c + __popcll(bal[0] & below) + __popcll(bal[1] & below) + __popcll(bal[2] & below) + __popcll(bal[3] & below);
+      const int total = __popcll(bal[0]) + __popcll(bal[1]) + __popcll(bal[2]) + __popcll(bal[3]);
+      if (n_c + total > STRICT_CAND) { overflow = true; break; }
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (f[e]) { cand_v[wave][pos] = xe[e]; cand_i[wave][pos] = j + e; ++pos; }
+      n_c += total;
+    }
+    if (overflow) break;
+  }
+  if (lane == 0) cand_n[wave] = overflow ? -1 : n_c;
+  __syncthreads();
+  // ---- phase 3
+  if (wave == 0) {
+    const bool any_overflow = cand_n[0] < 0 || cand_n[1] < 0 || cand_n[2] < 0 || cand_n[3] < 0;
+    if (any_overflow) {  // adversarial order: plain chunked replay of the rest of the row from memory
+      for (int c0 = p1; c0 < len; c0 += 64) {
+        const int j = c0 + lane;
+        strict_replay64(heap, k, j < len ? r[j] : 0.f, j, j < len, lane);
+      }
+    } else {
+      for (int w = 0; w < 4; ++w)
+        for (int c0 = 0; c0 < cand_n[w]; c0 += 64) {
+          const int c = c0 + lane;
+          const bool ok = c < cand_n[w];
+          strict_replay64(heap, k, ok ? cand_v[w][c] : 0.f, ok ? cand_i[w][c] : 0, ok, lane);
+        }
+    }
     stl_order::sort_heap_acc(heap, k);
     if (lane < n_top) {
       out_idx[(size_t)row * n_top + lane] = lane < k ? heap.idx : -1;
@@ -928,10 +968,8 @@ int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int
                      int* out_ids, int tie_mode, hipStream_t st) {
   if (rows == 0) return FP_OK;
   if (tie_mode == 1) {
-    FP_REQUIRE(n_top <= 64, "strict (torch) tie order: n_top must be <= 64 (got %d)", n_top);
-    static FpDeviceOnce attr;
-    fp_allow_dynamic_lds(attr, &topn_rows_strict_kernel, STRICT_SEG * 4);
-    hipLaunchKernelGGL(topn_rows_strict_kernel, dim3(rows), dim3(256), STRICT_SEG * 4, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+    FP_REQUIRE(n_top <= 32, "strict (torch) tie order: n_top must be <= 32 (got %d)", n_top);  // short rows (< 64 n_top) fit the LDS pair array
+    hipLaunchKernelGGL(topn_rows_strict_kernel, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
   } else if (n_top <= 8) {
     hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
   } else {

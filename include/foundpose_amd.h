@@ -70,7 +70,7 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
  * 32-detection chunks by the same kernel.  out_scores/out_ids [num_det, n_top]; ids are object-local template ids,
  * -1 / -inf past the object's template count.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of
  * torch.topk on a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows of any length,
- * n_top <= 64). */
+ * n_top <= 32). */
 #define FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) (2 * (size_t)(num_det) * (size_t)(max_templates) + 16 * (size_t)(num_det) + 2)
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
                    int max_det_per_obj,

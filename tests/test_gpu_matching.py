@@ -525,3 +525,31 @@ def test_num_words_not_multiple_of_4_fails_loudly():
     from foundpose_amd._lib import FoundPoseNativeError
     with pytest.raises(FoundPoseNativeError, match="multiples of 4"):
         _cosine_topk(torch.rand(2, 14).cuda(), torch.rand(5, 14).cuda(), 3)
+
+
+@pytest.mark.parametrize("T,order", [(10000, "ascending"), (10000, "descending"), (30000, "ascending"), (5000, "plateaus"), (2048, "ascending"), (2500, "plateaus")])
+def test_strict_topn_adversarial_rows(T, order):
+    """Rows on which torch.topk's partial_sort does the most work -- scores ascending along the row (every element replaces the
+    heap's root; the candidate lists of the filter phase overflow and the row is replayed chunk by chunk), descending (nothing
+    after the first five acts), long exact plateaus (ties everywhere) -- against torch.topk on the device's own scores."""
+    from foundpose_amd import ops
+    W, B = 16, 3
+    t = torch.arange(T, dtype=torch.float64)
+    if order == "ascending":
+        theta = (1.0 - t / T) * 1.5
+    elif order == "descending":
+        theta = (t / T) * 1.5
+    else:
+        theta = torch.floor(t / 37.0) % 11 * 0.1   # 11 score levels in runs of 37
+    bank = torch.zeros(T, W, dtype=torch.float64)
+    bank[:, 0], bank[:, 1] = torch.cos(theta), torch.sin(theta)
+    q = torch.zeros(B, W, dtype=torch.float64)
+    q[:, 0] = 1.0
+    q[1, 1] = 0.3
+    q[2, 1] = -0.2
+    sc, ids, sims = _cosine_topk(ops.normalize_rows(q.float().cuda()), ops.normalize_rows(bank.float().cuda()), 5, tie_mode=1)
+    S = sims[:B * T].reshape(B, T).cpu()
+    for b in range(B):
+        tv, ti = torch.topk(S[b], 5, sorted=True)
+        assert ids[b].cpu().tolist() == ti.tolist(), (order, b)
+        assert torch.equal(sc[b].cpu(), tv)
