@@ -36,19 +36,39 @@ class FoundPoseEngine:
 
     def query_points(self, masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
         """filter_points_by_mask for the whole batch -> (points [sumQ,2], point_img [sumQ] i32, counts)."""
+        return self._query_points_end(*self._query_points_begin(masks))
+
+    def _query_points_begin(self, masks: torch.Tensor):
+        """Enqueues the mask test of every grid point and an asynchronous copy of the per-detection counts to pinned memory.
+        The counts are the one thing the host needs from the device per batch (segment tables of the matching stage); the
+        caller enqueues the ViT forward BEFORE waiting for them, so the wait ends as soon as the previous batch has drained
+        and the device never idles between batches (a blocking .tolist() here left a bubble per step)."""
         B, H, W = masks.shape
         pts, xi, yi, inside = self._grid(W, H, masks.device)
         on = (masks[:, yi, xi] != 0) & inside[None, :]
-        idx = on.nonzero()  # row-major: grouped by detection, grid order inside (like the reference)
-        counts = on.sum(1).tolist()  # the only host sync of a batch; done before the ViT is enqueued
+        cnt_host = torch.empty(B, dtype=torch.int32, pin_memory=True)
+        cnt_host.copy_(on.sum(1, dtype=torch.int32), non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return on, cnt_host, ev, pts
+
+    def _query_points_end(self, on, cnt_host, ev, pts):
+        ev.synchronize()
+        counts = cnt_host.tolist()
+        total = sum(counts)
+        try:
+            idx = torch.nonzero_static(on, size=total)  # row-major: grouped by detection, grid order inside (like the reference); no host sync
+        except (RuntimeError, NotImplementedError, AttributeError):
+            idx = on.nonzero()
         return pts[idx[:, 1]].contiguous(), idx[:, 0].to(torch.int32).contiguous(), counts
 
     def infer_batch(self, images: torch.Tensor, masks: torch.Tensor, det_obj: Optional[Sequence[int]] = None,
                     keep_debug: bool = False) -> MatchResult:
         B, _, H, W = images.shape
         det_obj = [0] * B if det_obj is None else list(det_obj)
-        q_pts, q_img, counts = self.query_points(masks)
-        fmap, _ = self.extractor.forward_tokens(images)
+        pending = self._query_points_begin(masks)
+        fmap, _ = self.extractor.forward_tokens(images)          # ~120 launches enqueued before the host waits for the counts
+        q_pts, q_img, counts = self._query_points_end(*pending)
         gh, gw = self.extractor.num_patches
         D = fmap.shape[-1]
         raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))

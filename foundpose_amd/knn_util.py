@@ -38,7 +38,10 @@ class KNN:
         if self.index is None:
             raise RuntimeError("KNN.search called before KNN.fit")
         if self.radius is not None:
-            raise NotImplementedError("range search (radius) is unused by the inference path and not implemented")
+            raise NotImplementedError(
+                "range search (radius) is not implemented on the MI355X path.  (No shipped config sets a radius, and the reference's "
+                "own branch calls index.range_search_with_radius (knn_util.py:86-89), a method faiss indices do not have -- the "
+                "faiss API is range_search(x, thresh) -> (lims, D, I) -- so there is no behaviour to match.)")
         src_device = data.device
         q = data.to("cuda", torch.float32)
         if self.metric == "cosine":
