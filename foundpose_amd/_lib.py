@@ -54,6 +54,7 @@ _PROTOS = {
     "fp_sample_bilinear": [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
     "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
+    "fp_vit_sample_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_vit_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, vp, vp, vp],
     "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],

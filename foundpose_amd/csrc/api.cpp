@@ -516,4 +516,13 @@ int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, in
   return FP_OK;
 }
 
+int fp_vit_sample_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w, int img_h,
+                           const float* points, const int32_t* point_img, int num_points, float* out, fp_stream_t stream) {
+  FP_REQUIRE(m && ws && ws->x && points && out, "fp_vit_sample_features: null pointer");
+  FP_REQUIRE(B >= 1 && grid_h >= 1 && grid_w >= 1 && img_w >= 1 && img_h >= 1, "fp_vit_sample_features: bad sizes");
+  const int ntok = 1 + m->registers + grid_h * grid_w;
+  return ln_sample_launch(ws->x, m->dim, m->norm_w, m->norm_b, 1e-6f, apply_norm, m->dim, ntok, 1 + m->registers, grid_h, grid_w, img_w, img_h,
+                          points, point_img, num_points, out, ST(stream));
+}
+
 }  // extern "C"

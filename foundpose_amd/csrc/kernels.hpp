@@ -142,6 +142,8 @@ struct LayerNormArgs {
   int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi
 };
 int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
+int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
+                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st);
 // x [rows, dim] fp32 -> xb = bf16(x) [rows, ld_xb] and stats[0 * stats_stride + row] = (sum x, sum x^2), slots 1..parts-1 zero
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);

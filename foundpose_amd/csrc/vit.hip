@@ -85,6 +85,124 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
   }
 }
 
+// Final LayerNorm + bilinear sampling in one pass (SURVEY 8b `fp_ln_gather_pca`, the LN + gather half): the reference
+// normalises the whole token map (dinov2_utils.py:138-142) and then samples it at the query points inside the mask
+// (feature_util.py:100-131) -- 38 % of the cells at the metric's disc mask.  Here one wave per query point normalises the
+// (up to) four tokens its bilinear footprint touches, straight from the residual stream, and combines them: the
+// [B, Np, D] fp32 map (180 MB at batch 32) is never written or re-read.  Arithmetic identical to layernorm_kernel followed
+// by sample_bilinear_kernel (same per-lane channel layout, same reduction order, same fma chain): bit-identical output.
+struct LnSampleArgs {
+  const float* x; int ld_x;            // residual stream [B * ntok, D]
+  const float* weight; const float* bias; float eps; int apply_norm;
+  int dim, ntok, skip, gh, gw, img_w, img_h;
+  const float* points; const int* point_img; int num_points;
+  float* out;                           // [num_points, dim]
+};
+
+template <int VEC>
+__global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
+  constexpr int MAXI = 2048 / (64 * VEC);
+  typedef __attribute__((ext_vector_type(VEC))) float vec_t;
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (p >= a.num_points) return;
+  const int nv = a.dim / (64 * VEC);
+  const int img = a.point_img ? a.point_img[p] : 0;
+  const float px = a.points[2 * p], py = a.points[2 * p + 1];
+  // coordinate and weight arithmetic of torch's CPU grid_sampler, as in sample_bilinear_kernel (match.hip)
+  float ix, iy;
+  {
+#pragma clang fp contract(off)
+    const float sx = 2.0f / (float)a.img_w, sy = 2.0f / (float)a.img_h;
+    const float ux = sx * px, uy = sy * py;
+    const float u1 = (ux - 1.0f) + 1.0f, v1 = (uy - 1.0f) + 1.0f;
+    ix = fmaf(u1, (float)a.gw / 2.f, -0.5f);
+    iy = fmaf(v1, (float)a.gh / 2.f, -0.5f);
+  }
+  const float fx = floorf(ix), fy = floorf(iy);
+  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  float wx1, wx0, wy1, wy0;
+  {
+#pragma clang fp contract(off)
+    wx1 = ix - fx; wx0 = 1.f - wx1; wy1 = iy - fy; wy0 = 1.f - wy1;
+  }
+  vec_t acc[MAXI];
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[i][e] = 0.f;
+  // taps in torch's order nw, ne, sw, se; NOT unrolled: one tap's row in registers at a time (unrolled, the four taps' loads
+  // were hoisted together and the kernel spilled 1792 VGPRs)
+#pragma unroll 1
+  for (int t = 0; t < 4; ++t) {
+    const int txt = x0 + (t & 1), tyt = y0 + (t >> 1);
+    float wtt;
+    {
+#pragma clang fp contract(off)
+      wtt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);   // s*e, s*w, n*e, n*w
+    }
+    const bool valid = txt >= 0 && txt < a.gw && tyt >= 0 && tyt < a.gh;  // wave-uniform
+    vec_t y[MAXI];
+    if (valid) {
+      const float* x = a.x + ((size_t)img * a.ntok + a.skip + tyt * a.gw + txt) * a.ld_x;
+      vec_t v[MAXI];
+#pragma unroll
+      for (int i = 0; i < MAXI; ++i)
+        if (i < nv) v[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
+      if (a.apply_norm) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+          if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) s += v[i][e];
+          }
+        const float mean = wave_sum(s) / (float)a.dim;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+          if (i < nv) {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+              const float d = v[i][e] - mean;
+              ss += d * d;
+            }
+          }
+        const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+          if (i < nv) {
+            const int c = (i * 64 + lane) * VEC;
+            const vec_t w = *reinterpret_cast<const vec_t*>(a.weight + c);
+            const vec_t b = *reinterpret_cast<const vec_t*>(a.bias + c);
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) y[i][e] = (v[i][e] - mean) * rstd * w[e] + b[e];
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < MAXI; ++i)
+          if (i < nv) y[i] = v[i];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXI; ++i)
+      if (i < nv) {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+          const float val = valid ? y[i][e] : 0.f;
+          if (t == 0) {
+#pragma clang fp contract(off)
+            acc[i][e] = val * wtt;
+          } else {
+            acc[i][e] = fmaf(val, wtt, acc[i][e]);
+          }
+        }
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i)
+    if (i < nv) *reinterpret_cast<vec_t*>(a.out + (size_t)p * a.dim + (i * 64 + lane) * VEC) = acc[i];
+}
+
 // images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
 // column = c*P*P + py*P + px (the flattening of the conv weight [D,3,P,P]); columns >= 3*P*P are zero.
 // A patch row is 14 pixels wide: whichever side a thread walks, the other side is touched in 28/56-byte pieces (one
@@ -212,6 +330,17 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   else
     hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("layernorm");
+  return FP_OK;
+}
+
+int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
+                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st) {
+  FP_REQUIRE(dim % 128 == 0 && dim <= 2048, "ln_sample: dim (%d) must be a multiple of 128, at most 2048", dim);
+  if (num_points == 0) return FP_OK;
+  LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out};
+  if (dim % 256 == 0) hipLaunchKernelGGL(ln_sample_kernel<4>, dim3(cdiv(num_points, 4)), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(ln_sample_kernel<2>, dim3(cdiv(num_points, 4)), dim3(256), 0, st, a);
+  FP_CHECK_LAUNCH("ln_sample");
   return FP_OK;
 }
 

@@ -296,6 +296,40 @@ class DinoFeatureExtractor(torch.nn.Module):
         self.num_patches = (gh, gw)
         return fmap, cls
 
+    def forward_hidden(self, images: torch.Tensor) -> Tuple[int, int, int]:
+        """Runs the backbone up to the hooked block and leaves its output in the workspace (no final norm, no feature map):
+        the first half of the engine's fused path, followed by sample_patch_features.  -> (B, gh, gw).  Token facet only."""
+        if self._model is None:
+            raise _lib.FoundPoseNativeError("call extractor.to('cuda') before running it")
+        if self.facet != "token" or self.use_graph:
+            raise NotImplementedError("forward_hidden serves the eager token path")
+        _lib.require_cuda(images)
+        images = images.float().contiguous()
+        B, _, H, W = images.shape
+        if H % self.patch_size or W % self.patch_size:
+            raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {self.patch_size}")
+        gh, gw = H // self.patch_size, W // self.patch_size
+        pos_patch, prefix = self._grid_tables(gh, gw)
+        self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
+        ws, _ = self._workspace(B, gh, gw)
+        if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
+            raise _lib.FoundPoseNativeError("precision='fp8' needs its static activation scales before the first forward (act_scales= / calibrate_fp8)")
+        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        self.num_patches = (gh, gw)
+        self._hidden = (B, gh, gw, H, W)
+        return B, gh, gw
+
+    def sample_patch_features(self, points: torch.Tensor, point_img: torch.Tensor) -> torch.Tensor:
+        """Final norm + sample_feature_map_at_points for the batch forward_hidden just ran: points [P, 2] in image coordinates,
+        point_img [P] i32 -> [P, D] fp32, bit-identical to forward()["feature_maps"] sampled with ops.sample_bilinear."""
+        B, gh, gw, H, W = self._hidden
+        ws, _ = self._workspace(B, gh, gw)
+        points = points.float().contiguous()
+        out = torch.empty(points.shape[0], self.arch.dim, dtype=torch.float32, device=points.device)
+        call("fp_vit_sample_features", C.byref(self._model), C.byref(ws), B, gh, gw, int(self.apply_norm), W, H, ptr(points), ptr(point_img),
+             points.shape[0], ptr(out), stream())
+        return out
+
     def _forward_facet(self, images, B, H, W, gh, gw):
         """key / query / value facet (dinov2_utils.py:176-194, 294-311 in the reference): the qkv projection of
         blocks[layer] is what the forward leaves in the workspace; per token the reference orders the vector (d, head)."""

@@ -6,6 +6,7 @@ sampling -> PCA projection -> establish_correspondences. Detections are independ
 shards them across its GPUs (one process per GPU) and gathers fixed-size result records at the end.
 """
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -67,11 +68,17 @@ class FoundPoseEngine:
         B, _, H, W = images.shape
         det_obj = [0] * B if det_obj is None else list(det_obj)
         pending = self._query_points_begin(masks)
-        fmap, _ = self.extractor.forward_tokens(images)          # ~120 launches enqueued before the host waits for the counts
-        q_pts, q_img, counts = self._query_points_end(*pending)
-        gh, gw = self.extractor.num_patches
-        D = fmap.shape[-1]
-        raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
+        fused = self.extractor.facet == "token" and not self.extractor.use_graph and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"  # env: A/B switch
+        if fused:   # final norm + sampling in one pass over the query points only: the [B, Np, D] map is never written
+            self.extractor.forward_hidden(images)                # ~120 launches enqueued before the host waits for the counts
+            q_pts, q_img, counts = self._query_points_end(*pending)
+            raw = self.extractor.sample_patch_features(q_pts, q_img)
+        else:
+            fmap, _ = self.extractor.forward_tokens(images)
+            q_pts, q_img, counts = self._query_points_end(*pending)
+            gh, gw = self.extractor.num_patches
+            D = fmap.shape[-1]
+            raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
         feats = self._project(raw, counts, det_obj)
         return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
 

@@ -197,6 +197,14 @@ int fp_vit_forward(const fp_vit_model* model, const fp_vit_workspace* ws, const 
 int fp_vit_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int n_patches, int apply_norm,
                     float* fmap, float* cls, fp_stream_t stream);
 
+/* Final LayerNorm + sample_feature_map_at_points in one pass (SURVEY 8b `fp_ln_gather_pca`, its LayerNorm + gather half;
+ * fp_pca_project finishes): out[p, :] = bilinear sample (feature_util.py:100-131) at points[p] (image coordinates, image
+ * img_w x img_h, detection point_img[p]) of LayerNorm(tokens) (dinov2_utils.py:138-142; apply_norm = 0: raw tokens),
+ * computed from the residual stream fp_vit_forward left in ws->x -- the [B, Np, D] feature map is never written.
+ * Bit-identical to fp_vit_features followed by fp_sample_bilinear.  out [num_points, D] fp32. */
+int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,
+                           int img_h, const float* points, const int32_t* point_img, int num_points, float* out, fp_stream_t stream);
+
 /* Building blocks, exported for unit tests and for callers that schedule the layers themselves. */
 int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
                 fp_stream_t stream);

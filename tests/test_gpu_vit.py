@@ -495,3 +495,24 @@ def test_folded_layernorm_gemm_pair(tile, M, D, N2):
         if epi == 1:
             ref = torch.nn.functional.gelu(ref)
         assert float((out - ref).abs().max()) < 1.5 * 2 ** -8 * float(ref.abs().max()), (epi, tile)
+
+
+@pytest.mark.parametrize("version,size,precision", [("vits14-reg", 224, "fp32"), ("vits14-reg", 224, "bf16"), ("vitl14-reg", 518, "bf16")])
+def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
+    """fp_vit_sample_features (final LayerNorm + bilinear sampling at the query points only, straight from the residual
+    stream) == forward()["feature_maps"] sampled with fp_sample_bilinear, bit for bit -- also at points off the cell centres
+    and outside the image, where the four taps and the zero padding matter."""
+    from foundpose_amd import feature_util, ops
+    layer = 3
+    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision=precision).to("cuda")
+    B = 3
+    imgs = synthetic.make_crops(B, size, seed=2).cuda()
+    g = torch.Generator().manual_seed(0)
+    grid = feature_util.generate_grid_points((size, size), 14.0)
+    pts = torch.cat([grid[torch.randperm(grid.shape[0], generator=g)[:200]], torch.rand(150, 2, generator=g) * (size + 20) - 10]).cuda()
+    img_of = torch.randint(0, B, (pts.shape[0],), generator=g).to(torch.int32).cuda()
+    fmap = ex(imgs)["feature_maps"]
+    want = ops.sample_bilinear(fmap, pts, img_of, (size, size))
+    ex.forward_hidden(imgs)
+    got = ex.sample_patch_features(pts, img_of)
+    assert torch.equal(got, want)
