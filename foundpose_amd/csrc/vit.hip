@@ -99,9 +99,10 @@ struct LnSampleArgs {
   float* out;                           // [num_points, dim]
 };
 
-template <int VEC>
+// NVT = vectors of VEC floats a lane may hold of one row (dim <= 64 * VEC * NVT); small NVT keeps two rows in registers
+// (the current tap's and the next tap's, in flight under the current one's two reductions) at 4+ waves per SIMD.
+template <int VEC, int NVT>
 __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
-  constexpr int MAXI = 2048 / (64 * VEC);
   typedef __attribute__((ext_vector_type(VEC))) float vec_t;
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (p >= a.num_points) return;
@@ -119,76 +120,78 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
     iy = fmaf(v1, (float)a.gh / 2.f, -0.5f);
   }
   const float fx = floorf(ix), fy = floorf(iy);
-  const int x0 = (int)fx, y0 = (int)fy, x1 = x0 + 1, y1 = y0 + 1;
+  const int x0 = (int)fx, y0 = (int)fy;
   float wx1, wx0, wy1, wy0;
   {
 #pragma clang fp contract(off)
     wx1 = ix - fx; wx0 = 1.f - wx1; wy1 = iy - fy; wy0 = 1.f - wy1;
   }
-  vec_t acc[MAXI];
+  // tap t of torch's order nw, ne, sw, se: grid cell (x0 + (t & 1), y0 + (t >> 1)); a tap outside the grid contributes zero
+  auto tap_valid = [&](int t) {
+    const int tx = x0 + (t & 1), ty = y0 + (t >> 1);
+    return tx >= 0 && tx < a.gw && ty >= 0 && ty < a.gh;  // wave-uniform
+  };
+  auto tap_load = [&](int t, vec_t (&v)[NVT]) {
+    int tx = x0 + (t & 1), ty = y0 + (t >> 1);
+    tx = tx < 0 ? 0 : (tx >= a.gw ? a.gw - 1 : tx);   // an invalid tap reads a valid row and is zeroed below
+    ty = ty < 0 ? 0 : (ty >= a.gh ? a.gh - 1 : ty);
+    const float* x = a.x + ((size_t)img * a.ntok + a.skip + ty * a.gw + tx) * a.ld_x;
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
+    for (int i = 0; i < NVT; ++i)
+      if (i < nv) v[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
+  };
+  vec_t acc[NVT], v[NVT], vn[NVT];
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) acc[i][e] = 0.f;
-  // taps in torch's order nw, ne, sw, se; NOT unrolled: one tap's row in registers at a time (unrolled, the four taps' loads
-  // were hoisted together and the kernel spilled 1792 VGPRs)
+  for (int i = 0; i < NVT; ++i)
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) { acc[i][e] = 0.f; vn[i][e] = 0.f; }
+  tap_load(0, v);
+  // NOT unrolled: unrolled, the four taps' rows are all hoisted to the top (1792 spilled VGPRs at dim 2048)
 #pragma unroll 1
   for (int t = 0; t < 4; ++t) {
-    const int txt = x0 + (t & 1), tyt = y0 + (t >> 1);
+    if (t < 3) tap_load(t + 1, vn);
     float wtt;
     {
 #pragma clang fp contract(off)
       wtt = ((t >> 1) ? wy1 : wy0) * ((t & 1) ? wx1 : wx0);   // s*e, s*w, n*e, n*w
     }
-    const bool valid = txt >= 0 && txt < a.gw && tyt >= 0 && tyt < a.gh;  // wave-uniform
-    vec_t y[MAXI];
-    if (valid) {
-      const float* x = a.x + ((size_t)img * a.ntok + a.skip + tyt * a.gw + txt) * a.ld_x;
-      vec_t v[MAXI];
+    const bool valid = tap_valid(t);
+    if (a.apply_norm) {
+      float s = 0.f;
 #pragma unroll
-      for (int i = 0; i < MAXI; ++i)
-        if (i < nv) v[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
-      if (a.apply_norm) {
-        float s = 0.f;
+      for (int i = 0; i < NVT; ++i)
+        if (i < nv) {
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-          if (i < nv) {
+          for (int e = 0; e < VEC; ++e) s += v[i][e];
+        }
+      const float mean = wave_sum(s) / (float)a.dim;
+      float ss = 0.f;
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) s += v[i][e];
+      for (int i = 0; i < NVT; ++i)
+        if (i < nv) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) {
+            const float d = v[i][e] - mean;
+            ss += d * d;
           }
-        const float mean = wave_sum(s) / (float)a.dim;
-        float ss = 0.f;
+        }
+      const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
 #pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-          if (i < nv) {
+      for (int i = 0; i < NVT; ++i)
+        if (i < nv) {
+          const int c = (i * 64 + lane) * VEC;
+          const vec_t w = *reinterpret_cast<const vec_t*>(a.weight + c);
+          const vec_t b = *reinterpret_cast<const vec_t*>(a.bias + c);
 #pragma unroll
-            for (int e = 0; e < VEC; ++e) {
-              const float d = v[i][e] - mean;
-              ss += d * d;
-            }
-          }
-        const float rstd = rsqrtf(wave_sum(ss) / (float)a.dim + a.eps);
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-          if (i < nv) {
-            const int c = (i * 64 + lane) * VEC;
-            const vec_t w = *reinterpret_cast<const vec_t*>(a.weight + c);
-            const vec_t b = *reinterpret_cast<const vec_t*>(a.bias + c);
-#pragma unroll
-            for (int e = 0; e < VEC; ++e) y[i][e] = (v[i][e] - mean) * rstd * w[e] + b[e];
-          }
-      } else {
-#pragma unroll
-        for (int i = 0; i < MAXI; ++i)
-          if (i < nv) y[i] = v[i];
-      }
+          for (int e = 0; e < VEC; ++e) v[i][e] = (v[i][e] - mean) * rstd * w[e] + b[e];
+        }
     }
 #pragma unroll
-    for (int i = 0; i < MAXI; ++i)
+    for (int i = 0; i < NVT; ++i)
       if (i < nv) {
 #pragma unroll
         for (int e = 0; e < VEC; ++e) {
-          const float val = valid ? y[i][e] : 0.f;
+          const float val = valid ? v[i][e] : 0.f;
           if (t == 0) {
 #pragma clang fp contract(off)
             acc[i][e] = val * wtt;
@@ -197,9 +200,11 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
           }
         }
       }
+#pragma unroll
+    for (int i = 0; i < NVT; ++i) v[i] = vn[i];
   }
 #pragma unroll
-  for (int i = 0; i < MAXI; ++i)
+  for (int i = 0; i < NVT; ++i)
     if (i < nv) *reinterpret_cast<vec_t*>(a.out + (size_t)p * a.dim + (i * 64 + lane) * VEC) = acc[i];
 }
 
@@ -338,8 +343,11 @@ int ln_sample_launch(const float* x, int ld_x, const float* weight, const float*
   FP_REQUIRE(dim % 128 == 0 && dim <= 2048, "ln_sample: dim (%d) must be a multiple of 128, at most 2048", dim);
   if (num_points == 0) return FP_OK;
   LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out};
-  if (dim % 256 == 0) hipLaunchKernelGGL(ln_sample_kernel<4>, dim3(cdiv(num_points, 4)), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL(ln_sample_kernel<2>, dim3(cdiv(num_points, 4)), dim3(256), 0, st, a);
+  const dim3 grid(cdiv(num_points, 4));
+  if (dim % 256 == 0 && dim <= 1024) hipLaunchKernelGGL((ln_sample_kernel<4, 4>), grid, dim3(256), 0, st, a);
+  else if (dim % 256 == 0) hipLaunchKernelGGL((ln_sample_kernel<4, 8>), grid, dim3(256), 0, st, a);
+  else if (dim <= 512) hipLaunchKernelGGL((ln_sample_kernel<2, 4>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((ln_sample_kernel<2, 16>), grid, dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("ln_sample");
   return FP_OK;
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Micro-benchmarks of the hot kernels at the benchmark shapes (ViT-L/14-reg, 518^2, batch 32).
-    python tools/bench_kernels.py [gemm] [attn] [ln]
+    python tools/bench_kernels.py [gemm] [fp8] [attn] [cos] [ln] [crop] [match]
 """
 import os
 import sys
@@ -72,6 +72,43 @@ def main():
                                          ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)
                 passes = (Bq + 31) // 32
                 print(f"cosine_topk T={T} W={W} B={Bq} tie_mode={mode}: {ms*1e3:8.1f} us  {passes*(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes x {passes} pass(es))", flush=True)
+    if "match" in what:
+        # the three exact-fp32 tile launches of one matching step at the bench shapes: PCA 1024 -> 256 of 32 x 517 patches,
+        # visual-word 3-NN (2048 words), cyclic distance tiles of 32 x 5 (query crop, template) pairs
+        from foundpose_amd._lib import call, ptr, stream
+        g = torch.Generator(device=dev).manual_seed(0)
+        Bq, Q, d, T, n_top, K = 32, 517, 256, 10000, 5, 300
+        raw = torch.randn(Bq * Q, 1024, device=dev, generator=g)
+        comps = torch.linalg.qr(torch.randn(1024, d, device=dev, generator=g))[0].T.contiguous()
+        mp = torch.randn(d, device=dev, generator=g)
+        ms = timeit(lambda: ops.pca_project(raw, comps, mp))
+        print(f"pca_project [{Bq*Q}, 1024] -> {d}: {ms*1e3:8.1f} us  {2.0*Bq*Q*1024*d/ms/1e9:7.1f} TF/s (fp32 MFMA peak 157)", flush=True)
+        qf = ops.pca_project(raw, comps, mp)
+        words = torch.randn(2048, d, device=dev, generator=g)
+        qn, wn = ops.sqnorm_rows(qf), ops.sqnorm_rows(words)
+        ms = timeit(lambda: ops.knn_l2(qf, words, 3, qn, wn))
+        print(f"knn_l2 k=3 [{Bq*Q}] x 2048 words d={d}: {ms*1e3:8.1f} us  {2.0*Bq*Q*2048*d/ms/1e9:7.1f} TF/s", flush=True)
+        pc = torch.randint(300, 451, (T,), generator=torch.Generator().manual_seed(1))
+        tpl_off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(pc, 0)]).to(torch.int32).to(dev)
+        P = int(tpl_off[-1])
+        feats = torch.randn(P, d, device=dev, generator=g)
+        fn = ops.sqnorm_rows(feats)
+        verts = torch.randn(P, 3, device=dev, generator=g)
+        pts = torch.rand(Bq * Q, 2, device=dev, generator=g) * 518
+        q_off = (torch.arange(Bq + 1, dtype=torch.int32) * Q).to(dev)
+        tpl_ids = torch.randint(0, T, (Bq, n_top), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(dev)
+        feat_base = torch.zeros(Bq, dtype=torch.int32, device=dev)
+        p_max = int(pc.max())
+        scratch = torch.empty(Bq * n_top * (Q + p_max), dtype=torch.int64, device=dev)
+        o = dict(counts=torch.empty(Bq, n_top, dtype=torch.int32, device=dev), q_ids=torch.empty(Bq, n_top, K, dtype=torch.int32, device=dev),
+                 f_ids=torch.empty(Bq, n_top, K, dtype=torch.int32, device=dev), dists=torch.empty(Bq, n_top, K, device=dev),
+                 conf=torch.empty(Bq, n_top, K, device=dev), c2d=torch.empty(Bq, n_top, K, 2, device=dev), c3d=torch.empty(Bq, n_top, K, 3, device=dev))
+        ms = timeit(lambda: call("fp_cyclic_buddies", ptr(qf), ptr(qn), ptr(pts), ptr(q_off), Bq, Q, ptr(feats), ptr(fn), ptr(tpl_off), p_max,
+                                 ptr(verts), ptr(tpl_ids), ptr(feat_base), n_top, d, K, K, ptr(scratch), ptr(o["counts"]), ptr(o["q_ids"]),
+                                 ptr(o["f_ids"]), ptr(o["dists"]), ptr(o["conf"]), ptr(o["c2d"]), ptr(o["c3d"]), 1, stream()))
+        live = float((pc[tpl_ids.cpu().long()].double() * Q).sum())
+        print(f"cyclic_buddies {Bq} x {n_top} pairs, Q={Q}, P=300..450 (p_max {p_max}): {ms*1e3:8.1f} us whole call "
+              f"(memset + distance tiles + selection)  {2.0*live*d/ms/1e9:7.1f} TF/s on the live distances", flush=True)
     if "ln" in what:
         x = torch.randn(M, D, device=dev)
         w, b = torch.randn(D, device=dev), torch.randn(D, device=dev)
