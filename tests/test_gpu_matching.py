@@ -30,7 +30,11 @@ def test_sqnorm_bitexact():
 
 
 @pytest.mark.parametrize("m,n,d,k", [(300, 500, 256, 1), (300, 500, 256, 3), (77, 2048, 256, 3), (1, 5, 32, 1),
-                                     (513, 129, 64, 5), (40, 40, 256, 40), (200, 300, 36, 2)])
+                                     (513, 129, 64, 5), (40, 40, 256, 40), (200, 300, 36, 2),
+                                     # ragged edge tiles of the 128 x 128 engine (1x4 / 4x1 wave cuts, dead 32-blocks): every epilogue
+                                     (133, 133, 64, 1), (133, 133, 64, 3), (37, 300, 32, 3), (300, 37, 32, 3), (300, 37, 32, 1),
+                                     (64, 64, 32, 5), (65, 200, 32, 1), (197, 70, 32, 3), (160, 193, 32, 12), (33, 161, 32, 8),
+                                     (5, 517, 32, 1), (517, 5, 32, 1), (517, 5, 32, 4), (129, 97, 32, 1), (97, 129, 32, 2)])
 def test_knn_l2_bitexact(m, n, d, k):
     from foundpose_amd import ops
     rng = np.random.default_rng(m * 7 + n)
@@ -44,6 +48,44 @@ def test_knn_l2_bitexact(m, n, d, k):
     o_d2, o_idx = clib.l2_knn(q, db, k)
     assert np.array_equal(idx.cpu().numpy().astype(np.int64), o_idx)
     assert np.array_equal(d2.cpu().numpy(), o_d2)  # bitwise: MFMA fp32 == k-ordered fmaf chain
+
+
+@pytest.mark.parametrize("Q,P", [(5, 5), (5, 140), (140, 5), (33, 70), (70, 33), (64, 129), (129, 64), (133, 133), (517, 389), (389, 517),
+                                 (97, 200), (200, 97), (1, 300), (300, 1)])
+def test_cyclic_buddies_pair_edge_tiles(Q, P):
+    """One (query crop, template) pair at sizes that put every wave cut of the distance tile (2x2, 1x4, 4x1, dead blocks) on
+    both the row side (query -> nearest template patch) and the column side (template patch -> nearest query patch):
+    ids, cycle distances and scores equal the oracle's, in the reference's torch.topk order."""
+    from foundpose_amd import corresp_util
+    rng = np.random.default_rng(Q * 1000 + P)
+    obj = rng.standard_normal((P, 64)).astype(np.float32)
+    qf = rng.standard_normal((Q, 64)).astype(np.float32)
+    n_copy = min(Q, P) // 2
+    qf[:n_copy] = obj[rng.permutation(P)[:n_copy]]            # exact buddies (zero feature distance)
+    if Q > 3:
+        qf[Q - 1] = qf[0]                                      # duplicated query patch: exact ties on the column side
+    if P > 3:
+        obj[P - 1] = obj[1]                                    # duplicated template patch: exact ties on the row side
+    pts = (rng.integers(0, 37, (Q, 2)) * 14 + 7).astype(np.float32)
+    for top_k in (300, 7):
+        q_ids, o_ids, dists, scores = corresp_util.cyclic_buddies_matching(cu(pts), cu(qf), None, cu(obj), None, top_k)
+        o_q, o_o, o_d, o_s, _ = om.cyclic_buddies(pts, qf, obj, top_k, topk_mode="torch")
+        assert np.array_equal(q_ids.cpu().numpy(), o_q)
+        assert np.array_equal(o_ids.cpu().numpy(), o_o)
+        assert np.array_equal(dists.cpu().numpy(), o_d)
+        assert np.array_equal(scores.cpu().numpy(), o_s, equal_nan=True)
+
+
+def test_gemm_f32_edge_tiles_exact_chain():
+    """Plain-store epilogue on ragged tiles: every output equals the k-ascending fmaf chain of the oracle, bit for bit."""
+    from foundpose_amd import ops
+    rng = np.random.default_rng(11)
+    for m, n, K in [(5, 133, 36), (133, 5, 36), (70, 70, 64), (33, 200, 32), (200, 33, 32), (129, 129, 40), (64, 65, 32), (260, 256, 128)]:
+        a = rng.standard_normal((m, K)).astype(np.float32)
+        w = rng.standard_normal((n, K)).astype(np.float32)
+        got = ops.gemm_f32(cu(a), cu(w)).cpu().numpy()
+        ref = np.stack([clib.dot_rows(w, a[i]) for i in range(m)])
+        assert np.array_equal(got, ref), (m, n, K)
 
 
 def test_knn_interface_matches_reference_conventions():
