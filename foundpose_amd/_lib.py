@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -99,7 +99,7 @@ def lib() -> C.CDLL:
 
 def cosine_scratch_floats(num_det: int, max_templates: int) -> int:
     """FP_COSINE_SCRATCH_FLOATS of include/foundpose_amd.h."""
-    return 2 * num_det * max_templates + 16 * num_det + 2
+    return 2 * num_det * max_templates + 17 * num_det + 2
 
 
 def exported_symbols():

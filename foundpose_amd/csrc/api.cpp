@@ -108,6 +108,7 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
     c.desc_n = desc_n; c.bank_n = bank_n; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
     c.sims = scratch_sims; c.ld_sims = max_templates;
     c.cand = reinterpret_cast<unsigned long long*>(scratch_sims + (size_t)num_det * max_templates + ((size_t)num_det * max_templates & 1));
+    c.need_replay = reinterpret_cast<int*>(scratch_sims + 2 * (size_t)num_det * max_templates + 16 * (size_t)num_det + 2);  // behind the keys
     return launch_cosine_topk(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores,
                               out_ids, tie_mode, ST(stream));
   }

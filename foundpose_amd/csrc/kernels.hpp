@@ -166,12 +166,13 @@ struct CosineArgs {
   float* sims; int ld_sims;  // [num_det, ld_sims] finished scores
   int k_slices;              // set by the launcher: 8 when W % 128 == 0, else 1 (canonical chain split)
   unsigned long long* cand;  // [num_det, grid.x, n_top] candidate keys of the fused kernel (null: not wanted)
-  int n_top;
+  int n_top;                 // candidates per (workgroup, detection): the caller's n_top, + 1 in the torch tie order
+  int* need_replay;          // [num_det] torch tie order: 1 = the row has a tie among its best n_top + 1 scores
 };
 int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
 int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
-                     int* out_ids, int tie_mode, hipStream_t st);
+                     int* out_ids, int tie_mode, hipStream_t st, const int* need_replay = nullptr);
 
 // ---------------------------------------------------------------- pnp.hip
 struct PnpArgs {

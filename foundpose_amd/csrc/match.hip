@@ -304,7 +304,8 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
       const int t = blk * 16 + rt;
       if (t < T && rd < nd) {
         a.sims[(size_t)(d0 + rd) * a.ld_sims + t] = v;
-        unsigned long long key = ((unsigned long long)order_key(v, true) << 32) | (unsigned)t;
+        // (a NaN of either sign ranks first, as in torch.topk: it then shows up among the candidates and sends the row to the replay)
+        unsigned long long key = ((unsigned long long)order_key(v != v ? __uint_as_float(0x7fc00000u) : v, true) << 32) | (unsigned)t;
 #pragma unroll
         for (int s = 0; s < COS_NMAX; ++s) {  // sorted insertion (ascending keys = best first)
           const unsigned long long lo = key < best[s] ? key : best[s];
@@ -338,8 +339,12 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
 
 // Canonical top-n of each row from the candidate keys of cosine_fused_kernel: one wave per detection, per-lane sorted
 // lists over a strided share of the ncand keys, then n rounds of wave-wide arg-best.  The score travels inside the key.
+// need_replay (torch tie order): the workgroups emitted n_top + 1 candidates; if the best n_top + 1 scores of the row are
+// strictly decreasing, the top-n SET and its ORDER are unique, so every correct top-k -- torch.topk's partial_sort /
+// nth_element + sort included -- returns exactly this list and the row's replay is skipped (flag 0).  Any equal pair, a
+// +-0 pair or a NaN among them sets the flag and topn_rows_strict_kernel redoes the row from the scores.
 __global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
-                                                         float* __restrict__ out_val, int* __restrict__ out_idx) {
+                                                         float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
@@ -362,19 +367,30 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long lon
       }
     }
   }
-  for (int s = 0; s < n_top; ++s) {
+  float prev = 0.f;
+  int tie = 0;
+  const int rounds = need_replay ? n_top + 1 : n_top;
+  for (int s = 0; s < rounds; ++s) {
     const unsigned long long b = wave_min_u64(best[0]);
     if (b == ~0ull) {
-      if (lane == 0) { out_idx[(size_t)row * n_top + s] = -1; out_val[(size_t)row * n_top + s] = -INFINITY; }
-    } else if (best[0] == b) {
-      const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits
-      out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
-      out_val[(size_t)row * n_top + s] = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+      if (lane == 0 && s < n_top) { out_idx[(size_t)row * n_top + s] = -1; out_val[(size_t)row * n_top + s] = -INFINITY; }
+      continue;
+    }
+    const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits
+    const float val = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+    if (val != val || (s > 0 && !(prev > val))) tie = 1;  // wave-uniform
+    prev = val;
+    if (best[0] == b) {
+      if (s < n_top) {
+        out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
+        out_val[(size_t)row * n_top + s] = val;
+      }
 #pragma unroll
       for (int t = 0; t + 1 < COS_NMAX; ++t) best[t] = best[t + 1];
       best[COS_NMAX - 1] = ~0ull;
     }
   }
+  if (need_replay && lane == 0) need_replay[row] = tie;
 }
 
 // Canonical top-n of each row (largest first, ties -> lowest index) straight from the scores, one 256-thread block per
@@ -474,13 +490,15 @@ __device__ __forceinline__ void strict_replay64(LaneHeap& heap, int k, float v, 
 }
 
 __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                               int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx) {
+                                                               int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                               const int* __restrict__ need_replay) {
   __shared__ __attribute__((aligned(16))) float head[2 * STRICT_HEAD];   // phase 1 staging; the short-row branch's (value, index) pairs
   __shared__ float cand_v[4][STRICT_CAND];
   __shared__ int cand_i[4][STRICT_CAND];
   __shared__ int cand_n[4];
   __shared__ float s_root_v;
   const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (need_replay && !need_replay[row]) return;  // the row's top n + 1 scores are distinct: cand_merge_kernel's list is the answer
   const int len = row_len ? row_len[row] : n_default;
   const float* r = vals + (size_t)row * ld;
   const int k = min(n_top, len);
@@ -965,11 +983,11 @@ int launch_unpack_best(const unsigned long long* best, long long n, float* d2, i
 
 // Top-n of finished scores [rows, ld]: tie_mode 1 = the reference's torch.topk order, 0 = canonical.
 int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
-                     int* out_ids, int tie_mode, hipStream_t st) {
+                     int* out_ids, int tie_mode, hipStream_t st, const int* need_replay) {
   if (rows == 0) return FP_OK;
   if (tie_mode == 1) {
     FP_REQUIRE(n_top <= 32, "strict (torch) tie order: n_top must be <= 32 (got %d)", n_top);  // short rows (< 64 n_top) fit the LDS pair array
-    hipLaunchKernelGGL(topn_rows_strict_kernel, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
+    hipLaunchKernelGGL(topn_rows_strict_kernel, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids, need_replay);
   } else if (n_top <= 8) {
     hipLaunchKernelGGL(topn_rows_block_kernel<8>, dim3(rows), dim3(256), 0, st, sims, ld, row_len, max_len, n_top, out_scores, out_ids);
   } else {
@@ -987,14 +1005,17 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
   const int wslice = a.W / a.k_slices;
   const int nblk = cdiv(max_templates, 16);
   bool fused = a.k_slices == 8 && wslice % 64 == 0 && wslice <= 256;
-  const bool want_cand = tie_mode == 0 && n_top <= COS_NMAX;
+  // canonical order: n_top candidates per workgroup finish the row.  torch order: n_top + 1, so that the merge can tell
+  // whether the row has a tie at all (cand_merge_kernel); only rows that do are replayed from the scores
+  const bool want_cand = tie_mode == 0 ? n_top <= COS_NMAX : n_top + 1 <= COS_NMAX;
+  const int n_emit = tie_mode == 0 ? n_top : n_top + 1;
   if (fused) {
     // one persistent workgroup per CU, shared evenly by the (object, 32-detection chunk) pairs of the launch
     const int nq = max_det_per_obj <= 16 ? 1 : 2;
     const int chunks = cdiv(max_det_per_obj, nq * 16);
     const int per = fp_num_cus() / (num_obj * chunks);
     const int gx = per < 1 ? 1 : (per > nblk ? nblk : per);
-    a.n_top = n_top;
+    a.n_top = n_emit;
     if (!want_cand) a.cand = nullptr;
     const size_t lds = COS_RING_BYTES + (size_t)COS_RED_BUFS * 8 * nq * 4 * COS_RED_PITCH * 4;
     static FpDeviceOnce attr1, attr2;
@@ -1005,9 +1026,11 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);
     FP_CHECK_LAUNCH("cosine_fused");
     if (want_cand) {
-      hipLaunchKernelGGL(cand_merge_kernel, dim3(cdiv(num_det, 4)), dim3(256), 0, st, a.cand, gx * n_top, num_det, n_top, out_scores, out_ids);
+      hipLaunchKernelGGL(cand_merge_kernel, dim3(cdiv(num_det, 4)), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
+                         tie_mode == 1 ? a.need_replay : nullptr);
       FP_CHECK_LAUNCH("cand_merge");
-      return FP_OK;
+      if (tie_mode == 0) return FP_OK;
+      return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st, a.need_replay);
     }
   } else {
     const int nq = max_det_per_obj <= 16 ? 1 : (max_det_per_obj <= 32 ? 2 : 4);
@@ -1025,5 +1048,5 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     else hipLaunchKernelGGL(cosine_generic_kernel<4>, grid, dim3(256), lds, st, a);
     FP_CHECK_LAUNCH("cosine_generic");
   }
-  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st);
+  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, st, nullptr);
 }

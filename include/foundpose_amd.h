@@ -26,7 +26,7 @@ typedef void* fp_stream_t; /* hipStream_t */
 
 enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
 
-#define FP_ABI_VERSION 10
+#define FP_ABI_VERSION 11
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -63,15 +63,16 @@ int fp_tfidf_build(const int32_t* word_ids, const float* word_d2, int knn_k, con
  * det_seg_off [num_obj+1] over rows of desc_n, obj_tpl_off [num_obj+1] over rows of bank_n (both
  * normalised), det_num_templates [num_det] = template count of each detection's object.  scratch_sims:
  * FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) floats -- the finished scores [num_det, max_templates] (left there
- * for the caller) followed by the candidate keys of the fused top-n.  Canonical fp32 summation order of a score:
+ * for the caller) followed by the candidate keys of the fused top-n and one replay flag per detection.  Canonical fp32 summation order of a score:
  * num_words % 128 == 0: 8 contiguous k-slices, each an fma chain visiting every 16-block of k as
  * [0,4,8,12,1,5,...,15], slice sums added in slice order; num_words % 16 == 0: one such chain; else k ascending.
  * The order depends on num_words only -- never on the batch: more than 32 detections of one object are served in
  * 32-detection chunks by the same kernel.  out_scores/out_ids [num_det, n_top]; ids are object-local template ids,
  * -1 / -inf past the object's template count.  tie_mode: 0 = canonical (score, then lowest id); 1 = the tie order of
  * torch.topk on a CPU tensor (libstdc++ partial_sort / nth_element+sort replayed on the device; rows of any length,
- * n_top <= 32). */
-#define FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) (2 * (size_t)(num_det) * (size_t)(max_templates) + 16 * (size_t)(num_det) + 2)
+ * n_top <= 32).  With n_top <= 7 the replay runs only for rows whose best n_top + 1 scores contain a tie (equal values,
+ * +-0 or NaN): strictly decreasing scores make the top-n list unique, so the canonical list IS torch's. */
+#define FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) (2 * (size_t)(num_det) * (size_t)(max_templates) + 17 * (size_t)(num_det) + 2)
 int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det,
                    int max_det_per_obj,
                    const float* bank_n, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,

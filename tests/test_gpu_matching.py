@@ -198,6 +198,47 @@ def test_strict_template_order_with_duplicate_templates():
                 assert ids[b].cpu().tolist() == ref.tolist(), (T, mode, b)
 
 
+@pytest.mark.parametrize("W", [128, 2048])   # 2048: the fused streaming kernel + tie flags; 128 words: the generic fallback + full replay
+@pytest.mark.parametrize("T", [64, 500, 3000])
+def test_torch_order_replay_only_where_ties_exist(T, W):
+    """tie_order="torch" replays torch.topk only for rows whose best n + 1 scores contain a tie; a row without one takes the
+    canonical list.  Rows built to put a tie (a) inside the top 5, (b) across the cut (ranks 5/6), (c) only below rank 6
+    (no replay needed), (d) nowhere, (e) everywhere (all templates identical), (f) zero scores (disjoint words): each
+    must equal torch.topk on the CPU copy of the device scores, and the canonical mode the lowest-id rule."""
+    from foundpose_amd import ops
+    from foundpose_amd._lib import call, ptr, stream, cosine_scratch_floats
+    rng = np.random.default_rng(T + W)
+    half = W // 2
+    bank = np.zeros((T, W), np.float32)
+    bank[:, :half] = rng.random((T, half)).astype(np.float32)            # templates live on the first half of the words
+    q = np.zeros((6, W), np.float32)
+    q[:, :half] = rng.random((6, half)).astype(np.float32)
+    order = np.argsort(-(bank / np.linalg.norm(bank, axis=1, keepdims=True)) @ (q[0] / np.linalg.norm(q[0])))
+    bank_a = bank.copy(); bank_a[order[2]] = bank_a[order[1]]            # (a) ranks 2 and 3 identical
+    bank_b = bank.copy(); bank_b[order[5]] = bank_b[order[4]]            # (b) ranks 5 and 6 identical
+    bank_c = bank.copy(); bank_c[order[8]] = bank_c[order[7]]            # (c) ranks 8 and 9 identical
+    cases = [("a", bank_a, q[0]), ("b", bank_b, q[0]), ("c", bank_c, q[0]), ("d", bank, q[1]),
+             ("e", np.repeat(bank[:1], T, 0), q[2])]
+    qz = np.zeros(W, np.float32); qz[half:] = rng.random(W - half).astype(np.float32)
+    cases.append(("f", bank, qz))                                        # (f) every score exactly +0
+    for name, bk, qq in cases:
+        bank_n, q_n = ops.normalize_rows(cu(bk)), ops.normalize_rows(cu(qq[None]))
+        seg, tpl, nt = cu(np.array([0, 1], np.int32)), cu(np.array([0, T], np.int32)), cu(np.full(1, T, np.int32))
+        sims = torch.empty(cosine_scratch_floats(1, T), device="cuda")
+        for mode in (1, 0):
+            sc = torch.empty(1, 5, device="cuda")
+            ids = torch.empty(1, 5, dtype=torch.int32, device="cuda")
+            call("fp_cosine_topk", ptr(q_n), ptr(seg), ptr(nt), 1, 1, ptr(bank_n), ptr(tpl), 1, T, W, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream())
+            s_cpu = sims[:T].cpu()
+            if mode == 1:
+                rv, ri = torch.topk(s_cpu, 5, sorted=True)
+            else:
+                v, i = clib.topk_canonical(s_cpu.numpy(), 5, True)
+                rv, ri = torch.from_numpy(v), torch.from_numpy(i)
+            assert ids[0].cpu().tolist() == ri.tolist(), (name, T, W, mode)
+            assert torch.equal(sc[0].cpu(), rv), (name, T, W, mode)
+
+
 @pytest.mark.parametrize("name", sorted(MATCH_CASES))
 def test_establish_correspondences_vs_oracle_and_reference(name):
     c, g, repre, pts, feats = match_case_inputs(name)
