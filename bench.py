@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--tie-order", default="torch", choices=["torch", "canonical"],
                     help="'torch' (default, the headline): the reference's torch.topk tie order replayed on the device; 'canonical': (value, lowest index)")
     ap.add_argument("--graph", action="store_true", help="replay the ViT forward as one hipGraph (measured: no gain, the step is GPU-bound: 34.51 vs 34.44 ms)")
+    ap.add_argument("--no-token-select", action="store_true",
+                    help="run the hooked block on every token (default: only on the patch tokens the query points sample; same outputs bit for bit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
     ap.add_argument("--cpu-detections", type=int, default=3)
@@ -115,6 +117,9 @@ def main():
     if args.precision == "fp8":
         extractor.calibrate_fp8(images)  # static activation scales are part of the fp8 model (no implicit calibration)
     eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order)
+    if args.no_token_select:
+        os.environ["FP_TOKEN_SELECT"] = "0"
+    select_on = extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0" and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"
 
     def step(e=eng):
         res = e.infer_batch(images, masks, det_obj)
@@ -154,6 +159,20 @@ def main():
     step(eng_o)
     el_o, _ = timed(eng_o, 5)   # a fixed count: everything but the K timed steps is the same in every run (tools/rocprof_delta.py relies on it)
     ms_other = 1e3 * el_o / 5
+    # token selection of the hooked block: the selected share, and the step without it next to the headline
+    sel_info = {"enabled": bool(select_on)}
+    n_tok_img = 1 + arch.registers + (args.size // 14) ** 2
+    sel_total = B * n_tok_img
+    if select_on:
+        sel_total = eng._query_points_end(*eng._query_points_begin(masks, select_tokens=True))[3][3]
+        os.environ["FP_TOKEN_SELECT"] = "0"
+        step()
+        el_ns, _ = timed(eng, 5)
+        os.environ["FP_TOKEN_SELECT"] = "1"
+        sel_info.update({"selected_tokens_per_crop": round(sel_total / B, 1), "tokens_per_crop": n_tok_img,
+                         "ms_per_step_all_tokens": round(1e3 * el_ns / 5, 3),
+                         "note": "the hooked block computes attention queries, proj and the MLP for the patch tokens under the sampling taps of the query "
+                                 "points only (keys / values: all tokens); sampled features are bit-identical (tests/test_gpu_vit.py, tests/test_gpu_parity_e2e.py)"})
 
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
@@ -190,7 +209,13 @@ def main():
         fl = lambda n, k: 2.0 * mv * n * k     # algorithmic: valid rows only
         ls_flops, ls_ms = fl(arch.dim, arch.dim) + fl(arch.dim, hid), ms_proj + ms_fc2
         ach = ls_flops / (ls_ms * 1e-3) / 1e12
-        vit_tf = vit_flops_per_crop(arch, args.size, args.layer) * det_per_s / world / 1e12
+        # executed FLOPs: the hooked block runs qkv on all tokens and everything else on the selected ones
+        D_, n_ = arch.dim, n_tok_img
+        full_blk = 24 * n_ * D_ ** 2 + 4 * n_ * n_ * D_
+        s_ = sel_total / B
+        last_blk = 6 * n_ * D_ ** 2 + 4 * s_ * n_ * D_ + 18 * s_ * D_ ** 2
+        flops_exec = vit_flops_per_crop(arch, args.size, args.layer) - full_blk + last_blk
+        vit_tf = flops_exec * det_per_s / world / 1e12
         # ---- HBM roofline of the template retrieval (descriptors of the object's templates read once per 32 detections)
         from foundpose_amd._lib import call, cosine_scratch_floats, ptr, stream
         Bq = min(max(1, B // args.objects), 128)   # detections of one object in a batch (the kernel serves them in chunks of 32)
@@ -212,7 +237,7 @@ def main():
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic (seeded crops assembled from 682 noise patch textures, disc masks, random-init ViT weights, planted bank: each crop's "
                                              "fp32 features sit with graded noise in 5 consecutive templates, the rest are random texture sets; words = 3 instances per texture)",
-            "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block), "
+            "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block" + (", the hooked block on the sampled tokens only" if select_on else "") + "), "
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
                                    f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}, "
                                    f"tie order '{args.tie_order}'" + (" (the reference's torch.topk order, replayed on the device)" if args.tie_order == "torch" else ""),
@@ -231,7 +256,9 @@ def main():
                                      "proj": {"launch_ms": round(ms_proj, 4), "frac": round(fl(arch.dim, arch.dim) / (ms_proj * 1e-3) / 1e12 / peak_mfma, 4)},
                                      "fc2": {"launch_ms": round(ms_fc2, 4), "frac": round(fl(arch.dim, hid) / (ms_fc2 * 1e-3) / 1e12 / peak_mfma, 4)}},
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
-                                        "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": vit_flops_per_crop(arch, args.size, args.layer)},
+                                        "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": flops_exec,
+                                        "flops_per_detection_all_tokens": vit_flops_per_crop(arch, args.size, args.layer)},
+            "token_selection": sel_info,
             "roofline_knn": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}' (template-descriptor streaming + top-5, whole call)", "bound": "hbm",
                              "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                              "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),

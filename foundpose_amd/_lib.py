@@ -55,6 +55,10 @@ _PROTOS = {
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
     "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
     "fp_vit_sample_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
+    "fp_vit_select_tokens": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "fp_vit_forward_prefix": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
+    "fp_vit_block_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, vp, vp, i32, i32, vp],
+    "fp_vit_sample_features_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp],
     "fp_vit_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, vp, vp, vp],
     "fp_patchify": [vp, i32, i32, i32, i32, vp, i32, i32, vp],
     "fp_layernorm": [vp, i32, vp, vp, f32, vp, i32, i32, i32, i32, i32, i32, i32, vp],

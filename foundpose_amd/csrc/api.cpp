@@ -316,7 +316,7 @@ int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int 
                  int dim, int heads, int dtype, fp_stream_t stream) {
   FP_REQUIRE(qkv && out, "fp_attention: null pointer");
   AttnArgs a;
-  a.out_fp8_scale = 0.f;
+  memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
   a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads;
   return attn_launch(a, dtype, ST(stream));
@@ -340,9 +340,18 @@ int fp_warp_crops(const void* src, int n_src, int src_h, int src_w, int channels
 }
 
 // ------------------------------------------------------------------ ViT forward (launch sequence in C++)
-int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
-                   int layer, fp_stream_t stream) {
-  FP_REQUIRE(m && ws && images && m->blocks, "fp_vit_forward: null pointer");
+}  // extern "C"
+
+namespace {
+enum { VIT_FULL = 0, VIT_PREFIX = 1, VIT_LAST_SELECTED = 2 };
+struct VitSelection { const int32_t* rows; const int32_t* off; int num, max_per_img; };
+
+// VIT_FULL: embedding + blocks 0..layer.  VIT_PREFIX: embedding + blocks 0..layer-1, leaving what block `layer` starts from
+// (fp32 stream, its bf16 copy, the LayerNorm row sums).  VIT_LAST_SELECTED: block `layer` alone, computed for the selected
+// tokens only (queries of the attention, rows of proj / fc1 / fc2) on top of a VIT_PREFIX run -- keys and values are all tokens.
+int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer, int mode,
+                     const VitSelection* sel, fp_stream_t stream) {
+  FP_REQUIRE(m && ws && (images || mode == VIT_LAST_SELECTED) && m->blocks, "fp_vit_forward: null pointer");
   FP_REQUIRE(layer >= -1 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);  // -1: token embedding only
   FP_REQUIRE(H % m->patch == 0 && W % m->patch == 0, "fp_vit_forward: image size must be a multiple of the patch size");
   const int D = m->dim, np = (H / m->patch) * (W / m->patch), ntok = 1 + m->registers + np;
@@ -360,6 +369,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
              "fp_vit_forward: fp8 row strides (bytes) must cover the row and keep 16-byte alignment");
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
+  if (mode != VIT_LAST_SELECTED) {
   TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, adt, st));
   TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
   if (bf) {
@@ -378,6 +388,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     a.tok_skip = 1 + m->registers;
     TRY(f32_tile_launch(F32_EPI_TOKENS, a, Mp, D, 1, st));
   }
+  }
 
   // row strides of the bf16 / fp32 operands (fp8 mode: dense)
   const int ldy = (!f8 && ws->ld_y) ? ws->ld_y : D, ldh = (!f8 && ws->ld_h) ? ws->ld_h : m->hidden;
@@ -390,7 +401,7 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = ldy; ln.out_dtype = adt;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
-  at.out_fp8_scale = 0.f;
+  memset(&at, 0, sizeof(at));
   at.qkv = ws->qkv; at.ld_qkv = ldq; at.out = ws->y; at.ld_out = ldy;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
 
@@ -402,23 +413,52 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
     FP_REQUIRE(ws->xb && ws->stats, "fp_vit_forward: ln_fold needs workspace xb and stats");
     FP_REQUIRE(D % 128 == 0, "fp_vit_forward: ln_fold needs dim %% 128 == 0");
     ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
-    if (layer >= 0) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st));
+    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st));
   }
+  FP_REQUIRE(mode == VIT_FULL || fold, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold only");
   float2* ln_row = stats + (size_t)ln_parts * ws->m_pad;  // (rstd, mean * rstd) per row, behind the partial-sum slots
-  auto finalize = [&]() -> int { return ln_finalize_launch(stats, ln_parts, ws->m_pad, Mtok, D, 1e-6f, ln_row, st); };
+  int rows_valid = Mtok, rows_pad = ws->m_pad;  // the selected tail of the hooked block narrows these to the compact rows
+  // (the residual GEMM files its partial sums with a stride of ITS row count: rows_pad)
+  auto finalize = [&]() -> int { return ln_finalize_launch(stats, ln_parts, rows_pad, rows_valid, D, 1e-6f, ln_row, st); };
   auto gemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
                   const float* colsum, bool produce) -> int {
     GemmBf16Args g;
     memset(&g, 0, sizeof(g));
     g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
-    g.M = ws->m_pad; g.N = N; g.K = K; g.M_valid = Mtok; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+    g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
     if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; }
     return gemm_bf16_launch(epi, g, st);
   };
 
-  for (int i = 0; i <= layer; ++i) {
+  const int i_first = mode == VIT_LAST_SELECTED ? layer : 0, i_last = mode == VIT_PREFIX ? layer - 1 : layer;
+  for (int i = i_first; i <= i_last; ++i) {
     const fp_vit_block& b = m->blocks[i];
+    if (fold && mode == VIT_LAST_SELECTED) {
+      // The hooked block for the selected tokens only.  K and V need every token: LayerNorm constants and the qkv GEMM run on
+      // all rows (its Q columns of unselected rows are the only wasted work); attention takes its queries through the index
+      // list and writes compact rows; from there on every operand has num_sel rows.  Row r of every compact buffer is
+      // token sel->rows[r]; the per-row arithmetic (GEMM chains, 128-column stat groups) does not depend on where a row sits,
+      // so the selected rows carry the bits the full block would have given them.
+      FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
+      TRY(finalize());
+      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
+      AttnArgs as = at;
+      as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;
+      TRY(attn_launch(as, FP_DTYPE_BF16, st));
+      float* xs = reinterpret_cast<float*>(ws->qkv);  // qkv is dead after the attention: [num_sel, D] fp32 rows of the stream
+      TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xs, st));
+      rows_valid = sel->num;
+      rows_pad = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
+      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, true));
+      TRY(finalize());
+      if (m->ffn_swiglu)
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false));
+      else
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false));
+      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, false));
+      continue;
+    }
     if (fold) {
       // x += ls1 * proj(attn(ln1(x))): qkv reads bf16(x) and normalises in its epilogue; proj refreshes bf16(x) + row sums
       FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
@@ -490,6 +530,30 @@ int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const floa
   }
   return FP_OK;
 }
+}  // namespace
+
+extern "C" {
+
+int fp_vit_forward(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
+                   int layer, fp_stream_t stream) {
+  return vit_forward_impl(m, ws, images, B, H, W, layer, VIT_FULL, nullptr, stream);
+}
+
+int fp_vit_forward_prefix(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W,
+                          int layer, fp_stream_t stream) {
+  FP_REQUIRE(layer >= 0, "fp_vit_forward_prefix: layer must be >= 0");
+  return vit_forward_impl(m, ws, images, B, H, W, layer, VIT_PREFIX, nullptr, stream);
+}
+
+int fp_vit_block_selected(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int H, int W, int layer,
+                          const int32_t* sel_rows, const int32_t* sel_off, int num_sel, int max_sel_per_img, fp_stream_t stream) {
+  FP_REQUIRE(sel_rows && sel_off, "fp_vit_block_selected: null pointer");
+  FP_REQUIRE(layer >= 0 && num_sel >= 1 && max_sel_per_img >= 1 && max_sel_per_img <= num_sel, "fp_vit_block_selected: bad sizes (layer %d, %d selected, at most %d per image)",
+             layer, num_sel, max_sel_per_img);
+  FP_REQUIRE(m && ws && num_sel <= ws->m_pad, "fp_vit_block_selected: more selected tokens than workspace rows");
+  const VitSelection sel{sel_rows, sel_off, num_sel, max_sel_per_img};
+  return vit_forward_impl(m, ws, nullptr, B, H, W, layer, VIT_LAST_SELECTED, &sel, stream);
+}
 
 int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int n_patches, int apply_norm,
                     float* fmap, float* cls, fp_stream_t stream) {
@@ -524,6 +588,24 @@ int fp_vit_sample_features(const fp_vit_model* m, const fp_vit_workspace* ws, in
   const int ntok = 1 + m->registers + grid_h * grid_w;
   return ln_sample_launch(ws->x, m->dim, m->norm_w, m->norm_b, 1e-6f, apply_norm, m->dim, ntok, 1 + m->registers, grid_h, grid_w, img_w, img_h,
                           points, point_img, num_points, out, ST(stream));
+}
+
+int fp_vit_select_tokens(const uint8_t* point_on, const int64_t* point_cells, int B, int num_points, int num_cells, int n_tok, int32_t* scratch,
+                         int32_t* counts, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream) {
+  FP_REQUIRE(point_on && point_cells && scratch && counts && sel_rows && sel_off && row_map, "fp_vit_select_tokens: null pointer");
+  return select_tokens_launch(point_on, reinterpret_cast<const long long*>(point_cells), B, num_points, num_cells, n_tok, scratch, counts, sel_rows,
+                              sel_off, row_map, ST(stream));
+}
+
+int fp_vit_sample_features_selected(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,
+                                    int img_h, const float* points, const int32_t* point_img, int num_points, const int32_t* row_map, float* out,
+                                    fp_stream_t stream) {
+  FP_REQUIRE(m && ws && ws->qkv && points && out && row_map, "fp_vit_sample_features_selected: null pointer");
+  FP_REQUIRE(B >= 1 && grid_h >= 1 && grid_w >= 1 && img_w >= 1 && img_h >= 1, "fp_vit_sample_features_selected: bad sizes");
+  const int ntok = 1 + m->registers + grid_h * grid_w;
+  // fp_vit_block_selected left the selected tokens' rows of the residual stream, compact, where the qkv projections were
+  return ln_sample_launch(reinterpret_cast<const float*>(ws->qkv), m->dim, m->norm_w, m->norm_b, 1e-6f, apply_norm, m->dim, ntok, 1 + m->registers,
+                          grid_h, grid_w, img_w, img_h, points, point_img, num_points, out, ST(stream), row_map);
 }
 
 }  // extern "C"

@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   const int l31 = lane & 31, kh = lane >> 5;
   int qt, head, img;
   {
-    const int nqt = (a.n_tok + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
     int pair;
     if ((pairs & 7) == 0) {  // all query tiles of an (image, head) pair on one XCD (one L2), see attn_bf16_kernel
       const int j = i >> 3;
@@ -249,15 +249,19 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   }
   const int N = a.n_tok, D = a.dim;
   const __bf16* qkv = reinterpret_cast<const __bf16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  // queries: every token, or the image's selected tokens (the keys are always all N tokens)
+  const int sel_base = a.sel_off ? a.sel_off[img] : 0;
+  const int NQ = a.sel_off ? a.sel_off[img + 1] - sel_base : N;
+  if (qt * 256 >= NQ) return;  // selected mode: the grid is sized for the image with the most queries
   // The last query tile of an (image, head) pair is usually short (1374 tokens = 5 x 256 + 94).  With two 32-query blocks
   // per wave only 2 of its 4 waves would have queries, each doing a full tile's work: the block would cost as much as a
   // full one for 37 % of the queries.  When <= 128 queries remain every wave takes ONE 32-query block instead (the QC = 1
   // instantiation of the tile loop): the same arithmetic per query, half the work per wave, the tail block ends in about
   // half the time.  Block-uniform.
-  const bool short_tail = QB == 2 && qt == (N + 255) / 256 - 1 && N - qt * 256 <= 128;
+  const bool short_tail = QB == 2 && qt == (NQ + 255) / 256 - 1 && NQ - qt * 256 <= 128;
   const int nqb = short_tail ? 1 : QB;
   const int q0 = qt * 256 + wave * (32 * nqb);
-  const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
+  const bool active = q0 < NQ;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
 
   // ---- staging: wave w issues row groups 2w, 2w+1 (8 keys x 128 B each) of K and of V
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (unsigned)((size_t)N * a.ld_qkv * 2), 0x00020000);
@@ -292,7 +296,8 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const int q = q0 + (qb < nqb ? qb : 0) * 32 + l31;
-    const int qc = q < N ? q : N - 1;
+    int qc = q < NQ ? q : NQ - 1;
+    if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;  // the selected query's token
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
       qf[qb][ds] = *reinterpret_cast<const bf16x8*>(qkv + (size_t)qc * a.ld_qkv + head * 64 + (ds * 2 + kh) * 8);
@@ -434,8 +439,9 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
       const int q = q0 + qb * 32 + l31;
       const float l_tot = l_run[qb] + __shfl_xor(l_run[qb], 32, 64);
       const float inv = 1.f / l_tot;
-      if (q < N && a.out_fp8_scale > 0.f) {  // fp8 mode: the proj GEMM's input, quantised here (ld_out in bytes)
-        unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
+      const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
+      if (q < NQ && a.out_fp8_scale > 0.f) {  // fp8 mode: the proj GEMM's input, quantised here (ld_out in bytes)
+        unsigned char* o = reinterpret_cast<unsigned char*>(a.out) + orow * a.ld_out + head * 64;
         const float sc = inv * a.out_fp8_scale;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -443,8 +449,8 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
           for (int g = 0; g < 4; ++g)
             *reinterpret_cast<unsigned*>(o + dt * 32 + 8 * g + 4 * kh) =
                 pack_fp8x4(oacc[qb][dt][4 * g + 0] * sc, oacc[qb][dt][4 * g + 1] * sc, oacc[qb][dt][4 * g + 2] * sc, oacc[qb][dt][4 * g + 3] * sc);
-      } else if (q < N) {
-        __bf16* o = reinterpret_cast<__bf16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
+      } else if (q < NQ) {
+        __bf16* o = reinterpret_cast<__bf16*>(a.out) + orow * a.ld_out + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -519,13 +525,18 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     const char* w64_env = getenv("FP_ATTN_W64");  // read per call: tests compare the two kernels in one process
     const int w64 = w64_env ? atoi(w64_env) : 1;
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
+    const bool sel = a.sel_off != nullptr;
+    FP_REQUIRE(!sel || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");
+    FP_REQUIRE(!sel || (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull), "attention: query selection exists in the 64-queries-per-wave kernel only");
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
-      if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(512), 0, st, a);
-      else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(cdiv(a.n_tok, 256) * a.heads * a.batch), dim3(256), 0, st, a);
+      const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, 256) * a.heads * a.batch);
+      if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
     }
   } else if (dtype == FP_DTYPE_F32) {
+    FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
     dim3 grid(cdiv(a.n_tok, 256), a.heads, a.batch);
     hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, st, a);
   } else {

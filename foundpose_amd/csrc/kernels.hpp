@@ -128,6 +128,10 @@ struct AttnArgs {
   void* out; int ld_out;         // [B*N, D]
   int batch, n_tok, dim, heads;
   float out_fp8_scale;           // bf16 kernel: > 0 -> the output leaves as e4m3(o * scale) bytes (ld_out in bytes)
+  // query selection (bf16, 64-queries-per-wave kernel; null = every token is a query): image b attends with the tokens
+  // sel_rows[sel_off[b] .. sel_off[b+1]) (global rows b * n_tok + token, ascending) over ALL its keys, and output row r of
+  // the compact [num_sel, D] result belongs to sel_rows[r]
+  const int* sel_rows; const int* sel_off; int max_sel;  // max_sel >= the largest per-image count (sizes the grid)
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 
@@ -143,7 +147,11 @@ struct LayerNormArgs {
 };
 int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
 int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
-                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st);
+                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st,
+                     const int* row_map = nullptr);
+int gather_rows_launch(const float* x, const int* rows, int n, int dim, float* out, hipStream_t st);
+int select_tokens_launch(const unsigned char* on, const long long* cells9, int B, int G, int C, int n_tok, int* scratch_rank, int* counts,
+                         int* sel_rows, int* sel_off, int* row_map, hipStream_t st);
 // x [rows, dim] fp32 -> xb = bf16(x) [rows, ld_xb] and stats[0 * stats_stride + row] = (sum x, sum x^2), slots 1..parts-1 zero
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);

@@ -97,6 +97,8 @@ struct LnSampleArgs {
   int dim, ntok, skip, gh, gw, img_w, img_h;
   const float* points; const int* point_img; int num_points;
   float* out;                           // [num_points, dim]
+  const int* row_map;                   // null: x holds every token.  Else x holds the SELECTED tokens only, compact:
+                                        // row_map[img * gh * gw + cell] = the patch token's row in x (< 0: not selected)
 };
 
 // NVT = vectors of VEC floats a lane may hold of one row (dim <= 64 * VEC * NVT); small NVT keeps two rows in registers
@@ -135,10 +137,23 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
     int tx = x0 + (t & 1), ty = y0 + (t >> 1);
     tx = tx < 0 ? 0 : (tx >= a.gw ? a.gw - 1 : tx);   // an invalid tap reads a valid row and is zeroed below
     ty = ty < 0 ? 0 : (ty >= a.gh ? a.gh - 1 : ty);
-    const float* x = a.x + ((size_t)img * a.ntok + a.skip + ty * a.gw + tx) * a.ld_x;
+    size_t row = (size_t)img * a.ntok + a.skip + ty * a.gw + tx;
+    bool have = true;
+    if (a.row_map) {
+      const int r = a.row_map[(size_t)img * a.gh * a.gw + ty * a.gw + tx];
+      have = r >= 0;  // a tap the selection missed would be a caller bug: it is made loud (NaN), never silently wrong
+      row = have ? (size_t)r : 0;
+    }
+    const float* x = a.x + row * a.ld_x;
 #pragma unroll
     for (int i = 0; i < NVT; ++i)
-      if (i < nv) v[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
+      if (i < nv) {
+        v[i] = *reinterpret_cast<const vec_t*>(x + (i * 64 + lane) * VEC);
+        if (!have) {
+#pragma unroll
+          for (int e = 0; e < VEC; ++e) v[i][e] = __builtin_nanf("");
+        }
+      }
   };
   vec_t acc[NVT], v[NVT], vn[NVT];
 #pragma unroll
@@ -301,6 +316,78 @@ __global__ void ln_finalize_kernel(const float2* __restrict__ partial, int parts
   out[row] = make_float2(rs, mu * rs);
 }
 
+// ---- token selection for the hooked block (fp_vit_select_tokens): which patch tokens will the sampling of the query points
+// read?  Kernel 1, one workgroup per image: the cells named by the live grid points (cells9: for every grid point the 3 x 3
+// cells around its sampling position, a superset of the four bilinear taps) are flagged in LDS, a block scan ranks them.
+// Kernel 2 adds the counts of the images in front and writes the lists.
+__global__ __launch_bounds__(256) void token_flags_kernel(const unsigned char* __restrict__ on, const long long* __restrict__ cells9, int G, int C,
+                                                          int* __restrict__ local_rank, int* __restrict__ counts) {
+  extern __shared__ int sel_smem[];
+  int* flag = sel_smem;            // [C + 1] (slot C collects the cells outside the map)
+  __shared__ int wave_tot[4];
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int c = tid; c <= C; c += 256) flag[c] = 0;
+  __syncthreads();
+  for (int g = tid; g < G; g += 256)
+    if (on[(size_t)b * G + g]) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) flag[(int)cells9[(size_t)g * 9 + k]] = 1;  // benign race: every writer stores 1
+    }
+  __syncthreads();
+  // exclusive scan over the cells in chunks of 256
+  int base = 0;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + tid;
+    const int f = c < C ? flag[c] : 0;
+    const unsigned long long m = __ballot(f != 0);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wave_tot[wave] = __popcll(m);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      if (w < wave) woff += wave_tot[w];
+      tot += wave_tot[w];
+    }
+    if (c < C) local_rank[(size_t)b * C + c] = f ? base + woff + before : -1;
+    base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) counts[b] = base;
+}
+
+__global__ __launch_bounds__(256) void token_lists_kernel(const int* __restrict__ local_rank, const int* __restrict__ counts, int B, int C, int n_tok,
+                                                          int* __restrict__ sel_rows, int* __restrict__ sel_off, int* __restrict__ row_map) {
+  __shared__ int s_off;
+  const int b = blockIdx.x, tid = threadIdx.x;
+  if (tid < 64) {
+    int part = 0;
+    for (int i = tid; i < b; i += 64) part += counts[i];
+    part = (int)wave_sum((float)part);  // counts are small integers (< 2^24): exact in fp32
+    if (tid == 0) {
+      s_off = part;
+      sel_off[b] = part;
+      if (b == B - 1) sel_off[B] = part + counts[b];
+    }
+  }
+  __syncthreads();
+  const int off = s_off, skip = n_tok - C;
+  for (int c = tid; c < C; c += 256) {
+    const int r = local_rank[(size_t)b * C + c];
+    row_map[(size_t)b * C + c] = r < 0 ? -1 : off + r;
+    if (r >= 0) sel_rows[off + r] = b * n_tok + skip + c;
+  }
+}
+
+// rows of the fp32 residual stream picked by index: out[r] = x[rows[r]] (the selected tokens of the hooked block)
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ x, const int* __restrict__ rows, int n, int dim, float* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const float4* src = reinterpret_cast<const float4*>(x + (size_t)rows[r] * dim);
+  float4* dst = reinterpret_cast<float4*>(out + (size_t)r * dim);
+  for (int c = lane; c < dim / 4; c += 64) dst[c] = src[c];
+}
+
 __global__ void prefix_tokens_kernel(const float* __restrict__ prefix, int n_prefix, int dim, float* __restrict__ tokens, int batch, int n_tok) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)batch * n_prefix * dim;
@@ -338,11 +425,31 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   return FP_OK;
 }
 
+int select_tokens_launch(const unsigned char* on, const long long* cells9, int B, int G, int C, int n_tok, int* scratch_rank, int* counts,
+                         int* sel_rows, int* sel_off, int* row_map, hipStream_t st) {
+  FP_REQUIRE(B >= 1 && G >= 1 && C >= 1 && n_tok >= C, "select_tokens: bad sizes");
+  FP_REQUIRE((size_t)(C + 1) * 4 <= 64 * 1024 && (long long)B * n_tok < (1ll << 24), "select_tokens: map too large");
+  hipLaunchKernelGGL(token_flags_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, st, on, cells9, G, C, scratch_rank, counts);
+  FP_CHECK_LAUNCH("token_flags");
+  hipLaunchKernelGGL(token_lists_kernel, dim3(B), dim3(256), 0, st, scratch_rank, counts, B, C, n_tok, sel_rows, sel_off, row_map);
+  FP_CHECK_LAUNCH("token_lists");
+  return FP_OK;
+}
+
+int gather_rows_launch(const float* x, const int* rows, int n, int dim, float* out, hipStream_t st) {
+  FP_REQUIRE(dim % 4 == 0, "gather_rows: dim %% 4 != 0");
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, x, rows, n, dim, out);
+  FP_CHECK_LAUNCH("gather_rows");
+  return FP_OK;
+}
+
 int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
-                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st) {
+                     int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st,
+                     const int* row_map) {
   FP_REQUIRE(dim % 128 == 0 && dim <= 2048, "ln_sample: dim (%d) must be a multiple of 128, at most 2048", dim);
   if (num_points == 0) return FP_OK;
-  LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out};
+  LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out, row_map};
   const dim3 grid(cdiv(num_points, 4));
   if (dim % 256 == 0 && dim <= 1024) hipLaunchKernelGGL((ln_sample_kernel<4, 4>), grid, dim3(256), 0, st, a);
   else if (dim % 256 == 0) hipLaunchKernelGGL((ln_sample_kernel<4, 8>), grid, dim3(256), 0, st, a);

@@ -296,13 +296,22 @@ class DinoFeatureExtractor(torch.nn.Module):
         self.num_patches = (gh, gw)
         return fmap, cls
 
-    def forward_hidden(self, images: torch.Tensor) -> Tuple[int, int, int]:
+    @property
+    def supports_token_selection(self) -> bool:
+        """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms."""
+        return self.facet == "token" and not self.use_graph and self.precision == "bf16" and self.fold_layernorm and self.layer >= 0
+
+    def forward_hidden(self, images: torch.Tensor, prefix_only: bool = False) -> Tuple[int, int, int]:
         """Runs the backbone up to the hooked block and leaves its output in the workspace (no final norm, no feature map):
-        the first half of the engine's fused path, followed by sample_patch_features.  -> (B, gh, gw).  Token facet only."""
+        the first half of the engine's fused path, followed by sample_patch_features.  -> (B, gh, gw).  Token facet only.
+        prefix_only: stop BEFORE the hooked block (fp_vit_forward_prefix); forward_selected_block then runs it for the tokens
+        the sampling needs."""
         if self._model is None:
             raise _lib.FoundPoseNativeError("call extractor.to('cuda') before running it")
         if self.facet != "token" or self.use_graph:
             raise NotImplementedError("forward_hidden serves the eager token path")
+        if prefix_only and not self.supports_token_selection:
+            raise NotImplementedError("token selection needs the bf16 mode with folded LayerNorms")
         _lib.require_cuda(images)
         images = images.float().contiguous()
         B, _, H, W = images.shape
@@ -314,20 +323,33 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
             raise _lib.FoundPoseNativeError("precision='fp8' needs its static activation scales before the first forward (act_scales= / calibrate_fp8)")
-        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        call("fp_vit_forward_prefix" if prefix_only else "fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
         self.num_patches = (gh, gw)
         self._hidden = (B, gh, gw, H, W)
         return B, gh, gw
 
-    def sample_patch_features(self, points: torch.Tensor, point_img: torch.Tensor) -> torch.Tensor:
+    def forward_selected_block(self, sel_rows: torch.Tensor, sel_off: torch.Tensor, num_sel: int, max_sel_per_img: int) -> None:
+        """The hooked block for the selected tokens only, after forward_hidden(prefix_only=True).  sel_rows: i32 global token
+        rows (b * n_tok + token; ascending, grouped by image; entries past num_sel are ignored), sel_off [B+1] i32."""
+        B, gh, gw, H, W = self._hidden
+        ws, _ = self._workspace(B, gh, gw)
+        call("fp_vit_block_selected", C.byref(self._model), C.byref(ws), B, H, W, self.layer, ptr(sel_rows), ptr(sel_off), int(num_sel),
+             int(max_sel_per_img), stream())
+
+    def sample_patch_features(self, points: torch.Tensor, point_img: torch.Tensor, row_map: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Final norm + sample_feature_map_at_points for the batch forward_hidden just ran: points [P, 2] in image coordinates,
-        point_img [P] i32 -> [P, D] fp32, bit-identical to forward()["feature_maps"] sampled with ops.sample_bilinear."""
+        point_img [P] i32 -> [P, D] fp32, bit-identical to forward()["feature_maps"] sampled with ops.sample_bilinear.
+        row_map (after forward_selected_block): i32 [B * gh * gw], patch cell -> row of the compact selected-token buffer."""
         B, gh, gw, H, W = self._hidden
         ws, _ = self._workspace(B, gh, gw)
         points = points.float().contiguous()
         out = torch.empty(points.shape[0], self.arch.dim, dtype=torch.float32, device=points.device)
-        call("fp_vit_sample_features", C.byref(self._model), C.byref(ws), B, gh, gw, int(self.apply_norm), W, H, ptr(points), ptr(point_img),
-             points.shape[0], ptr(out), stream())
+        if row_map is None:
+            call("fp_vit_sample_features", C.byref(self._model), C.byref(ws), B, gh, gw, int(self.apply_norm), W, H, ptr(points), ptr(point_img),
+                 points.shape[0], ptr(out), stream())
+        else:
+            call("fp_vit_sample_features_selected", C.byref(self._model), C.byref(ws), B, gh, gw, int(self.apply_norm), W, H, ptr(points),
+                 ptr(point_img), points.shape[0], ptr(row_map), ptr(out), stream())
         return out
 
     def _forward_facet(self, images, B, H, W, gh, gw):

@@ -12,6 +12,7 @@ from typing import List, Optional, Sequence, Tuple
 import torch
 
 from . import feature_util, ops
+from ._lib import call, ptr, stream
 from .bank import DeviceBank
 from .dinov2_utils import DinoFeatureExtractor
 from .matching import MatchResult, match_batch
@@ -39,37 +40,89 @@ class FoundPoseEngine:
         """filter_points_by_mask for the whole batch -> (points [sumQ,2], point_img [sumQ] i32, counts)."""
         return self._query_points_end(*self._query_points_begin(masks))
 
-    def _query_points_begin(self, masks: torch.Tensor):
+    def _cells9(self, w: int, h: int, device):
+        """For every grid point the 3 x 3 patch cells around the cell its sampling position rounds to: a superset of the four
+        bilinear taps whatever way the last ulp of the tap arithmetic falls.  -> [G * 9] long, cells outside the map -> gh * gw."""
+        key = ("cells9", w, h)
+        if key not in self._grids:
+            ps = self.extractor.patch_size
+            gh, gw = h // ps, w // ps
+            pts = self._grid(w, h, device)[0]
+            cx = torch.round(pts[:, 0] / ps - 0.5).long()
+            cy = torch.round(pts[:, 1] / ps - 0.5).long()
+            d = torch.tensor([-1, 0, 1], device=device)
+            xs = (cx[:, None, None] + d[None, None, :]).expand(-1, 3, 3)
+            ys = (cy[:, None, None] + d[None, :, None]).expand(-1, 3, 3)
+            ok = (xs >= 0) & (xs < gw) & (ys >= 0) & (ys < gh)
+            self._grids[key] = torch.where(ok, ys * gw + xs, torch.full_like(xs, gh * gw)).reshape(-1).contiguous()
+        return self._grids[key]
+
+    def _query_points_begin(self, masks: torch.Tensor, select_tokens: bool = False):
         """Enqueues the mask test of every grid point and an asynchronous copy of the per-detection counts to pinned memory.
         The counts are the one thing the host needs from the device per batch (segment tables of the matching stage); the
         caller enqueues the ViT forward BEFORE waiting for them, so the wait ends as soon as the previous batch has drained
-        and the device never idles between batches (a blocking .tolist() here left a bubble per step)."""
+        and the device never idles between batches (a blocking .tolist() here left a bubble per step).
+        select_tokens: also the patch tokens the sampling of those points will read (engine docstring: the hooked block only
+        has to produce these) -- index lists on the device, their per-image counts next to the point counts."""
         B, H, W = masks.shape
         pts, xi, yi, inside = self._grid(W, H, masks.device)
         on = (masks[:, yi, xi] != 0) & inside[None, :]
-        cnt_host = torch.empty(B, dtype=torch.int32, pin_memory=True)
-        cnt_host.copy_(on.sum(1, dtype=torch.int32), non_blocking=True)
+        cnt_host = torch.empty(2 * B if select_tokens else B, dtype=torch.int32, pin_memory=True)
+        cnt = on.sum(1, dtype=torch.int32)
+        sel = None
+        if select_tokens:
+            ps = self.extractor.patch_size
+            C = (H // ps) * (W // ps)
+            n_tok = 1 + self.extractor.arch.registers + C   # cls | registers | patches
+            cells = self._cells9(W, H, masks.device)
+            dev = masks.device
+            sel_cnt = torch.empty(B, dtype=torch.int32, device=dev)
+            sel_rows = torch.empty(B * C, dtype=torch.int32, device=dev)
+            sel_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
+            row_map = torch.empty(B * C, dtype=torch.int32, device=dev)
+            scratch = torch.empty(B * C, dtype=torch.int32, device=dev)
+            on_u8 = on.view(torch.uint8) if on.is_contiguous() else on.contiguous().view(torch.uint8)
+            call("fp_vit_select_tokens", ptr(on_u8), ptr(cells), B, on.shape[1], C, n_tok, ptr(scratch), ptr(sel_cnt), ptr(sel_rows), ptr(sel_off),
+                 ptr(row_map), stream())
+            cnt = torch.cat([cnt, sel_cnt])
+            sel = (sel_rows, sel_off, row_map)
+        cnt_host.copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return on, cnt_host, ev, pts
+        return on, cnt_host, ev, pts, sel
 
-    def _query_points_end(self, on, cnt_host, ev, pts):
+    def _query_points_end(self, on, cnt_host, ev, pts, sel=None):
         ev.synchronize()
-        counts = cnt_host.tolist()
+        B = on.shape[0]
+        counts = cnt_host[:B].tolist()
         total = sum(counts)
         try:
             idx = torch.nonzero_static(on, size=total)  # row-major: grouped by detection, grid order inside (like the reference); no host sync
         except (RuntimeError, NotImplementedError, AttributeError):
             idx = on.nonzero()
-        return pts[idx[:, 1]].contiguous(), idx[:, 0].to(torch.int32).contiguous(), counts
+        out = (pts[idx[:, 1]].contiguous(), idx[:, 0].to(torch.int32).contiguous(), counts)
+        if sel is None:
+            return out
+        sel_counts = cnt_host[B:].tolist()
+        return out + ((sel[0], sel[1], sel[2], sum(sel_counts), max(sel_counts)),)
 
     def infer_batch(self, images: torch.Tensor, masks: torch.Tensor, det_obj: Optional[Sequence[int]] = None,
                     keep_debug: bool = False) -> MatchResult:
         B, _, H, W = images.shape
         det_obj = [0] * B if det_obj is None else list(det_obj)
-        pending = self._query_points_begin(masks)
         fused = self.extractor.facet == "token" and not self.extractor.use_graph and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"  # env: A/B switch
-        if fused:   # final norm + sampling in one pass over the query points only: the [B, Np, D] map is never written
+        # The reference samples the hooked block's feature map at the query points and nowhere else (infer.py:452-466), so
+        # that block only has to produce the patch tokens under the sampling taps: its attention queries, proj and MLP run on
+        # those tokens (keys / values: all tokens).  Same sampled features bit for bit; FP_TOKEN_SELECT=0 is the A/B switch.
+        select = fused and self.extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0"
+        pending = self._query_points_begin(masks, select_tokens=select)
+        if select:
+            self.extractor.forward_hidden(images, prefix_only=True)  # ~115 launches enqueued before the host waits for the counts
+            q_pts, q_img, counts, (sel_rows, sel_off, row_map, num_sel, max_sel) = self._query_points_end(*pending)
+            if num_sel > 0:
+                self.extractor.forward_selected_block(sel_rows, sel_off, num_sel, max_sel)
+            raw = self.extractor.sample_patch_features(q_pts, q_img, row_map=row_map)
+        elif fused:   # final norm + sampling in one pass over the query points only: the [B, Np, D] map is never written
             self.extractor.forward_hidden(images)                # ~120 launches enqueued before the host waits for the counts
             q_pts, q_img, counts = self._query_points_end(*pending)
             raw = self.extractor.sample_patch_features(q_pts, q_img)

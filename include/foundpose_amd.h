@@ -206,6 +206,36 @@ int fp_vit_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B
 int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,
                            int img_h, const float* points, const int32_t* point_img, int num_points, float* out, fp_stream_t stream);
 
+/* Query-token selection in the hooked block (bf16 model with ln_fold).  The reference runs the backbone on every token and
+ * then reads the feature map at the query points only (utils/dinov2_utils.py:257,304 -> utils/feature_util.py:100-131 at the
+ * points of scripts/infer.py:452-466): the hooked block's OUTPUT is needed for the patch tokens under the sampling taps and
+ * for no other token, while its keys and values still come from all tokens.  Three calls replace fp_vit_forward +
+ * fp_vit_sample_features with identical sampled features (bit for bit: a token's row never depends on which rows share its
+ * GEMM tile or attention block):
+ *   fp_vit_forward_prefix   embedding + blocks 0..layer-1 (what block `layer` starts from stays in the workspace);
+ *   fp_vit_block_selected   block `layer`: LayerNorm constants and the qkv projection for all tokens, then attention
+ *                           queries, proj, fc1 and fc2 for the selected tokens only.  sel_rows [num_sel] = global token
+ *                           rows (b * n_tok + token), ascending, grouped by image; sel_off [B + 1] = offsets of the images
+ *                           in sel_rows; max_sel_per_img >= the largest per-image count (host value: it sizes the grid).
+ *                           The selected rows of the residual stream are left compact ([num_sel, D] fp32) in ws->qkv;
+ *   fp_vit_sample_features_selected   as fp_vit_sample_features, reading those rows through row_map [B * grid_h * grid_w]:
+ *                           patch cell -> its row in the compact buffer, < 0 if the cell was not selected.  Every tap of
+ *                           every point must be selected (a missed tap returns NaN features, never a silently wrong row). */
+/* The selection itself, on the device (two small launches): point_on [B, num_points] u8 = grid point g of image b is a query
+ * point; point_cells [num_points, 9] i64 = the patch cells the sampling of grid point g may read (its 3 x 3 neighbourhood;
+ * num_cells for "outside the map").  -> counts [B] selected tokens per image (copy them to the host for num_sel /
+ * max_sel_per_img), sel_rows [B * num_cells] (first sum(counts) entries valid), sel_off [B + 1], row_map [B * num_cells];
+ * scratch: B * num_cells i32. */
+int fp_vit_select_tokens(const uint8_t* point_on, const int64_t* point_cells, int B, int num_points, int num_cells, int n_tok, int32_t* scratch,
+                         int32_t* counts, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream);
+int fp_vit_forward_prefix(const fp_vit_model* model, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer,
+                          fp_stream_t stream);
+int fp_vit_block_selected(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int H, int W, int layer, const int32_t* sel_rows,
+                          const int32_t* sel_off, int num_sel, int max_sel_per_img, fp_stream_t stream);
+int fp_vit_sample_features_selected(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm,
+                                    int img_w, int img_h, const float* points, const int32_t* point_img, int num_points,
+                                    const int32_t* row_map, float* out, fp_stream_t stream);
+
 /* Building blocks, exported for unit tests and for callers that schedule the layers themselves. */
 int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
                 fp_stream_t stream);

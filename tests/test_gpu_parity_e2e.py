@@ -73,3 +73,28 @@ def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, temp
     assert full["templates_equal"] == batch and plbf["planted_top5_in_order"] == batch and pl32["planted_top5_in_order"] == batch
     # correspondences: the same patch-to-feature pairs up to the few nearest neighbours the bf16 feature error moves
     assert pbf["corresp_overlap"] >= 0.9 and full["corresp_overlap"] >= 0.9
+
+
+def test_token_selection_changes_nothing_end_to_end(monkeypatch):
+    """The engine's default path computes the hooked block for the sampled tokens only; with FP_TOKEN_SELECT=0 it runs the
+    block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark
+    geometry (ViT-L/14-reg layer 18, 518 px) with masks of different sizes in one batch."""
+    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    wl = workload.build_planted_workload(ex32, 8, 518, 1, 200, seed=5, crop_seed=1)
+    del ex32
+    bank = DeviceBank(wl.repres)
+    masks = wl.masks.clone()
+    masks[1, :, 300:] = 0          # half a disc
+    masks[2] = 0
+    masks[2, 200:260, 100:400] = 1  # a bar
+    masks[3] = 1                    # everything
+    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    eng = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
+    assert exbf.supports_token_selection
+    monkeypatch.setenv("FP_TOKEN_SELECT", "1")
+    a = eng.infer_batch(wl.crops, masks, wl.det_obj)
+    monkeypatch.setenv("FP_TOKEN_SELECT", "0")
+    b = eng.infer_batch(wl.crops, masks, wl.det_obj)
+    for name in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d"):
+        x, y = getattr(a, name), getattr(b, name)
+        assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), name

@@ -516,3 +516,47 @@ def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
     ex.forward_hidden(imgs)
     got = ex.sample_patch_features(pts, img_of)
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("version,size,layer", [("vits14-reg", 224, 3), ("vits14-reg", 224, 0), ("vitl14-reg", 518, 2)])
+def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer):
+    """fp_vit_forward_prefix + fp_vit_block_selected + fp_vit_sample_features_selected: the hooked block computed only for
+    the patch tokens the sampling reads (attention queries, proj, fc1, fc2 on the selected rows; keys / values all tokens)
+    gives the SAME sampled features, bit for bit, as the full forward -- per-image selections of different sizes (a disc, a
+    thin bar, a single cell, everything), points on and off the cell centres."""
+    from foundpose_amd import feature_util
+    from foundpose_amd.engine import FoundPoseEngine
+    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision="bf16").to("cuda")
+    assert ex.supports_token_selection
+    B = 4
+    imgs = synthetic.make_crops(B, size, seed=5).cuda()
+    masks = torch.zeros(B, size, size, dtype=torch.uint8)
+    masks[0] = synthetic.make_disc_mask(size)
+    masks[1, size // 3: size // 3 + 20, 10: size - 30] = 1
+    masks[2, size // 2, size // 2] = 1
+    masks[2, 7, 7] = 1                       # a corner cell: taps outside the map
+    masks[3] = 1
+    masks = masks.cuda()
+    eng = FoundPoseEngine(ex, None)
+    # full forward, then sampling at the engine's query points
+    ex.forward_hidden(imgs)
+    q_pts, q_img, counts = eng.query_points(masks)
+    want = ex.sample_patch_features(q_pts, q_img)
+    # selected: prefix, block on the selected tokens, sampling through the row map
+    pending = eng._query_points_begin(masks, select_tokens=True)
+    ex.forward_hidden(imgs, prefix_only=True)
+    q_pts2, q_img2, counts2, (sel_rows, sel_off, row_map, num_sel, max_sel) = eng._query_points_end(*pending)
+    assert counts2 == counts and torch.equal(q_pts2, q_pts)
+    gh = size // 14
+    assert 0 < num_sel < B * gh * gh and max_sel == gh * gh   # image 3 selects every cell, image 2 a handful
+    ex.forward_selected_block(sel_rows, sel_off, num_sel, max_sel)
+    got = ex.sample_patch_features(q_pts2, q_img2, row_map=row_map)
+    assert not bool(torch.isnan(got).any())
+    assert torch.equal(got, want)
+    # points off the cell centres inside the selected region sample the same values too (image 3: every cell is selected)
+    g = torch.Generator().manual_seed(1)
+    off = (torch.rand(300, 2, generator=g) * (size + 16) - 8).cuda()
+    img3 = torch.full((300,), 3, dtype=torch.int32, device="cuda")
+    got_off = ex.sample_patch_features(off, img3, row_map=row_map)
+    ex.forward_hidden(imgs)
+    assert torch.equal(got_off, ex.sample_patch_features(off, img3))
