@@ -55,7 +55,7 @@ _PROTOS = {
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],
     "fp_vit_forward": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
     "fp_vit_sample_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
-    "fp_vit_select_tokens": [vp, vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp],
+    "fp_query_select": [vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "fp_vit_forward_prefix": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
     "fp_vit_block_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "fp_vit_sample_features_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp],

@@ -590,11 +590,13 @@ int fp_vit_sample_features(const fp_vit_model* m, const fp_vit_workspace* ws, in
                           points, point_img, num_points, out, ST(stream));
 }
 
-int fp_vit_select_tokens(const uint8_t* point_on, const int64_t* point_cells, int B, int num_points, int num_cells, int n_tok, int32_t* scratch,
-                         int32_t* counts, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream) {
-  FP_REQUIRE(point_on && point_cells && scratch && counts && sel_rows && sel_off && row_map, "fp_vit_select_tokens: null pointer");
-  return select_tokens_launch(point_on, reinterpret_cast<const long long*>(point_cells), B, num_points, num_cells, n_tok, scratch, counts, sel_rows,
-                              sel_off, row_map, ST(stream));
+int fp_query_select(const uint8_t* masks, int B, int H, int W, const int32_t* pix_x, const int32_t* pix_y, const float* grid_points, int num_points,
+                    const int64_t* point_cells, int num_cells, int n_tok, int32_t* scratch, int32_t* counts, float* out_points, int32_t* out_point_img,
+                    int32_t* out_q_off, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream) {
+  FP_REQUIRE(masks && pix_x && pix_y && grid_points && scratch && counts && out_points && out_point_img, "fp_query_select: null pointer");
+  FP_REQUIRE(!point_cells || (sel_rows && sel_off && row_map), "fp_query_select: the token selection needs sel_rows, sel_off and row_map");
+  return query_select_launch(masks, B, H, W, pix_x, pix_y, grid_points, num_points, reinterpret_cast<const long long*>(point_cells), num_cells, n_tok,
+                             scratch, counts, out_points, out_point_img, out_q_off, sel_rows, sel_off, row_map, ST(stream));
 }
 
 int fp_vit_sample_features_selected(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,

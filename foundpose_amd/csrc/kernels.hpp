@@ -150,8 +150,9 @@ int ln_sample_launch(const float* x, int ld_x, const float* weight, const float*
                      int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st,
                      const int* row_map = nullptr);
 int gather_rows_launch(const float* x, const int* rows, int n, int dim, float* out, hipStream_t st);
-int select_tokens_launch(const unsigned char* on, const long long* cells9, int B, int G, int C, int n_tok, int* scratch_rank, int* counts,
-                         int* sel_rows, int* sel_off, int* row_map, hipStream_t st);
+int query_select_launch(const unsigned char* masks, int B, int H, int W, const int* pix_x, const int* pix_y, const float* grid_pts, int G,
+                        const long long* cells9, int C, int n_tok, int* scratch, int* counts, float* out_pts, int* out_img, int* q_off, int* sel_rows,
+                        int* sel_off, int* row_map, hipStream_t st);
 // x [rows, dim] fp32 -> xb = bf16(x) [rows, ld_xb] and stats[0 * stats_stride + row] = (sum x, sum x^2), slots 1..parts-1 zero
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);

@@ -316,66 +316,104 @@ __global__ void ln_finalize_kernel(const float2* __restrict__ partial, int parts
   out[row] = make_float2(rs, mu * rs);
 }
 
-// ---- token selection for the hooked block (fp_vit_select_tokens): which patch tokens will the sampling of the query points
-// read?  Kernel 1, one workgroup per image: the cells named by the live grid points (cells9: for every grid point the 3 x 3
-// cells around its sampling position, a superset of the four bilinear taps) are flagged in LDS, a block scan ranks them.
-// Kernel 2 adds the counts of the images in front and writes the lists.
-__global__ __launch_bounds__(256) void token_flags_kernel(const unsigned char* __restrict__ on, const long long* __restrict__ cells9, int G, int C,
-                                                          int* __restrict__ local_rank, int* __restrict__ counts) {
+// ---- query points and token selection of a batch (fp_query_select): the mask test of every grid point
+// (filter_points_by_mask, feature_util.py:36-41 in the reference: pixel = int(point + 0.5) strictly inside the canvas and on
+// the mask), the per-image point lists in grid order, and -- for the hooked block -- which patch tokens the sampling of those
+// points will read.  Kernel 1, one workgroup per image: ordered ballot scans rank the live points; the cells they name
+// (cells9: for every grid point the 3 x 3 cells around its sampling position, a superset of the four bilinear taps) are
+// flagged in LDS and ranked the same way.  Kernel 2 adds the counts of the images in front and writes the lists.
+FP_DEVICE int block_rank256(bool f, int& base, int* wave_tot, int lane, int wave) {
+  const unsigned long long m = __ballot(f);
+  const int before = __popcll(m & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_tot[wave] = __popcll(m);
+  __syncthreads();
+  int woff = 0, tot = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    if (w < wave) woff += wave_tot[w];
+    tot += wave_tot[w];
+  }
+  const int r = f ? base + woff + before : -1;
+  base += tot;
+  __syncthreads();
+  return r;
+}
+
+__global__ __launch_bounds__(256) void query_flags_kernel(const unsigned char* __restrict__ masks, int H, int W, const int* __restrict__ pix_x,
+                                                          const int* __restrict__ pix_y, int G, const long long* __restrict__ cells9, int C,
+                                                          int* __restrict__ point_rank, int* __restrict__ cell_rank, int* __restrict__ counts) {
   extern __shared__ int sel_smem[];
   int* flag = sel_smem;            // [C + 1] (slot C collects the cells outside the map)
   __shared__ int wave_tot[4];
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int c = tid; c <= C; c += 256) flag[c] = 0;
-  __syncthreads();
-  for (int g = tid; g < G; g += 256)
-    if (on[(size_t)b * G + g]) {
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (cells9) {
+    for (int c = tid; c <= C; c += 256) flag[c] = 0;
+    __syncthreads();
+  }
+  const unsigned char* mk = masks + (size_t)b * H * W;
+  int base = 0;
+  for (int g0 = 0; g0 < G; g0 += 256) {
+    const int g = g0 + tid;
+    bool on = false;
+    if (g < G) {
+      const int x = pix_x[g], y = pix_y[g];
+      on = x > 0 && x < W && y > 0 && y < H && mk[(size_t)y * W + x] != 0;
+    }
+    if (on && cells9) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) flag[(int)cells9[(size_t)g * 9 + k]] = 1;  // benign race: every writer stores 1
     }
-  __syncthreads();
-  // exclusive scan over the cells in chunks of 256
-  int base = 0;
-  for (int c0 = 0; c0 < C; c0 += 256) {
-    const int c = c0 + tid;
-    const int f = c < C ? flag[c] : 0;
-    const unsigned long long m = __ballot(f != 0);
-    const int before = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == 0) wave_tot[wave] = __popcll(m);
-    __syncthreads();
-    int woff = 0, tot = 0;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      if (w < wave) woff += wave_tot[w];
-      tot += wave_tot[w];
-    }
-    if (c < C) local_rank[(size_t)b * C + c] = f ? base + woff + before : -1;
-    base += tot;
-    __syncthreads();
+    const int r = block_rank256(on, base, wave_tot, lane, wave);
+    if (g < G) point_rank[(size_t)b * G + g] = r;
   }
   if (tid == 0) counts[b] = base;
+  if (!cells9) return;
+  __syncthreads();
+  base = 0;
+  for (int c0 = 0; c0 < C; c0 += 256) {
+    const int c = c0 + tid;
+    const int r = block_rank256(c < C && flag[c] != 0, base, wave_tot, lane, wave);
+    if (c < C) cell_rank[(size_t)b * C + c] = r;
+  }
+  if (tid == 0) counts[B + b] = base;
 }
 
-__global__ __launch_bounds__(256) void token_lists_kernel(const int* __restrict__ local_rank, const int* __restrict__ counts, int B, int C, int n_tok,
+__global__ __launch_bounds__(256) void query_lists_kernel(const int* __restrict__ point_rank, const int* __restrict__ cell_rank,
+                                                          const int* __restrict__ counts, int G, int C, int n_tok, const float* __restrict__ grid_pts,
+                                                          float* __restrict__ out_pts, int* __restrict__ out_img, int* __restrict__ q_off,
                                                           int* __restrict__ sel_rows, int* __restrict__ sel_off, int* __restrict__ row_map) {
-  __shared__ int s_off;
-  const int b = blockIdx.x, tid = threadIdx.x;
-  if (tid < 64) {
+  __shared__ int s_off[2];
+  const int b = blockIdx.x, B = gridDim.x, tid = threadIdx.x;
+  if (tid < 128) {  // wave 0: points in front of this image, wave 1: selected cells in front of it
+    const int which = tid >> 6, lane = tid & 63;
     int part = 0;
-    for (int i = tid; i < b; i += 64) part += counts[i];
-    part = (int)wave_sum((float)part);  // counts are small integers (< 2^24): exact in fp32
-    if (tid == 0) {
-      s_off = part;
-      sel_off[b] = part;
-      if (b == B - 1) sel_off[B] = part + counts[b];
+    if (which == 0 || cell_rank)
+      for (int i = lane; i < b; i += 64) part += counts[which * B + i];
+    part = (int)wave_sum((float)part);  // < 2^24: exact in fp32
+    if (lane == 0) {
+      s_off[which] = part;
+      int* off = which ? sel_off : q_off;
+      if (off && (which == 0 || cell_rank)) {
+        off[b] = part;
+        if (b == B - 1) off[B] = part + counts[which * B + b];
+      }
     }
   }
   __syncthreads();
-  const int off = s_off, skip = n_tok - C;
+  const int poff = s_off[0], coff = s_off[1], skip = n_tok - C;
+  for (int g = tid; g < G; g += 256) {
+    const int r = point_rank[(size_t)b * G + g];
+    if (r >= 0) {
+      out_pts[2 * (size_t)(poff + r)] = grid_pts[2 * g];
+      out_pts[2 * (size_t)(poff + r) + 1] = grid_pts[2 * g + 1];
+      out_img[poff + r] = b;
+    }
+  }
+  if (!cell_rank) return;
   for (int c = tid; c < C; c += 256) {
-    const int r = local_rank[(size_t)b * C + c];
-    row_map[(size_t)b * C + c] = r < 0 ? -1 : off + r;
-    if (r >= 0) sel_rows[off + r] = b * n_tok + skip + c;
+    const int r = cell_rank[(size_t)b * C + c];
+    row_map[(size_t)b * C + c] = r < 0 ? -1 : coff + r;
+    if (r >= 0) sel_rows[coff + r] = b * n_tok + skip + c;
   }
 }
 
@@ -425,14 +463,20 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   return FP_OK;
 }
 
-int select_tokens_launch(const unsigned char* on, const long long* cells9, int B, int G, int C, int n_tok, int* scratch_rank, int* counts,
-                         int* sel_rows, int* sel_off, int* row_map, hipStream_t st) {
-  FP_REQUIRE(B >= 1 && G >= 1 && C >= 1 && n_tok >= C, "select_tokens: bad sizes");
-  FP_REQUIRE((size_t)(C + 1) * 4 <= 64 * 1024 && (long long)B * n_tok < (1ll << 24), "select_tokens: map too large");
-  hipLaunchKernelGGL(token_flags_kernel, dim3(B), dim3(256), (size_t)(C + 1) * 4, st, on, cells9, G, C, scratch_rank, counts);
-  FP_CHECK_LAUNCH("token_flags");
-  hipLaunchKernelGGL(token_lists_kernel, dim3(B), dim3(256), 0, st, scratch_rank, counts, B, C, n_tok, sel_rows, sel_off, row_map);
-  FP_CHECK_LAUNCH("token_lists");
+int query_select_launch(const unsigned char* masks, int B, int H, int W, const int* pix_x, const int* pix_y, const float* grid_pts, int G,
+                        const long long* cells9, int C, int n_tok, int* scratch, int* counts, float* out_pts, int* out_img, int* q_off, int* sel_rows,
+                        int* sel_off, int* row_map, hipStream_t st) {
+  FP_REQUIRE(B >= 1 && G >= 1 && H >= 1 && W >= 1, "query_select: bad sizes");
+  FP_REQUIRE(!cells9 || (C >= 1 && n_tok >= C && (size_t)(C + 1) * 4 <= 64 * 1024), "query_select: bad token map");
+  FP_REQUIRE((long long)B * (G > n_tok ? G : n_tok) < (1ll << 24), "query_select: batch too large");
+  int* point_rank = scratch;
+  int* cell_rank = cells9 ? scratch + (size_t)B * G : nullptr;
+  hipLaunchKernelGGL(query_flags_kernel, dim3(B), dim3(256), cells9 ? (size_t)(C + 1) * 4 : 0, st, masks, H, W, pix_x, pix_y, G, cells9, C, point_rank,
+                     cell_rank, counts);
+  FP_CHECK_LAUNCH("query_flags");
+  hipLaunchKernelGGL(query_lists_kernel, dim3(B), dim3(256), 0, st, point_rank, cell_rank, counts, G, C, n_tok, grid_pts, out_pts, out_img, q_off, sel_rows,
+                     sel_off, row_map);
+  FP_CHECK_LAUNCH("query_lists");
   return FP_OK;
 }
 

@@ -28,17 +28,13 @@ class FoundPoseEngine:
         self._grids = {}
 
     def _grid(self, w: int, h: int, device):
+        """Grid points of a w x h crop (generate_grid_points) and their pixels int(point + 0.5) (filter_points_by_mask)."""
         key = (w, h)
         if key not in self._grids:
-            pts = feature_util.generate_grid_points((w, h), self.cell).to(device)
+            pts = feature_util.generate_grid_points((w, h), self.cell).to(device).float().contiguous()
             pix = (pts + 0.5).int()
-            inside = (pix[:, 0] > 0) & (pix[:, 0] < w) & (pix[:, 1] > 0) & (pix[:, 1] < h)
-            self._grids[key] = (pts, pix[:, 0].long(), pix[:, 1].long(), inside)
+            self._grids[key] = (pts, pix[:, 0].contiguous(), pix[:, 1].contiguous())
         return self._grids[key]
-
-    def query_points(self, masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
-        """filter_points_by_mask for the whole batch -> (points [sumQ,2], point_img [sumQ] i32, counts)."""
-        return self._query_points_end(*self._query_points_begin(masks))
 
     def _cells9(self, w: int, h: int, device):
         """For every grid point the 3 x 3 patch cells around the cell its sampling position rounds to: a superset of the four
@@ -57,50 +53,48 @@ class FoundPoseEngine:
             self._grids[key] = torch.where(ok, ys * gw + xs, torch.full_like(xs, gh * gw)).reshape(-1).contiguous()
         return self._grids[key]
 
+    def query_points(self, masks: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, List[int]]:
+        """filter_points_by_mask for the whole batch -> (points [sumQ,2], point_img [sumQ] i32, counts)."""
+        return self._query_points_end(*self._query_points_begin(masks))
+
     def _query_points_begin(self, masks: torch.Tensor, select_tokens: bool = False):
-        """Enqueues the mask test of every grid point and an asynchronous copy of the per-detection counts to pinned memory.
-        The counts are the one thing the host needs from the device per batch (segment tables of the matching stage); the
-        caller enqueues the ViT forward BEFORE waiting for them, so the wait ends as soon as the previous batch has drained
-        and the device never idles between batches (a blocking .tolist() here left a bubble per step).
-        select_tokens: also the patch tokens the sampling of those points will read (engine docstring: the hooked block only
-        has to produce these) -- index lists on the device, their per-image counts next to the point counts."""
+        """Enqueues fp_query_select -- the mask test of every grid point, the per-detection point lists and (select_tokens) the
+        patch tokens the sampling of those points will read, the only outputs the hooked block has to produce -- and an
+        asynchronous copy of the per-detection counts to pinned memory.  The counts are the one thing the host needs from the
+        device per batch (buffer sizes, segment tables of the matching stage); the caller enqueues the ViT forward BEFORE
+        waiting for them, so the wait ends as soon as the previous batch has drained and the device never idles between
+        batches (a blocking .tolist() here left a bubble per step)."""
         B, H, W = masks.shape
-        pts, xi, yi, inside = self._grid(W, H, masks.device)
-        on = (masks[:, yi, xi] != 0) & inside[None, :]
-        cnt_host = torch.empty(2 * B if select_tokens else B, dtype=torch.int32, pin_memory=True)
-        cnt = on.sum(1, dtype=torch.int32)
+        dev = masks.device
+        pts, pix_x, pix_y = self._grid(W, H, dev)
+        G = pts.shape[0]
+        m8 = masks if masks.dtype == torch.uint8 else (masks.view(torch.uint8) if masks.dtype == torch.bool else (masks != 0).to(torch.uint8))
+        m8 = m8.contiguous()
+        ps = self.extractor.patch_size if select_tokens else 1
+        C = (H // ps) * (W // ps) if select_tokens else 0
+        n_tok = 1 + self.extractor.arch.registers + C if select_tokens else 0   # cls | registers | patches
+        cnt = torch.empty(2 * B if select_tokens else B, dtype=torch.int32, device=dev)
+        out_pts = torch.empty(B * G, 2, dtype=torch.float32, device=dev)
+        out_img = torch.empty(B * G, dtype=torch.int32, device=dev)
+        scratch = torch.empty(B * (G + C), dtype=torch.int32, device=dev)
         sel = None
         if select_tokens:
-            ps = self.extractor.patch_size
-            C = (H // ps) * (W // ps)
-            n_tok = 1 + self.extractor.arch.registers + C   # cls | registers | patches
-            cells = self._cells9(W, H, masks.device)
-            dev = masks.device
-            sel_cnt = torch.empty(B, dtype=torch.int32, device=dev)
-            sel_rows = torch.empty(B * C, dtype=torch.int32, device=dev)
-            sel_off = torch.empty(B + 1, dtype=torch.int32, device=dev)
-            row_map = torch.empty(B * C, dtype=torch.int32, device=dev)
-            scratch = torch.empty(B * C, dtype=torch.int32, device=dev)
-            on_u8 = on.view(torch.uint8) if on.is_contiguous() else on.contiguous().view(torch.uint8)
-            call("fp_vit_select_tokens", ptr(on_u8), ptr(cells), B, on.shape[1], C, n_tok, ptr(scratch), ptr(sel_cnt), ptr(sel_rows), ptr(sel_off),
-                 ptr(row_map), stream())
-            cnt = torch.cat([cnt, sel_cnt])
-            sel = (sel_rows, sel_off, row_map)
+            sel = (torch.empty(B * C, dtype=torch.int32, device=dev), torch.empty(B + 1, dtype=torch.int32, device=dev),
+                   torch.empty(B * C, dtype=torch.int32, device=dev))
+        call("fp_query_select", ptr(m8), B, H, W, ptr(pix_x), ptr(pix_y), ptr(pts), G, ptr(self._cells9(W, H, dev)) if select_tokens else None, C, n_tok,
+             ptr(scratch), ptr(cnt), ptr(out_pts), ptr(out_img), None, ptr(sel[0]) if sel else None, ptr(sel[1]) if sel else None,
+             ptr(sel[2]) if sel else None, stream())
+        cnt_host = torch.empty(cnt.shape[0], dtype=torch.int32, pin_memory=True)
         cnt_host.copy_(cnt, non_blocking=True)
         ev = torch.cuda.Event()
         ev.record()
-        return on, cnt_host, ev, pts, sel
+        return B, cnt_host, ev, out_pts, out_img, sel
 
-    def _query_points_end(self, on, cnt_host, ev, pts, sel=None):
+    def _query_points_end(self, B, cnt_host, ev, out_pts, out_img, sel=None):
         ev.synchronize()
-        B = on.shape[0]
         counts = cnt_host[:B].tolist()
         total = sum(counts)
-        try:
-            idx = torch.nonzero_static(on, size=total)  # row-major: grouped by detection, grid order inside (like the reference); no host sync
-        except (RuntimeError, NotImplementedError, AttributeError):
-            idx = on.nonzero()
-        out = (pts[idx[:, 1]].contiguous(), idx[:, 0].to(torch.int32).contiguous(), counts)
+        out = (out_pts[:total], out_img[:total], counts)
         if sel is None:
             return out
         sel_counts = cnt_host[B:].tolist()
@@ -147,6 +141,14 @@ class FoundPoseEngine:
     def _project(self, raw: torch.Tensor, counts: Sequence[int], det_obj: Sequence[int]) -> torch.Tensor:
         if raw.shape[1] == self.bank.feat_dim:
             return raw
+        if len(set(det_obj)) == 1:  # one object in the batch: its projector chain on all rows, no copy into a joint buffer
+            projs = self.bank.objects[det_obj[0]].projectors
+            if not projs:
+                raise ValueError("feature dims differ from the bank and the object has no projector")
+            x = raw
+            for p in projs:
+                x = p.transform(x)
+            return x
         out = torch.empty(raw.shape[0], self.bank.feat_dim, dtype=torch.float32, device=raw.device)
         r0 = 0
         i = 0

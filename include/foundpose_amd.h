@@ -221,13 +221,20 @@ int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws
  *   fp_vit_sample_features_selected   as fp_vit_sample_features, reading those rows through row_map [B * grid_h * grid_w]:
  *                           patch cell -> its row in the compact buffer, < 0 if the cell was not selected.  Every tap of
  *                           every point must be selected (a missed tap returns NaN features, never a silently wrong row). */
-/* The selection itself, on the device (two small launches): point_on [B, num_points] u8 = grid point g of image b is a query
- * point; point_cells [num_points, 9] i64 = the patch cells the sampling of grid point g may read (its 3 x 3 neighbourhood;
- * num_cells for "outside the map").  -> counts [B] selected tokens per image (copy them to the host for num_sel /
- * max_sel_per_img), sel_rows [B * num_cells] (first sum(counts) entries valid), sel_off [B + 1], row_map [B * num_cells];
- * scratch: B * num_cells i32. */
-int fp_vit_select_tokens(const uint8_t* point_on, const int64_t* point_cells, int B, int num_points, int num_cells, int n_tok, int32_t* scratch,
-                         int32_t* counts, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream);
+/* Query points of a batch and, optionally, the token selection above -- on the device, two small launches, no host
+ * round trip (generate_grid_points + filter_points_by_mask, utils/feature_util.py:19-41, called per detection at
+ * scripts/infer.py:359,478).  masks [B, H, W] u8; grid point g = grid_points[g] (x, y) with pixel (pix_x[g], pix_y[g]) =
+ * int(point + 0.5); it is a query point of image b iff the pixel lies strictly inside the canvas and on the mask.
+ * -> counts [B] points per image (+ [B, 2B) selected tokens per image when point_cells is given: copy them to the host);
+ *    out_points [B * num_points, 2] / out_point_img [B * num_points]: the first sum(counts) rows are the query points,
+ *    grouped by image, grid order inside (the order of the reference's boolean indexing); out_q_off [B + 1] (may be null).
+ * point_cells (may be null) [num_points, 9] i64 = the patch cells the sampling of grid point g may read (the 3 x 3 cells
+ * around the cell its sampling position rounds to; num_cells for "outside the map") -> sel_rows [B * num_cells] (first
+ * sum(counts[B:]) entries valid), sel_off [B + 1], row_map [B * num_cells] as fp_vit_block_selected /
+ * fp_vit_sample_features_selected take them.  scratch: B * (num_points + num_cells) i32. */
+int fp_query_select(const uint8_t* masks, int B, int H, int W, const int32_t* pix_x, const int32_t* pix_y, const float* grid_points, int num_points,
+                    const int64_t* point_cells, int num_cells, int n_tok, int32_t* scratch, int32_t* counts, float* out_points, int32_t* out_point_img,
+                    int32_t* out_q_off, int32_t* sel_rows, int32_t* sel_off, int32_t* row_map, fp_stream_t stream);
 int fp_vit_forward_prefix(const fp_vit_model* model, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer,
                           fp_stream_t stream);
 int fp_vit_block_selected(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int H, int W, int layer, const int32_t* sel_rows,
