@@ -230,6 +230,19 @@ def main():
         ms_knn, ms_knn_other = knn(tie_mode), knn(1 - tie_mode)
         knn_bytes = args.templates * 2048 * 4 + Bq * 2048 * 4 + Bq * args.templates * 4   # bank (read once) + queries + finished scores
         knn_flops = 2.0 * Bq * args.templates * 2048
+        # the same call at BASELINE config 5's bank size (50 000 templates, one 32-detection pass): the stream is long enough to
+        # amortise launch + ring fill, which dominate at 10 000 templates (82 MB = 10 us of HBM time)
+        T5 = 50000
+        bank5 = ops.normalize_rows(torch.rand(T5, 2048, device=dev))
+        q5 = ops.normalize_rows(torch.rand(32, 2048, device=dev))
+        seg5, tpl5 = torch.tensor([0, 32], dtype=torch.int32, device=dev), torch.tensor([0, T5], dtype=torch.int32, device=dev)
+        nt5 = torch.full((32,), T5, dtype=torch.int32, device=dev)
+        sims5 = torch.empty(cosine_scratch_floats(32, T5), device=dev)
+        sc5, ids5 = torch.empty(32, 5, device=dev), torch.empty(32, 5, dtype=torch.int32, device=dev)
+        ms_knn5 = time_kernel(lambda: call("fp_cosine_topk", ptr(q5), ptr(seg5), ptr(nt5), 32, 32, ptr(bank5), ptr(tpl5), 1, T5, 2048, 5, ptr(sims5),
+                                           ptr(sc5), ptr(ids5), tie_mode, stream()), iters=20)
+        knn5_bytes = T5 * 2048 * 4 + 32 * 2048 * 4 + 32 * T5 * 4
+        del bank5, sims5
         key = (args.version, args.size, B, args.precision)
         result = {
             "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",
@@ -266,6 +279,10 @@ def main():
                              "fp32_mfma_tflops": round(knn_flops / (ms_knn * 1e-3) / 1e12, 1), "fp32_mfma_peak": 157.3,
                              "note": "exact-fp32 scores: at 32 detections per bank pass the op sits at the fp32-MFMA / HBM ridge (16 FLOP/B vs 19.7), "
                                      "more detections per object add passes (32 at a time) and make it MFMA-bound"},
+            "roofline_knn_50k_templates": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}', 50 000 templates x 32 detections (BASELINE config 5's bank, random descriptors)",
+                                           "bound": "hbm", "achieved": round(knn5_bytes / (ms_knn5 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                           "frac": round(knn5_bytes / (ms_knn5 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn5, 4),
+                                           "bytes_per_launch": knn5_bytes},
         }
         lists = [last.corresp_list(b) for b in range(B)]
         parity = {"tie_order": args.tie_order, "planted": workload.planted_stats(lists, wl.targets.tolist())}

@@ -88,6 +88,7 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch):
     masks[2] = 0
     masks[2, 200:260, 100:400] = 1  # a bar
     masks[3] = 1                    # everything
+    masks[5] = 0                    # no query point at all: the detection selects no token
     exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
     eng = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
     assert exbf.supports_token_selection
