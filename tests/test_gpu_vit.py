@@ -560,3 +560,34 @@ def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer):
     got_off = ex.sample_patch_features(off, img3, row_map=row_map)
     ex.forward_hidden(imgs)
     assert torch.equal(got_off, ex.sample_patch_features(off, img3))
+
+
+@pytest.mark.parametrize("dtype", [torch.uint8, torch.bool, torch.float32])
+def test_query_select_equals_filter_points_by_mask(dtype):
+    """fp_query_select (the engine's batched mask test + point lists) == generate_grid_points + filter_points_by_mask of the
+    reference (feature_util.py:19-41) per detection, in its order; mask dtypes as callers hand them over; random masks,
+    an empty one, a full one, pixels on the canvas border."""
+    from foundpose_amd import feature_util
+    from foundpose_amd.engine import FoundPoseEngine
+    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=1_norm=1", seed=8, precision="bf16").to("cuda")
+    g = torch.Generator().manual_seed(3)
+    for size, cell in ((224, 14.0), (210, 10.0), (126, 7.0)):
+        B = 5
+        m = (torch.rand(B, size, size, generator=g) > 0.6)
+        m[1] = False
+        m[2] = True
+        m[3] = False
+        m[3, 0, :] = True          # only border pixels: strictly-inside test
+        m[3, :, 0] = True
+        masks = m.to(dtype).cuda()
+        eng = FoundPoseEngine(ex, None, grid_cell_size=cell)
+        pts, img, counts = eng.query_points(masks)
+        grid = feature_util.generate_grid_points((size, size), cell).cuda()
+        off = 0
+        for b in range(B):
+            ref = feature_util.filter_points_by_mask(grid, m[b].cuda())
+            assert counts[b] == ref.shape[0], (size, b)
+            assert torch.equal(pts[off:off + counts[b]], ref)
+            assert bool((img[off:off + counts[b]] == b).all())
+            off += counts[b]
+        assert off == pts.shape[0]
