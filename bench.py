@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the ViT forward as one hipGraph (measured: no gain, the step is GPU-bound: 34.51 vs 34.44 ms)")
     ap.add_argument("--no-token-select", action="store_true",
                     help="run the hooked block on every token (default: only on the patch tokens the query points sample; same outputs bit for bit)")
+    ap.add_argument("--overlap", action="store_true", help="matching of batch i on a second stream beside the backbone of batch i+1 (engine overlap_matching; measured +0.3...0.8 %%, not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
     ap.add_argument("--cpu-detections", type=int, default=3)
@@ -116,13 +117,17 @@ def main():
     extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
     if args.precision == "fp8":
         extractor.calibrate_fp8(images)  # static activation scales are part of the fp8 model (no implicit calibration)
-    eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order)
+    eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order, overlap_matching=args.overlap)
     if args.no_token_select:
         os.environ["FP_TOKEN_SELECT"] = "0"
     select_on = extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0" and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"
 
     def step(e=eng):
         res = e.infer_batch(images, masks, det_obj)
+        if e.overlap_matching:   # the record + exchange of this batch stay on the matching stream, beside the next batch's backbone
+            with torch.cuda.stream(e.side_stream):
+                rec = fe.pack_result(res)
+                return fe.gather_records(rec, world), res
         rec = fe.pack_result(res)
         return fe.gather_records(rec, world), res   # the one exchange step (RCCL all-gather over xGMI)
 

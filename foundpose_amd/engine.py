@@ -20,8 +20,16 @@ from .matching import MatchResult, match_batch
 
 class FoundPoseEngine:
     def __init__(self, extractor: DinoFeatureExtractor, bank: DeviceBank, grid_cell_size: float = 14.0,
-                 top_n_templates: int = 5, top_k_buddies: int = 300, tie_order: str = "canonical") -> None:
+                 top_n_templates: int = 5, top_k_buddies: int = 300, tie_order: str = "canonical", overlap_matching: bool = False) -> None:
+        """overlap_matching: the matching stage of a batch (projection, retrieval, cyclic buddies: ~1 ms of small, latency-bound
+        launches) is enqueued on a second stream behind an event, so the next infer_batch's backbone -- enqueued on the
+        caller's stream -- runs beside it: the small launches fill the CUs the big GEMMs leave idle in their tail rounds.
+        infer_batch then returns a MatchResult whose tensors are complete when `result.ready` has fired: call
+        `result.wait()` (corresp_list does) before touching them on another stream, and run follow-up work that should stay
+        overlapped under `with torch.cuda.stream(engine.side_stream)`."""
         self.extractor, self.bank = extractor, bank
+        self.overlap_matching = overlap_matching
+        self._side = None
         self.cell = grid_cell_size
         self.top_n, self.top_k = top_n_templates, top_k_buddies
         self.tie_order = tie_order
@@ -126,8 +134,27 @@ class FoundPoseEngine:
             gh, gw = self.extractor.num_patches
             D = fmap.shape[-1]
             raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
-        feats = self._project(raw, counts, det_obj)
-        return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+        if not self.overlap_matching:
+            feats = self._project(raw, counts, det_obj)
+            return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+        main, side = torch.cuda.current_stream(), self.side_stream
+        produced = torch.cuda.Event()
+        produced.record(main)
+        with torch.cuda.stream(side):
+            side.wait_event(produced)
+            for t in (raw, q_pts, q_img):       # allocated on the caller's stream, consumed here
+                t.record_stream(side)
+            feats = self._project(raw, counts, det_obj)
+            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            res.ready = torch.cuda.Event()
+            res.ready.record(side)
+        return res
+
+    @property
+    def side_stream(self) -> torch.cuda.Stream:
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        return self._side
 
     def infer_detections(self, image_hwc: torch.Tensor, masks_modal: torch.Tensor, boxes_amodal, camera_c2w,
                          crop_size, crop_rel_pad: float, det_obj: Optional[Sequence[int]] = None, keep_debug: bool = False):

@@ -31,9 +31,17 @@ class MatchResult:
     coord_3d: torch.Tensor         # [B, n, K, 3] f32
     query_tfidf: Optional[torch.Tensor] = None  # [B, W] (debug)
     word_ids: Optional[torch.Tensor] = None     # [sumQ, k]
+    ready: Optional["torch.cuda.Event"] = None  # set when the matching ran on the engine's side stream (overlap_matching): the tensors are
+                                                # complete once this event has fired; wait() makes the current stream wait for it
+
+    def wait(self) -> "MatchResult":
+        if self.ready is not None:
+            torch.cuda.current_stream().wait_event(self.ready)
+        return self
 
     def corresp_list(self, b: int, debug: bool = False) -> List[Dict]:
         """The reference's List[Dict] for detection b (keys as in corresp_util.py:142-163)."""
+        self.wait()
         counts = self.counts[b].tolist()
         tids = self.template_ids[b].tolist()
         out = []

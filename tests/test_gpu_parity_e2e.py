@@ -99,3 +99,23 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch):
     for name in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d"):
         x, y = getattr(a, name), getattr(b, name)
         assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), name
+
+
+def test_overlap_matching_same_results():
+    """overlap_matching=True runs the matching stage on the engine's side stream beside the next batch's backbone: two
+    back-to-back batches give the tensors of the plain engine, once `ready` has fired."""
+    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    wl = workload.build_planted_workload(ex32, 8, 518, 1, 200, seed=5, crop_seed=1)
+    del ex32
+    bank = DeviceBank(wl.repres)
+    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    plain = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
+    over = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch", overlap_matching=True)
+    want = [plain.infer_batch(wl.crops[i:i + 4], wl.masks[i:i + 4], wl.det_obj[i:i + 4]) for i in (0, 4)]
+    got = [over.infer_batch(wl.crops[i:i + 4], wl.masks[i:i + 4], wl.det_obj[i:i + 4]) for i in (0, 4)]   # second forward enqueued beside the first matching
+    for a, b in zip(got, want):
+        assert a.ready is not None
+        a.wait()
+        for name in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d"):
+            x, y = getattr(a, name), getattr(b, name)
+            assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), name
