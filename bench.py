@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the ViT forward as one hipGraph (measured: no gain, the step is GPU-bound: 34.51 vs 34.44 ms)")
     ap.add_argument("--no-token-select", action="store_true",
                     help="run the hooked block on every token (default: only on the patch tokens the query points sample; same outputs bit for bit)")
+    ap.add_argument("--mask", default="disc", choices=["disc", "full"],
+                    help="detection masks: the centred disc of radius 0.35 S (SURVEY 8d, the headline) or the full crop (worst case: every patch is a query point)")
     ap.add_argument("--overlap", action="store_true", help="matching of batch i on a second stream beside the backbone of batch i+1 (engine overlap_matching; measured +0.3...0.8 %%, not the default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
@@ -111,7 +113,9 @@ def main():
     B = args.batch
     # ---- planted workload: the fp32 mode of the library produces the features that are planted (the reference's arithmetic)
     ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to(dev)
-    wl = workload.build_planted_workload(ex32, B, args.size, args.objects, args.templates, 256, 2048, seed=7, crop_seed=rank)
+    full_mask = torch.ones(args.size, args.size, dtype=torch.uint8) if args.mask == "full" else None
+    wl = workload.build_planted_workload(ex32, B, args.size, args.objects, args.templates, 256, 2048, seed=7, crop_seed=rank, mask=full_mask,
+                                         words_per_texture=1 if args.mask == "full" else workload.WORDS_PER_TEXTURE)
     bank = DeviceBank(wl.repres, device=dev)
     images, masks, det_obj = wl.crops, wl.masks, wl.det_obj     # inputs resident in HBM before timing
     extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
@@ -257,7 +261,7 @@ def main():
                                              "fp32 features sit with graded noise in 5 consecutive templates, the rest are random texture sets; words = 3 instances per texture)",
             "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block" + (", the hooked block on the sampled tokens only" if select_on else "") + "), "
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
-                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, disc mask Q={int(masks[0, 7::14, 7::14].sum())}, "
+                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, {args.mask} mask Q={int(masks[0, 7::14, 7::14].sum())}, "
                                    f"tie order '{args.tie_order}'" + (" (the reference's torch.topk order, replayed on the device)" if args.tie_order == "torch" else ""),
                        "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step",
                        "tie_order": args.tie_order},

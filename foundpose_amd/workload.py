@@ -89,11 +89,12 @@ def query_features(extractor, crops: torch.Tensor, masks: torch.Tensor, cell: fl
 
 def build_planted_workload(extractor, batch: int, size: int, num_objects: int, templates_per_object: int, feat_dim: int = 256,
                            num_words: int = 2048, seed: int = 0, crop_seed: int = 0, noise: Sequence[float] = PLANT_NOISE,
-                           patch_frac: Sequence[float] = PLANT_PATCHES, mask: Optional[torch.Tensor] = None) -> PlantedWorkload:
+                           patch_frac: Sequence[float] = PLANT_PATCHES, mask: Optional[torch.Tensor] = None,
+                           words_per_texture: int = WORDS_PER_TEXTURE) -> PlantedWorkload:
     """`extractor`: the extractor whose features are planted (use precision="fp32": the reference's arithmetic)."""
     dev = torch.device("cuda", torch.cuda.current_device())
     m = synthetic.make_disc_mask(size) if mask is None else mask
-    n_tex = num_words // WORDS_PER_TEXTURE
+    n_tex = num_words // words_per_texture   # (a mask with more patches than num_words / 3 needs fewer instance words per texture)
     crops_h, tex = synthetic.make_dictionary_crops(batch, size, m, n_tex, extractor.patch_size, seed=crop_seed)
     crops = crops_h.to(dev)
     masks = m.unsqueeze(0).repeat(batch, 1, 1).to(dev)
@@ -132,13 +133,13 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
     first_of = torch.full((n_tex,), -1, dtype=torch.int64, device=dev)
     first_of[st[start]] = seen_rows
     have = first_of >= 0
-    for r in range(WORDS_PER_TEXTURE):
+    for r in range(words_per_texture):
         rows_r = order[rank == r]
         w_r = words[r * n_tex:(r + 1) * n_tex]
         w_r[have] = qf[first_of[have]] + 0.02 * sigma * torch.randn(int(have.sum()), feat_dim, generator=gd, device=dev)
         w_r[q_tex[rows_r]] = qf[rows_r]
     words = words.contiguous()
-    real_words = torch.cat([words[r * n_tex:(r + 1) * n_tex][have] for r in range(WORDS_PER_TEXTURE)])  # without the filler
+    real_words = torch.cat([words[r * n_tex:(r + 1) * n_tex][have] for r in range(words_per_texture)])  # without the filler
 
     K = torch.tensor([[1.2 * size, 0.0, size / 2.0], [0.0, 1.2 * size, size / 2.0], [0.0, 0.0, 1.0]], dtype=torch.float64)
     R = _random_rotations(batch, g)
