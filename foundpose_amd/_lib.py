@@ -106,6 +106,11 @@ def cosine_scratch_floats(num_det: int, max_templates: int) -> int:
     return 2 * num_det * max_templates + 17 * num_det + 2
 
 
+def cyclic_scratch_bytes(pairs: int, q_max: int, p_max: int) -> int:
+    """FP_CYCLIC_SCRATCH_BYTES of include/foundpose_amd.h."""
+    return 8 * pairs * (((p_max + 127) // 128) * q_max + ((q_max + 127) // 128) * p_max)
+
+
 def exported_symbols():
     return sorted(list(_PROTOS) + ["fp_last_error"])
 

@@ -135,21 +135,23 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   FP_REQUIRE(q_max >= 1 && p_max >= 1 && n_slots >= 1, "fp_cyclic_buddies: bad sizes");
   const int pairs = num_det * n_slots;
   if (pairs == 0) return FP_OK;
+  // partial nearest-neighbour tables, one slice per distance tile (no atomics, no preset): [pairs, col tiles, q_max] + [pairs, row tiles, p_max]
+  const int row_parts = (p_max + 127) / 128, col_parts = (q_max + 127) / 128;
   unsigned long long* row_best = reinterpret_cast<unsigned long long*>(scratch);
-  unsigned long long* col_best = row_best + (size_t)pairs * q_max;
-  HIP_TRY(hipMemsetAsync(row_best, 0xFF, (size_t)pairs * (q_max + p_max) * 8, ST(stream)), "fp_cyclic_buddies: memset");
+  unsigned long long* col_best = row_best + (size_t)pairs * row_parts * q_max;
   F32TileArgs a = zero_tile_args();
   a.A = query_feats; a.lda = d; a.B = bank_feats; a.ldb = d; a.K = d;
   a.a_seg_off = q_off; a.pair_a_div = n_slots;
   a.b_seg_off = tpl_off; a.pair_b_seg = tpl_ids;
   a.a_sqnorm = query_sqnorm; a.b_sqnorm = bank_sqnorm;
-  a.row_best = row_best; a.row_stride = q_max; a.col_best = col_best; a.col_stride = p_max;
+  a.row_best = row_best; a.row_stride = q_max; a.col_best = col_best; a.col_stride = p_max; a.best_parts = 1;
   TRY(f32_tile_launch(F32_EPI_DIST_ARGMIN, a, q_max, p_max, pairs, ST(stream)));
   CyclicArgs c;
   memset(&c, 0, sizeof(c));
   c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_off = tpl_off; c.feat_base = feat_base;
   c.points = query_points; c.vertices = vertices;
   c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max;
+  c.row_parts = row_parts; c.col_parts = col_parts;
   c.n_slots = n_slots; c.top_k = top_k; c.k_max = k_max; c.q_max = q_max; c.tie_mode = tie_mode;
   c.out_count = out_count; c.out_q_ids = out_q_ids; c.out_feat_ids = out_feat_ids; c.out_dists = out_dists;
   c.out_conf = out_conf; c.out_coord_2d = out_coord_2d; c.out_coord_3d = out_coord_3d;

@@ -328,7 +328,13 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
 #pragma unroll
       for (int w = 1; w < 4; ++w) v = sl[w * 128] < v ? sl[w * 128] : v;
       unsigned long long* dst = side ? a.col_best : a.row_best;
-      if (dst && v != ~0ull) atomicMin(dst + (size_t)pair * (side ? a.col_stride : a.row_stride) + (side ? n0 : m0) + x, v);
+      if (dst && a.best_parts) {  // this tile's slice of the partial tables: plain coalesced stores, nothing to preset, no contention
+        const size_t part = side ? (size_t)pair * gridDim.y + blockIdx.y : (size_t)pair * gridDim.x + blockIdx.x;
+        const int stride = side ? a.col_stride : a.row_stride, pos = (side ? n0 : m0) + x;
+        if (pos < stride) dst[part * stride + pos] = v;
+      } else if (dst && v != ~0ull) {
+        atomicMin(dst + (size_t)pair * (side ? a.col_stride : a.row_stride) + (side ? n0 : m0) + x, v);
+      }
     }
   } else if constexpr (EPI == F32_EPI_DIST_TOPK) {
     // k nearest columns of every row INSIDE this tile (k = a.row_stride <= 8): the 128 x 128 distances go to LDS (free after

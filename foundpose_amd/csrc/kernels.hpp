@@ -29,6 +29,10 @@ struct F32TileArgs {
   const float* a_sqnorm; const float* b_sqnorm;
   unsigned long long* row_best; int row_stride;
   unsigned long long* col_best; int col_stride;
+  // DIST_ARGMIN: 0 = atomicMin into row_best[pair * row_stride + row] / col_best[pair * col_stride + col] (tables preset to ~0);
+  // 1 = every tile stores its own slice, no atomics, no preset: row_best[(pair * grid.x + tile_n) * row_stride + row] and
+  // col_best[(pair * grid.y + tile_m) * col_stride + col]; the reader takes the min over the live tiles
+  int best_parts;
   const float* bias; const float* gamma;
   const float* pos; int tok_np, tok_n, tok_skip;
 };
@@ -43,8 +47,9 @@ struct CyclicArgs {
   const int* feat_base;    // [B] first feature row of the detection's object (ids are reported object-local)
   const float* points;     // [sumQ, 2]
   const float* vertices;   // [N_f, 3]
-  const unsigned long long* row_best; int row_stride;  // [pairs, row_stride] (d2, template patch)
-  const unsigned long long* col_best; int col_stride;  // [pairs, col_stride] (d2, query patch)
+  const unsigned long long* row_best; int row_stride;  // [pairs, row_parts, row_stride] (d2, template patch): per column tile of the template
+  const unsigned long long* col_best; int col_stride;  // [pairs, col_parts, col_stride] (d2, query patch): per row tile of the queries
+  int row_parts, col_parts;
   int n_slots, top_k, k_max, q_max;
   int tie_mode;            // 0 canonical (value, index); 1 torch.topk's CPU tie order (stl_order.hpp)
   int* out_count;          // [pairs]

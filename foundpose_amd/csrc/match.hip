@@ -734,15 +734,28 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   }
   if (!live) return;
   const int f0 = a.tpl_off[tpl];
-  const unsigned long long* rb = a.row_best + (size_t)pair * a.row_stride;
-  const unsigned long long* cb = a.col_best + (size_t)pair * a.col_stride;
+  // the distance tiles left one slice of nearest-neighbour keys per tile: the nearest over the whole template / crop is the
+  // smallest key over the live tiles (keys order by distance, then index: the same winner an atomicMin would have kept)
+  const int np = (a.tpl_off[tpl + 1] - f0 + 127) / 128, nq = (Q + 127) / 128;
+  const unsigned long long* rb = a.row_best + (size_t)pair * a.row_parts * a.row_stride;
+  const unsigned long long* cb = a.col_best + (size_t)pair * a.col_parts * a.col_stride;
   const float* pts = a.points + (size_t)q0 * 2;
 
   for (int i = tid; i < 2048; i += 256) {
     unsigned long long key = ~0ull;
     if (i < Q) {
-      const int o = (int)(rb[i] & 0xffffffffu);        // query -> nearest template patch
-      const int c = (int)(cb[o] & 0xffffffffu);        // that patch -> nearest query patch
+      unsigned long long kr = rb[i];
+      for (int t = 1; t < np; ++t) {
+        const unsigned long long v = rb[(size_t)t * a.row_stride + i];
+        kr = v < kr ? v : kr;
+      }
+      const int o = (int)(kr & 0xffffffffu);           // query -> nearest template patch
+      unsigned long long kc = cb[o];
+      for (int t = 1; t < nq; ++t) {
+        const unsigned long long v = cb[(size_t)t * a.col_stride + o];
+        kc = v < kc ? v : kc;
+      }
+      const int c = (int)(kc & 0xffffffffu);           // that patch -> nearest query patch
       q2o_s[i] = o;
       key = pack_dist_idx(point_dist(pts[2 * i], pts[2 * i + 1], pts[2 * c], pts[2 * c + 1]), (unsigned)i);
     }

@@ -12,7 +12,7 @@ from typing import Dict, List, Optional, Sequence
 import torch
 
 from . import ops
-from ._lib import call, cosine_scratch_floats, ptr, stream, require_cuda
+from ._lib import call, cosine_scratch_floats, cyclic_scratch_bytes, ptr, stream, require_cuda
 from .bank import DeviceBank
 
 
@@ -148,7 +148,7 @@ def match_batch(
     # ---- cyclic best buddies against the retrieved templates + correspondence assembly (the kernel pads its records itself)
     t_glob = torch.where(t_ids >= 0, t_ids + tpl_base[:, None], t_ids).contiguous()
     pairs = B * n
-    scratch = torch.empty(pairs * (q_max + bank.p_max), dtype=torch.int64, device=dev)
+    scratch = torch.empty(cyclic_scratch_bytes(pairs, q_max, bank.p_max) // 8, dtype=torch.int64, device=dev)
     counts = torch.empty(B, n, dtype=torch.int32, device=dev)
     q_ids = torch.empty(B, n, K, dtype=torch.int32, device=dev)
     feat_ids = torch.empty(B, n, K, dtype=torch.int32, device=dev)

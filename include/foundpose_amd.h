@@ -85,11 +85,14 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
  *   bank_feats [N_f,d] sorted by template, bank_sqnorm [N_f], tpl_off [T_total+1], vertices [N_f,3]
  *   tpl_ids [B*n_slots] GLOBAL template ids (object's first template + local id), <0 = empty slot
  *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
- *   scratch: B*n_slots*(q_max + p_max)*8 bytes
+ *   scratch: FP_CYCLIC_SCRATCH_BYTES(B * n_slots, q_max, p_max) bytes (one slice of nearest-neighbour keys per 128 x 128
+ *   distance tile; nothing has to be preset)
  * outputs, padded to k_max >= top_k per (detection, slot): count, query ids, object feature ids (= the
  * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d.  tie_mode as in fp_cosine_topk: 1 makes
  * the order (and the choice among tied distances at the top_k boundary) identical to the reference's
  * torch.topk(-cycle_dists, k). */
+#define FP_CYCLIC_SCRATCH_BYTES(pairs, q_max, p_max) \
+  (8 * (size_t)(pairs) * ((size_t)(((p_max) + 127) / 128) * (size_t)(q_max) + (size_t)(((q_max) + 127) / 128) * (size_t)(p_max)))
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,

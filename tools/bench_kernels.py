@@ -99,7 +99,8 @@ def main():
         tpl_ids = torch.randint(0, T, (Bq, n_top), generator=torch.Generator().manual_seed(2)).to(torch.int32).to(dev)
         feat_base = torch.zeros(Bq, dtype=torch.int32, device=dev)
         p_max = int(pc.max())
-        scratch = torch.empty(Bq * n_top * (Q + p_max), dtype=torch.int64, device=dev)
+        from foundpose_amd._lib import cyclic_scratch_bytes
+        scratch = torch.empty(cyclic_scratch_bytes(Bq * n_top, Q, p_max) // 8, dtype=torch.int64, device=dev)
         o = dict(counts=torch.empty(Bq, n_top, dtype=torch.int32, device=dev), q_ids=torch.empty(Bq, n_top, K, dtype=torch.int32, device=dev),
                  f_ids=torch.empty(Bq, n_top, K, dtype=torch.int32, device=dev), dists=torch.empty(Bq, n_top, K, device=dev),
                  conf=torch.empty(Bq, n_top, K, device=dev), c2d=torch.empty(Bq, n_top, K, 2, device=dev), c3d=torch.empty(Bq, n_top, K, 3, device=dev))
