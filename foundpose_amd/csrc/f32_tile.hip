@@ -59,32 +59,41 @@ FP_DEVICE void store_tile(const Frag& f, float* __restrict__ lds, int tid) {
 // image keeping KMAX sorted (d2, column) keys, one shuffle merges the halves, thread `half == 0` emits k keys.  Columns past
 // the live part of the tile are never turned into keys.
 template <int KMAX>
+FP_DEVICE void topk_insert(unsigned long long (&best)[KMAX], unsigned long long key) {
+#pragma unroll
+  for (int s = 0; s < KMAX; ++s) {  // one compare per slot: the smaller key stays, the larger moves on
+    const bool lt = key < best[s];
+    const unsigned long long lo = lt ? key : best[s], hi = lt ? best[s] : key;
+    best[s] = lo;
+    key = hi;
+  }
+}
+
+template <int KMAX>
 FP_DEVICE void tile_topk_rows(const float* dt, int k, int tid, int n0, int live_n, bool row_live, unsigned long long* out) {
   const int row = tid >> 1, half = tid & 1;
-  unsigned long long best[KMAX];
+  // two independent sorted lists per thread (even / odd steps of the scan): the insertion is a chain of dependent
+  // compare-selects, two chains in flight hide each other's latency; they merge at the end
+  unsigned long long best[KMAX], bestb[KMAX];
 #pragma unroll
-  for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
-  auto insert = [&](unsigned long long key) {
-#pragma unroll
-    for (int s = 0; s < KMAX; ++s) {
-      const unsigned long long lo = key < best[s] ? key : best[s];
-      key = key < best[s] ? best[s] : key;
-      best[s] = lo;
-    }
-  };
+  for (int s = 0; s < KMAX; ++s) { best[s] = ~0ull; bestb[s] = ~0ull; }
   if (half * 64 < live_n) {  // a half with no live column keeps its empty list
-    for (int c = 0; c < 64; ++c) {
-      const int jl = half * 64 + ((c + 32 * half) & 63);  // the halves walk 32 columns apart: different LDS banks
-      const float d2 = dt[row * LDS_STRIDE + jl];
-      insert(jl >= live_n ? ~0ull : pack_dist_idx(d2, (unsigned)(n0 + jl)));
+    for (int c = 0; c < 64; c += 2) {
+      const int ja = half * 64 + ((c + 32 * half) & 63), jb = half * 64 + ((c + 1 + 32 * half) & 63);  // the halves walk 32 columns apart: different LDS banks
+      const float da = dt[row * LDS_STRIDE + ja], db = dt[row * LDS_STRIDE + jb];
+      topk_insert<KMAX>(best, ja >= live_n ? ~0ull : pack_dist_idx(da, (unsigned)(n0 + ja)));
+      topk_insert<KMAX>(bestb, jb >= live_n ? ~0ull : pack_dist_idx(db, (unsigned)(n0 + jb)));
     }
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)
+      if (s < k) topk_insert<KMAX>(best, bestb[s]);
   }
   unsigned long long other[KMAX];
 #pragma unroll
   for (int s = 0; s < KMAX; ++s) other[s] = __shfl_xor(best[s], 1, 64);
 #pragma unroll
   for (int s = 0; s < KMAX; ++s)
-    if (s < k) insert(other[s]);
+    if (s < k) topk_insert<KMAX>(best, other[s]);
   if (half == 0 && row_live) {
 #pragma unroll
     for (int s = 0; s < KMAX; ++s)
@@ -291,12 +300,15 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
 #pragma unroll
       for (int step = 0; step < 4; ++step) {
         const int half = 8 >> step;            // rows kept after this step
-        const bool up = (l31 >> (4 - step)) & 1;
+        // keep / send by a masked xor swap on the VALUES: written as `up ? rbest[x + half] : rbest[x]` the compiler turns the
+        // pair of selects into one dynamically indexed read of the register array -- a 16-way v_cmp_eq / v_cndmask chain per
+        // access, 2350 v_cndmask in the kernel and 59 of the epilogue's 86 us
+        const unsigned long long swap = ((l31 >> (4 - step)) & 1) ? ~0ull : 0ull;
 #pragma unroll
         for (int x = 0; x < 8; ++x) {
           if (x < half) {
-            const unsigned long long keep = up ? rbest[x + half] : rbest[x];
-            const unsigned long long send = up ? rbest[x] : rbest[x + half];
+            const unsigned long long d = (rbest[x] ^ rbest[x + half]) & swap;
+            const unsigned long long keep = rbest[x] ^ d, send = rbest[x + half] ^ d;
             const unsigned long long got = __shfl_xor(send, 16 >> step, 64);
             rbest[x] = got < keep ? got : keep;
           }
