@@ -225,60 +225,71 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
 
 // images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
 // column = c*P*P + py*P + px (the flattening of the conv weight [D,3,P,P]); columns >= 3*P*P are zero.
-// A patch row is 14 pixels wide: whichever side a thread walks, the other side is touched in 28/56-byte pieces (one
-// thread per element: 120 us; one thread per 14-pixel run: 117 us -- the access pattern, not the instruction count, is the
-// cost).  So one workgroup takes one ROW OF PATCHES (image b, patch row gy): the 3 x P image rows it covers are read as
-// whole rows (coalesced), normalised once, and parked in LDS; the gw output rows then leave as whole 16-byte chunks.
+// A patch row is 14 pixels wide: whichever side a thread walks, the other side is touched in 28/56-byte pieces.  So one
+// workgroup takes one ROW OF PATCHES (image b, patch row gy) and builds it in LDS in OUTPUT layout: a wave reads whole image
+// rows (coalesced, two rows = 18 loads in flight), normalises, and drops each pixel at [patch gx][c*P*P + py*P + px] through
+// a per-workgroup x -> (gx, px) table (no per-pixel division); the gw output rows then leave as whole 16-byte chunks.
+// (History: one thread per element 120 us, one per 14-pixel run 117 us, a strip in input layout with index divisions in
+//  both phases 92 us.)
 template <typename T>
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* strip = reinterpret_cast<T*>(smem_raw);  // [3 * P][W] normalised pixels of this row of patches
-  const int gw = W / P, gh = H / P;
-  const int b = blockIdx.x / gh, gy = blockIdx.x - b * gh, tid = threadIdx.x;
-  // (eight loads in flight per thread before the first LDS store: one load per iteration made the strip load a chain of
-  // 126 HBM round trips per workgroup -- 117 us for the launch, whatever the access pattern)
-  const int total = 3 * P * W;
+  constexpr int V = 16 / sizeof(T);  // elements per 16-byte chunk
+  const int gw = W / P, gh = H / P, lds_ld = ld + V;  // + one chunk per row: the patches' rows start in different banks
+  T* tile = reinterpret_cast<T*>(smem_raw);                                 // [gw][lds_ld]
+  unsigned short* xtab = reinterpret_cast<unsigned short*>(tile + (size_t)gw * lds_ld);  // [W]: gx * lds_ld is too wide for 16 bits: (gx << 8) | px
+  const int b = blockIdx.x / gh, gy = blockIdx.x - b * gh, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ncols = 3 * P * P;
+  for (int x = tid; x < W; x += 256) {
+    const int gx = x / P;
+    xtab[x] = (unsigned short)((gx << 8) | (x - gx * P));
+  }
+  const int pad = ld - ncols;  // zero columns behind the pixels
+  for (int id = tid; id < gw * pad; id += 256) {
+    const int gx = id / pad;
+    tile[(size_t)gx * lds_ld + ncols + (id - gx * pad)] = (T)0.f;
+  }
+  __syncthreads();
   const float* img_b = img + (size_t)b * 3 * H * W;
-  for (int base = tid; base < total; base += 256 * 8) {
-    float v[8];
+  constexpr int XI = 9;  // 64-lane pieces of an image row held at once (W <= 576; wider rows loop)
+  for (int r0 = wave; r0 < 3 * P; r0 += 8) {
+    float v[2][XI];
+    for (int xb = 0; xb < W; xb += 64 * XI) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256;
-      v[u] = 0.f;
-      if (idx < total) {
-        const int r = idx / W, x = idx - r * W, c = r / P, py = r - c * P;
-        v[u] = img_b[((size_t)c * H + gy * P + py) * W + x];
+      for (int h = 0; h < 2; ++h) {
+        const int r = r0 + 4 * h;
+        const int c = r / P, py = r - c * P;  // wave-uniform
+        const float* src = img_b + ((size_t)c * H + gy * P + py) * W;
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const int x = xb + lane + 64 * i;
+          v[h][i] = (r < 3 * P && x < W) ? src[x] : 0.f;
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int idx = base + u * 256;
-      if (idx < total) {
-        const int c = idx / (W * P);
+      for (int h = 0; h < 2; ++h) {
+        const int r = r0 + 4 * h;
+        if (r >= 3 * P) continue;
+        const int c = r / P;
         const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
         const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
-        strip[idx] = (T)((v[u] - mean) / stdv);  // T.Normalize: sub then div
+#pragma unroll
+        for (int i = 0; i < XI; ++i) {
+          const int x = xb + lane + 64 * i;
+          if (x < W) {
+            const unsigned t = xtab[x];
+            tile[(size_t)(t >> 8) * lds_ld + r * P + (t & 255u)] = (T)((v[h][i] - mean) / stdv);  // T.Normalize: sub then div
+          }
+        }
       }
     }
   }
   __syncthreads();
-  constexpr int V = 16 / sizeof(T);  // elements per 16-byte store
-  const int chunks = ld / V, ncols = 3 * P * P;
-  for (int id = tid; id < gw * chunks; id += 256) {
-    const int gx = id / chunks, ch = id - gx * chunks;
-    T v[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) {
-      const int col = ch * V + e;
-      T val = (T)0.f;
-      if (col < ncols) {
-        const int r = col / P, px = col - r * P;  // r = c * P + py
-        val = strip[r * W + gx * P + px];
-      }
-      v[e] = val;
-    }
-    *reinterpret_cast<uint4*>(out + ((size_t)(b * gh + gy) * gw + gx) * ld + ch * V) = *reinterpret_cast<const uint4*>(v);
-  }
+  const int chunks = ld / V;
+  T* out_row = out + (size_t)(b * gh + gy) * gw * ld;
+  for (int gx = wave; gx < gw; gx += 4)
+    for (int ch = lane; ch < chunks; ch += 64)
+      *reinterpret_cast<uint4*>(out_row + (size_t)gx * ld + ch * V) = *reinterpret_cast<const uint4*>(tile + (size_t)gx * lds_ld + ch * V);
 }
 
 // Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
@@ -509,9 +520,10 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
   FP_REQUIRE(ld_out >= 3 * patch * patch, "patchify: ld_out too small");
   const unsigned grid = (unsigned)(batch * (height / patch));  // one workgroup per row of patches
   if (grid == 0) return FP_OK;
-  const size_t esz = out_dtype == FP_DTYPE_BF16 ? 2 : 4, lds = (size_t)3 * patch * width * esz;
+  const size_t esz = out_dtype == FP_DTYPE_BF16 ? 2 : 4;
   FP_REQUIRE(ld_out % (16 / esz) == 0, "patchify: ld_out must keep 16-byte rows");
-  FP_REQUIRE(lds <= 160 * 1024, "patchify: a row of patches (3 x %d x %d pixels) does not fit LDS", patch, width);
+  const size_t lds = (size_t)(width / patch) * (ld_out + 16 / esz) * esz + (size_t)width * 2;  // the row of patches in output layout + the x table
+  FP_REQUIRE(lds <= 160 * 1024 && patch <= 255 && width / patch <= 255, "patchify: a row of patches (%d x %d columns) does not fit LDS", width / patch, ld_out);
   static FpDeviceOnce attr_b, attr_f;
   fp_allow_dynamic_lds(attr_b, &patchify_kernel<__bf16>, 160 * 1024);
   fp_allow_dynamic_lds(attr_f, &patchify_kernel<float>, 160 * 1024);
