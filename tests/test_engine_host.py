@@ -1,0 +1,40 @@
+"""Host-side logic of the batched engine (no GPU): the token selection's cell table must cover every bilinear tap the
+sampling kernel can touch -- fp_vit_sample_features_selected returns NaN for a tap outside the selection, so the cover
+property is what makes the selected path equal to the full one for ANY grid geometry, not only the tested ones."""
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd.engine import FoundPoseEngine
+
+
+class _Ext:  # the two attributes _cells9 reads
+    def __init__(self, patch_size):
+        self.patch_size = patch_size
+
+
+def _taps(px, py, W, H, gw, gh):
+    """The four taps of ln_sample_kernel / sample_bilinear_kernel for a point, in its float32 arithmetic (vit.hip)."""
+    f = np.float32
+    sx, sy = f(2.0) / f(W), f(2.0) / f(H)
+    u1 = (sx * f(px) - f(1.0)) + f(1.0)
+    v1 = (sy * f(py) - f(1.0)) + f(1.0)
+    ix = f(np.float64(u1) * np.float64(f(gw) / f(2.0)) - 0.5)   # fma: one rounding
+    iy = f(np.float64(v1) * np.float64(f(gh) / f(2.0)) - 0.5)
+    x0, y0 = int(np.floor(ix)), int(np.floor(iy))
+    return [(x, y) for y in (y0, y0 + 1) for x in (x0, x0 + 1) if 0 <= x < gw and 0 <= y < gh]
+
+
+@pytest.mark.parametrize("size,cell,patch", [(518, 14.0, 14), (224, 14.0, 14), (420, 14.0, 14), (210, 10.0, 14), (126, 7.0, 14), (518, 9.25, 14), (224, 16.0, 16)])
+def test_cells9_cover_every_sampling_tap(size, cell, patch):
+    eng = FoundPoseEngine(_Ext(patch), None, grid_cell_size=cell)
+    W = H = size
+    gw = gh = size // patch
+    pts = eng._grid(W, H, torch.device("cpu"))[0].numpy()
+    cells = eng._cells9(W, H, torch.device("cpu")).view(-1, 9).numpy()
+    assert cells.shape[0] == pts.shape[0]
+    assert cells.min() >= 0 and cells.max() <= gw * gh          # gw * gh = "outside the map"
+    for g in range(pts.shape[0]):
+        have = set(int(c) for c in cells[g] if c < gw * gh)
+        for (x, y) in _taps(pts[g, 0], pts[g, 1], W, H, gw, gh):
+            assert y * gw + x in have, (size, cell, g, pts[g], x, y)
