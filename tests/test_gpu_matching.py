@@ -239,6 +239,32 @@ def test_torch_order_replay_only_where_ties_exist(T, W):
             assert torch.equal(sc[0].cpu(), rv), (name, T, W, mode)
 
 
+@pytest.mark.parametrize("n_top", [1, 6, 7, 8, 12])
+def test_torch_order_top_n_sizes_vs_torch_topk(n_top):
+    """n_top up to 7 takes the candidate path with n_top + 1 keys per workgroup (8 = the candidate list's width), 8 and above
+    the full replay from the score matrix: both must equal torch.topk on the CPU copy of the scores, with duplicated
+    templates (ties) in the bank."""
+    from foundpose_amd import ops
+    from foundpose_amd._lib import call, ptr, stream, cosine_scratch_floats
+    rng = np.random.default_rng(n_top)
+    T, W, Bq = 1500, 2048, 5
+    bank = rng.random((T, W)).astype(np.float32)
+    bank[700:760] = bank[:60]                       # sixty duplicated templates: exact score ties
+    q = rng.random((Bq, W)).astype(np.float32)
+    q[1] = bank[10]                                 # its best score is shared by templates 10 and 710
+    bank_n, q_n = ops.normalize_rows(cu(bank)), ops.normalize_rows(cu(q))
+    seg, tpl, nt = cu(np.array([0, Bq], np.int32)), cu(np.array([0, T], np.int32)), cu(np.full(Bq, T, np.int32))
+    sims = torch.empty(cosine_scratch_floats(Bq, T), device="cuda")
+    sc = torch.empty(Bq, n_top, device="cuda")
+    ids = torch.empty(Bq, n_top, dtype=torch.int32, device="cuda")
+    call("fp_cosine_topk", ptr(q_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(tpl), 1, T, W, n_top, ptr(sims), ptr(sc), ptr(ids), 1, stream())
+    s_cpu = sims[:Bq * T].reshape(Bq, T).cpu()
+    for b in range(Bq):
+        rv, ri = torch.topk(s_cpu[b], n_top, sorted=True)
+        assert ids[b].cpu().tolist() == ri.tolist(), (n_top, b)
+        assert torch.equal(sc[b].cpu(), rv), (n_top, b)
+
+
 @pytest.mark.parametrize("name", sorted(MATCH_CASES))
 def test_establish_correspondences_vs_oracle_and_reference(name):
     c, g, repre, pts, feats = match_case_inputs(name)

@@ -571,9 +571,10 @@ def test_query_select_equals_filter_points_by_mask(dtype):
     from foundpose_amd.engine import FoundPoseEngine
     ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=1_norm=1", seed=8, precision="bf16").to("cuda")
     g = torch.Generator().manual_seed(3)
-    for size, cell in ((224, 14.0), (210, 10.0), (126, 7.0)):
+    for size, cell in ((224, 14.0), (210, 10.0), (126, 7.0), ((280, 168), 14.0)):   # the last one: width != height
         B = 5
-        m = (torch.rand(B, size, size, generator=g) > 0.6)
+        size_wh = size if isinstance(size, tuple) else (size, size)
+        m = (torch.rand(B, size_wh[1], size_wh[0], generator=g) > 0.6)
         m[1] = False
         m[2] = True
         m[3] = False
@@ -582,7 +583,7 @@ def test_query_select_equals_filter_points_by_mask(dtype):
         masks = m.to(dtype).cuda()
         eng = FoundPoseEngine(ex, None, grid_cell_size=cell)
         pts, img, counts = eng.query_points(masks)
-        grid = feature_util.generate_grid_points((size, size), cell).cuda()
+        grid = feature_util.generate_grid_points(size_wh, cell).cuda()
         off = 0
         for b in range(B):
             ref = feature_util.filter_points_by_mask(grid, m[b].cuda())
