@@ -29,6 +29,21 @@ struct Elem {
 // torch's comparator for largest=True: NaN sorts first, otherwise by value; the index never participates.
 FP_HD bool gt(const Elem& x, const Elem& y) { return ((x.v != x.v) && !(y.v != y.v)) || (x.v > y.v); }
 
+// The equivalence class of a value under `gt` as an integer that DESCENDS with the value: all NaNs share the smallest key
+// (they sort first), -0 and +0 share one, otherwise the usual order-preserving map of the float bits, inverted.
+FP_HD unsigned class_key(const Elem& x) {
+  if (x.v != x.v) return 0u;
+  const float f = x.v == 0.f ? 0.f : x.v;
+  unsigned b;
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__CUDA_ARCH__)
+  b = __float_as_uint(f);
+#else
+  __builtin_memcpy(&b, &f, 4);
+#endif
+  b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);  // ascending with the value; never 0xffffffff for a non-NaN
+  return ~b;                                        // descending; > 0 for every non-NaN (+inf -> 0x007fffff)
+}
+
 FP_HD void swap_(Elem& a, Elem& b) {
   const Elem t = a;
   a = b;

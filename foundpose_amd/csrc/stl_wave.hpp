@@ -25,8 +25,63 @@ using stl_order::gt;
 
 __device__ __forceinline__ void wsync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
+// position of the n-th (0-based) set bit of m, counted from bit 0; n < popcount(m)
+__device__ __forceinline__ int select_bit(unsigned long long m, int n) {
+  int pos = 0;
+#pragma unroll
+  for (int w = 32; w >= 1; w >>= 1) {
+    const int c = __popcll((m >> pos) & ((1ull << w) - 1ull));
+    if (n >= c) {
+      n -= c;
+      pos += w;
+    }
+  }
+  return pos;
+}
+
+// The same partition for a range whose scanned part a[lo + 1, hi) fits one chunk of 64 (most calls of an introsort over a
+// few hundred elements): everything stays in registers -- the median-of-3 from four broadcast reads, the stopper ranks from
+// two ballots, the partner of a swapped stopper by selecting the matching set bit of the other ballot, the exchange by one
+// lane permute -- instead of rank tables in LDS and four dependent LDS round trips.
+__device__ inline int partition_pivot_small(Elem* a, int lo, int hi, int lane) {
+  const int mid = lo + (hi - lo) / 2;
+  const Elem e0 = a[lo], ex = a[lo + 1], ey = a[mid], ez = a[hi - 1];
+  int src;  // move_median_to_first_: whose element is swapped with a[lo]
+  if (gt(ex, ey)) src = gt(ey, ez) ? mid : (gt(ex, ez) ? hi - 1 : lo + 1);
+  else src = gt(ex, ez) ? lo + 1 : (gt(ey, ez) ? hi - 1 : mid);
+  const Elem piv = src == lo + 1 ? ex : (src == mid ? ey : ez);
+  const int i = lo + 1 + lane;
+  const bool in = i < hi;
+  Elem v = in ? a[i] : piv;
+  if (i == src) v = e0;  // the arrangement after the median swap
+  const bool fl = in && !gt(v, piv), fr = in && !gt(piv, v);
+  const unsigned long long bl = __ballot(fl), br = __ballot(fr);
+  const unsigned long long below = (1ull << lane) - 1ull;
+  const int n_l = __popcll(bl), n_r = __popcll(br), np = n_l < n_r ? n_l : n_r;
+  const int m_l = __popcll(bl & below);                       // rank among the left stoppers, from the left
+  const int m_r = __popcll(br & ~below & ~(1ull << lane));    // rank among the right stoppers, from the right
+  int partner = lane;
+  bool sw_l = false;
+  if (fl && m_l < np) {
+    partner = select_bit(br, n_r - 1 - m_l);
+    sw_l = lane < partner;
+  }
+  const int s = __popcll(__ballot(sw_l));  // swapped pairs: the condition is monotone in the rank
+  if (!sw_l) partner = (fr && m_r < s) ? select_bit(bl, m_r) : lane;
+  Elem nv;
+  nv.v = __shfl(v.v, partner, 64);
+  nv.idx = __shfl(v.idx, partner, 64);
+  if (lane == 0) a[lo] = piv;
+  if (in) a[i] = nv;
+  wsync();
+  const int next_l = s < n_l ? lo + 1 + select_bit(bl, s) : 0x7fffffff;
+  const int last_r = s >= 1 ? lo + 1 + select_bit(br, n_r - s) : hi;
+  return next_l < last_r ? next_l : last_r;
+}
+
 // __unguarded_partition_pivot(first = lo, last = hi) on a[lo, hi), hi - lo > 3.  lpos / rpos: scratch for hi - lo ranks.
 __device__ inline int partition_pivot(Elem* a, int lo, int hi, unsigned short* lpos, unsigned short* rpos, int lane) {
+  if (hi - lo - 1 <= 64) return partition_pivot_small(a, lo, hi, lane);
   const int mid = lo + (hi - lo) / 2;
   if (lane == 0) stl_order::move_median_to_first_(a, lo, lo + 1, mid, hi - 1);
   wsync();
@@ -117,8 +172,45 @@ __device__ inline void sort(Elem* a, int first, int last, unsigned short* lpos, 
       f.last = cut;
     }
   }
-  // __final_insertion_sort == the stable sort of the current arrangement: place = #elements that precede
+  // __final_insertion_sort == the stable sort of the current arrangement: place = #elements that precede.  "u precedes v"
+  // (gt(u, v), or equivalent and earlier in the arrangement) is an order on (class of the value, position): the value's class as
+  // a descending integer key (all NaNs one class, first; -0 = +0) with the position below it makes one u64 per element, and
+  // place(i) = #{j : key_j < key_i} -- one LDS broadcast read and one 64-bit compare per pair instead of two float
+  // comparisons with NaN logic (the selection kernel spent a quarter of its time here).
   const int n = last - first;
+  unsigned long long* keys = reinterpret_cast<unsigned long long*>(tmp);  // n keys; the elements move through registers
+  constexpr int MAXC = 8;  // chunks of 64 a lane keeps in registers: n <= 512 here (k - 1 <= 511), else the two-pass form below
+  if (n <= 64 * MAXC) {
+    Elem mine[MAXC];
+    unsigned long long kmine[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = c * 64 + lane;
+      if (i < n) {
+        mine[c] = a[first + i];
+        kmine[c] = ((unsigned long long)stl_order::class_key(mine[c]) << 32) | (unsigned)i;
+        keys[i] = kmine[c];
+      }
+    }
+    wsync();
+    int place[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) place[c] = 0;
+    for (int j = 0; j < n; ++j) {
+      const unsigned long long kj = keys[j];  // same address on every lane: an LDS broadcast
+#pragma unroll
+      for (int c = 0; c < MAXC; ++c)
+        if (c * 64 < n) place[c] += kj < kmine[c] ? 1 : 0;
+    }
+    wsync();  // all reads of keys done before the elements overwrite... (keys alias tmp, not a)
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) {
+      const int i = c * 64 + lane;
+      if (i < n) a[first + place[c]] = mine[c];
+    }
+    wsync();
+    return;
+  }
   for (int i0 = 0; i0 < n; i0 += 64) {
     const int i = i0 + lane;
     if (i < n) {
