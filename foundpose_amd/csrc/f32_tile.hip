@@ -354,17 +354,24 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
     // and the tile emits k keys per row -- 24 B instead of the 512 B of the row's distances.  A merge over the n-tiles'
     // candidates finishes the row (launch_knn_merge).  Replaces "store [m, n] distances + k selection passes over them".
     float* dt = smem;  // [128][129]
+    // (all norm reads first: dt aliases the stage buffers in the compiler's eyes, a norm read after a dt store would wait for it)
+    float an_r[2][16], bn_c[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      bn_c[t] = nrm[128 + cb[t] + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) an_r[t][r] = nrm[rb[t] + (r & 3) + 8 * (r >> 2) + 4 * kh];
+    }
 #pragma unroll
     for (int tm = 0; tm < 2; ++tm)
 #pragma unroll
       for (int tn = 0; tn < 2; ++tn) {
         if (!(lm[tm] && ln[tn])) continue;
         const int jl = cb[tn] + l31;
-        const float bnj = nrm[128 + jl];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int il = rb[tm] + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          const float d2 = fmaf(-2.f, acc[tm][tn][r], nrm[il] + bnj);
+          const float d2 = fmaf(-2.f, acc[tm][tn][r], an_r[tm][r] + bn_c[tn]);
           dt[il * LDS_STRIDE + jl] = d2 < 0.f ? 0.f : d2;
         }
       }
