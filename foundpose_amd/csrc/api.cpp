@@ -321,7 +321,8 @@ int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int 
   memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
   a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads;
-  return attn_launch(a, dtype, ST(stream));
+  a.variant = (dtype >> 8) & 0xff;  // tuning / test bits: which bf16 work split runs (FP_ATTN_VARIANT_*)
+  return attn_launch(a, dtype & 0xff, ST(stream));
 }
 
 int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream) {

@@ -5,7 +5,7 @@
 //
 // bf16 kernels (flash-style, one pass over the keys, fp32 online softmax).  attn_bf16_w64_kernel (default: 64 queries
 // per wave, K/V tiles by LDS-DMA, see its header) and attn_bf16_kernel (32 queries per wave, register staging; kept as
-// the cross-check, FP_ATTN_W64=0) produce bit-identical results.  Common to both:
+// the cross-check, AttnArgs.variant = 1) produce bit-identical results.  Common to both:
 //   * block = (128 queries, head, image), 4 waves x 32 queries; K tile and V tile (64 keys x 64 d each, rows of the
 //     qkv buffer) staged through registers into LDS, next tile's loads in flight under the MFMAs, one barrier per tile
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (operands swapped so a lane owns ONE query's scores:
@@ -16,7 +16,6 @@
 //     kh*8 + 4r + j of column d) from an LDS image cut into 16-column blocks.  No pre-transposed V^T copy in HBM
 //     (92 MB per layer at the bench batch) and no transposing epilogue in the qkv GEMM.
 // fp32 kernel (parity mode): one thread per query, K/V rows broadcast from LDS, exact expf.
-#include <cstdlib>
 #include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
@@ -522,8 +521,8 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
-    const char* w64_env = getenv("FP_ATTN_W64");  // read per call: tests compare the two kernels in one process
-    const int w64 = w64_env ? atoi(w64_env) : 1;
+    FP_REQUIRE(a.variant >= 0 && a.variant <= 2, "attention: unknown kernel variant %d", a.variant);
+    const int w64 = a.variant == 1 ? 0 : (a.variant == 2 ? 2 : 1);  // default: 64 queries per wave
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     const bool sel = a.sel_off != nullptr;
     FP_REQUIRE(!sel || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");

@@ -137,6 +137,9 @@ struct AttnArgs {
   // sel_rows[sel_off[b] .. sel_off[b+1]) (global rows b * n_tok + token, ascending) over ALL its keys, and output row r of
   // the compact [num_sel, D] result belongs to sel_rows[r]
   const int* sel_rows; const int* sel_off; int max_sel;  // max_sel >= the largest per-image count (sizes the grid)
+  // bf16 work split (bit-identical outputs): 0 = 64 queries per wave, K/V by LDS-DMA (default); 1 = 32 queries per wave, register
+  // staging (the cross-check); 2 = the DMA kernel with one 32-query block per wave, 8 waves per 256-query block
+  int variant;
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 

@@ -324,6 +324,10 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_ransac_kernel(PnpArgs a) {
       const double x = P.R[0] * Xp[0] + P.R[1] * Xp[1] + P.R[2] * Xp[2] + P.t[0];
       const double y = P.R[3] * Xp[0] + P.R[4] * Xp[1] + P.R[5] * Xp[2] + P.t[1];
       const double z = P.R[6] * Xp[0] + P.R[7] * Xp[1] + P.R[8] * Xp[2] + P.t[2];
+      if (!(z > 1e-9)) {  // an inlier behind (or on) the camera plane: like reproj_err2, a cost no step is accepted with
+        v[27] += 1e30;
+        continue;
+      }
       const double iz = 1.0 / z;
       const double ru = fx * x * iz + cx - UV[p * 2 + 0], rv = fy * y * iz + cy - UV[p * 2 + 1];
       v[27] += ru * ru + rv * rv;
@@ -392,11 +396,14 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_ransac_kernel(PnpArgs a) {
     }
     __syncthreads();
     const int flag = s_flag;
+    __syncthreads();  // every wave has read the solve status before thread 0 may write s_flag again (below / next iteration)
     if (flag == 2) break;
     if (flag == 0) {
       if (tid == 0) s_lambda *= 10.0;
       __syncthreads();
-      if (s_lambda > 1e12) break;
+      const bool give_up = s_lambda > 1e12;
+      __syncthreads();  // ... and s_lambda before the next iteration's solve touches it
+      if (give_up) break;
       continue;
     }
     // cost + normal equations at the candidate; kept only if the step is accepted
@@ -419,7 +426,9 @@ __global__ __launch_bounds__(PNP_THREADS) void pnp_ransac_kernel(PnpArgs a) {
       }
     }
     __syncthreads();
-    if (s_flag == 2) break;
+    const int step_flag = s_flag;  // read into a register, then a barrier: the next iteration's thread 0 rewrites s_flag
+    __syncthreads();
+    if (step_flag == 2) break;
   }
   __syncthreads();
   if (tid == 0) {

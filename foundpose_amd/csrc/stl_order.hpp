@@ -13,7 +13,7 @@
 // on an array in place.  tests/test_stl_order.py checks it against the real std:: algorithms on tied inputs.
 #pragma once
 
-#if defined(__HIPCC__) || defined(__CUDACC__)
+#if defined(__HIPCC__)
 #define FP_HD __host__ __device__ inline
 #else
 #define FP_HD inline
@@ -35,7 +35,7 @@ FP_HD unsigned class_key(const Elem& x) {
   if (x.v != x.v) return 0u;
   const float f = x.v == 0.f ? 0.f : x.v;
   unsigned b;
-#if defined(__HIP_DEVICE_COMPILE__) || defined(__CUDA_ARCH__)
+#if defined(__HIP_DEVICE_COMPILE__)
   b = __float_as_uint(f);
 #else
   __builtin_memcpy(&b, &f, 4);

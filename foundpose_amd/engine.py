@@ -34,6 +34,25 @@ class FoundPoseEngine:
         self.top_n, self.top_k = top_n_templates, top_k_buddies
         self.tie_order = tie_order
         self._grids = {}
+        # per-stage HIP events of the last infer_batch (record_stage_times=True): the reference driver's `times` keys
+        # feat_extract / grid_sample / proj / corresp (scripts/infer.py:473-544), read back with stage_times()
+        self.record_stage_times = False
+        self._stage_events: List[Tuple[str, "torch.cuda.Event"]] = []
+
+    def _mark(self, name: str) -> None:
+        if self.record_stage_times:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            self._stage_events.append((name, e))
+
+    def stage_times(self) -> dict:
+        """Seconds per stage of the last infer_batch (whole batch), keyed like the reference's per-detection `times`
+        (scripts/infer.py:464-544).  Synchronises on the last event."""
+        ev = self._stage_events
+        if len(ev) < 2:
+            return {}
+        ev[-1][1].synchronize()
+        return {ev[i][0]: 1e-3 * ev[i - 1][1].elapsed_time(ev[i][1]) for i in range(1, len(ev))}
 
     def _grid(self, w: int, h: int, device):
         """Grid points of a w x h crop (generate_grid_points) and their pixels int(point + 0.5) (filter_points_by_mask)."""
@@ -117,26 +136,35 @@ class FoundPoseEngine:
         # that block only has to produce the patch tokens under the sampling taps: its attention queries, proj and MLP run on
         # those tokens (keys / values: all tokens).  Same sampled features bit for bit; FP_TOKEN_SELECT=0 is the A/B switch.
         select = fused and self.extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0"
+        self._stage_events = []
+        self._mark("start")
         pending = self._query_points_begin(masks, select_tokens=select)
         if select:
             self.extractor.forward_hidden(images, prefix_only=True)  # ~115 launches enqueued before the host waits for the counts
             q_pts, q_img, counts, (sel_rows, sel_off, row_map, num_sel, max_sel) = self._query_points_end(*pending)
             if num_sel > 0:
                 self.extractor.forward_selected_block(sel_rows, sel_off, num_sel, max_sel)
+            self._mark("feat_extract")
             raw = self.extractor.sample_patch_features(q_pts, q_img, row_map=row_map)
         elif fused:   # final norm + sampling in one pass over the query points only: the [B, Np, D] map is never written
             self.extractor.forward_hidden(images)                # ~120 launches enqueued before the host waits for the counts
             q_pts, q_img, counts = self._query_points_end(*pending)
+            self._mark("feat_extract")
             raw = self.extractor.sample_patch_features(q_pts, q_img)
         else:
             fmap, _ = self.extractor.forward_tokens(images)
             q_pts, q_img, counts = self._query_points_end(*pending)
+            self._mark("feat_extract")
             gh, gw = self.extractor.num_patches
             D = fmap.shape[-1]
             raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
+        self._mark("grid_sample")
         if not self.overlap_matching:
             feats = self._project(raw, counts, det_obj)
-            return match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            self._mark("proj")
+            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            self._mark("corresp")
+            return res
         main, side = torch.cuda.current_stream(), self.side_stream
         produced = torch.cuda.Event()
         produced.record(main)
@@ -145,7 +173,9 @@ class FoundPoseEngine:
             for t in (raw, q_pts, q_img):       # allocated on the caller's stream, consumed here
                 t.record_stream(side)
             feats = self._project(raw, counts, det_obj)
+            self._mark("proj")
             res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            self._mark("corresp")
             res.ready = torch.cuda.Event()
             res.ready.record(side)
         return res
@@ -201,13 +231,28 @@ RECORD_FLOATS_PER_CORRESP = 9  # q_id, feat_id, dist, conf, x, y, X, Y, Z
 
 
 def pack_result(res: MatchResult) -> torch.Tensor:
-    """Fixed-size fp32 record per detection for the final gather: [B, n*(3 + K*9)]
-    (template id, score, count, then K padded correspondences per template). Integer ids < 2^24 are exact in fp32."""
+    """Fixed-size record per detection for the final gather: [B, n*(3 + K*9)] 32-bit words, typed fp32 so the whole
+    record travels as one tensor (template id, score, count, then K padded correspondences per template).
+    The integer fields (template id, count, q_id = coord_2d_ids, feat_id = nn_vertex_ids, corresp_util.py:135-141 in the
+    reference) are BIT-CAST int32 -> fp32, not converted: a bank with more than 2^24 features (BASELINE config 5:
+    N_f = 18.7 M) has ids a float conversion would round.  unpack_result is the inverse."""
     B, n, K = res.q_ids.shape
-    head = torch.stack([res.template_ids.float(), res.template_scores, res.counts.float()], -1)  # [B,n,3]
-    body = torch.cat([res.q_ids.float().unsqueeze(-1), res.feat_ids.float().unsqueeze(-1), res.dists.unsqueeze(-1),
+    as_f = lambda t: t.to(torch.int32).contiguous().view(torch.float32)
+    head = torch.stack([as_f(res.template_ids), res.template_scores, as_f(res.counts)], -1)  # [B,n,3]
+    body = torch.cat([as_f(res.q_ids).unsqueeze(-1), as_f(res.feat_ids).unsqueeze(-1), res.dists.unsqueeze(-1),
                       res.conf.unsqueeze(-1), res.coord_2d, res.coord_3d], -1)  # [B,n,K,9]
     return torch.cat([head, body.reshape(B, n, K * RECORD_FLOATS_PER_CORRESP)], -1).reshape(B, -1).contiguous()
+
+
+def unpack_result(records: torch.Tensor, n: int, K: int) -> MatchResult:
+    """Inverse of pack_result on gathered records [R, n*(3 + K*9)] -> MatchResult of R detections (integer fields bit-exact)."""
+    R = records.shape[0]
+    per = records.reshape(R, n, 3 + K * RECORD_FLOATS_PER_CORRESP)
+    as_i = lambda t: t.contiguous().view(torch.int32)
+    body = per[..., 3:].reshape(R, n, K, RECORD_FLOATS_PER_CORRESP)
+    return MatchResult(template_ids=as_i(per[..., 0]), template_scores=per[..., 1].contiguous(), counts=as_i(per[..., 2]),
+                       q_ids=as_i(body[..., 0]), feat_ids=as_i(body[..., 1]), dists=body[..., 2].contiguous(), conf=body[..., 3].contiguous(),
+                       coord_2d=body[..., 4:6].contiguous(), coord_3d=body[..., 6:9].contiguous())
 
 
 def shard_detections(num_det: int, world_size: int, rank: int) -> Tuple[int, int]:

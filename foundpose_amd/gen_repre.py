@@ -114,9 +114,14 @@ def finish_repre(opts: GenRepreOpts, repre: repre_util.FeatureBasedObjectRepre) 
             repre.template_descs, repre.feat_cluster_idfs = descs, idfs
         else:
             raise ValueError(f"Unknown template descriptor type {opts.template_desc_opts.desc_type}.")
-    vis = projector_util.PCAProjector(n_components=3, whiten=False)
-    vis.fit(feats, max_samples=opts.pca_max_samples_for_fitting)
-    repre.feat_vis_projectors = [vis]
+    # visualisation projector (gen_repre.py:349-363): the raw-feature PCA is reused when there is one -- consumers apply
+    # feat_vis_projectors to RAW extractor features -- and a 3-component PCA is fitted only when PCA was not applied
+    if len(repre.feat_raw_projectors) and isinstance(repre.feat_raw_projectors[0], projector_util.PCAProjector):
+        repre.feat_vis_projectors = [repre.feat_raw_projectors[0]]
+    else:
+        vis = projector_util.PCAProjector(n_components=3, whiten=False)
+        vis.fit(feats, max_samples=opts.pca_max_samples_for_fitting)
+        repre.feat_vis_projectors = [vis]
     return repre
 
 

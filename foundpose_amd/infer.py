@@ -85,11 +85,21 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
     bank = DeviceBank([repre])
     eng = fe.FoundPoseEngine(extractor, bank, opts.grid_cell_size, opts.match_top_n_templates, opts.match_top_k_buddies, tie_order="torch")
+    eng.record_stage_times = True
     evaluator = eval_util.PoseEvaluator()
     vertices = repre.vertices.cpu().numpy()
     for frame in frames:
         scene_id, im_id, cam = frame["scene_id"], frame["im_id"], frame["camera"]
-        n_target = 1 if num_target_insts is None else num_target_insts.get((scene_id, im_id), 1)
+        # number of target instances (infer.py:308-321): from the test targets when given -- frames that are not a target of
+        # this object, or whose count is 0, are skipped -- otherwise the number of ground-truth annotations of the frame
+        if num_target_insts is not None:
+            if (scene_id, im_id) not in num_target_insts:
+                continue
+            n_target = int(num_target_insts[(scene_id, im_id)])
+        else:
+            n_target = len(frame["gt_annos"]) if frame.get("gt_annos") else 1
+        if n_target == 0:
+            continue
         instances = infer_pose_util.get_instances_for_pose_estimation(
             scene_id, im_id, object_lid, opts.use_detections, detections, int(opts.num_preds_factor * n_target), frame.get("gt_annos", []),
             (cam.width, cam.height))
@@ -116,12 +126,22 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         t2 = time.perf_counter()
         poses = pnp_util.estimate_poses(res, cams, opts.pnp_type, opts.pnp_ransac_iter, opts.pnp_inlier_thresh, opts.pnp_required_ransac_conf,
                                         opts.pnp_refine_lm, seed=seed)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
         best = pnp_util.select_best_coarse(poses)
         found, cid = best["found"].cpu().tolist(), best["corresp_id"].cpu().tolist()
         Rb, tb = best["R"].cpu().numpy(), best["t"].cpu().numpy()
-        t3 = time.perf_counter()
+        t4 = time.perf_counter()
         n = len(kept)
-        times = {"prep": (t1 - t0) / n, "feat_extract_and_corresp": (t2 - t1) / n, "pose_coarse": (t3 - t2) / n}
+        # The reference's per-detection `times` keys (infer.py:464-633, persisted by eval_util.py:327).  The instances of a frame
+        # run as ONE batch here, so every instance is charged its share of the batch; the four stages inside infer_batch come
+        # from HIP events on the stream (their sum is the device time of t1..t2, the host-side remainder is in feat_extract).
+        st = eng.stage_times()
+        dev_sum = sum(st.values())
+        times = {"prep": (t1 - t0) / n,
+                 "feat_extract": (st.get("feat_extract", 0.0) + max(0.0, (t2 - t1) - dev_sum)) / n,
+                 "grid_sample": st.get("grid_sample", 0.0) / n, "proj": st.get("proj", 0.0) / n, "corresp": st.get("corresp", 0.0) / n,
+                 "pose_coarse": (t3 - t2) / n, "final_select": (t4 - t3) / n}
         for b, (inst_j, inst) in enumerate(kept):
             if not found[b]:
                 continue
@@ -136,15 +156,18 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
 
 
 def infer(opts: InferOpts, frames_by_object, detections, repres: Dict[int, repre_util.FeatureBasedObjectRepre], output_dir: str, extractor=None,
-          precision: str = "bf16") -> List[str]:
+          precision: str = "bf16", num_target_insts: Optional[Dict[int, Dict[Tuple[int, int], int]]] = None) -> List[str]:
     """All objects: `frames_by_object(lid)` yields the frames that show object `lid`; one estimated-poses.json per object
-    under <output_dir>/<lid>/ (infer.py:813-816), then the BOP19 csv."""
+    under <output_dir>/<lid>/ (infer.py:813-816), then the BOP19 csv.
+    num_target_insts: {object lid: {(scene_id, im_id): inst_count}} from test_targets_bop19.json -- the number of poses to
+    estimate per (image, object) is num_preds_factor x inst_count (infer.py:308-346); frames without an entry are skipped."""
     lids = list(opts.object_lids) if opts.object_lids is not None else sorted(repres)
     if extractor is None:
         extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
     paths = []
     for lid in lids:
-        ev = infer_object(opts, lid, repres[lid], frames_by_object(lid), detections, extractor)
+        ev = infer_object(opts, lid, repres[lid], frames_by_object(lid), detections, extractor,
+                          num_target_insts=None if num_target_insts is None else num_target_insts.get(lid, {}))
         if opts.save_estimates:
             p = os.path.join(output_dir, str(lid), "estimated-poses.json")
             ev.save_results_json(p)
@@ -192,11 +215,11 @@ def main() -> None:
     detections = infer_pose_util.load_detections_in_bop_format(args.detections)
     lids = opts.object_lids or sorted({t["obj_id"] for t in targets})
     repres = {lid: repre_util.load_object_repre(repre_util.get_object_repre_dir_path(args.repre_dir, opts.repre_version, opts.object_dataset, lid)) for lid in lids}
-    n_inst = {}
+    n_inst: Dict[int, Dict[Tuple[int, int], int]] = {}
     for t in targets:
-        n_inst[(t["obj_id"], t["scene_id"], t["im_id"])] = t["inst_count"]
+        n_inst.setdefault(t["obj_id"], {})[(t["scene_id"], t["im_id"])] = t["inst_count"]
     out = infer(opts._replace(object_lids=list(lids)), lambda lid: load_bop_frames(args.dataset_dir, targets, lid), detections, repres, args.output_dir,
-                precision=args.precision)
+                precision=args.precision, num_target_insts=n_inst)
     print("\n".join(out))
 
 

@@ -35,8 +35,17 @@ class MatchResult:
                                                 # complete once this event has fired; wait() makes the current stream wait for it
 
     def wait(self) -> "MatchResult":
+        """Makes the current stream wait for the matching stream, and tells the caching allocator that the result tensors
+        (allocated on the matching stream) are now in use on the current one: without record_stream their blocks would go
+        back to the matching stream's pool the moment the result is dropped, and the next batch's matching could overwrite
+        them under a consumer kernel still reading on this stream."""
         if self.ready is not None:
-            torch.cuda.current_stream().wait_event(self.ready)
+            cur = torch.cuda.current_stream()
+            cur.wait_event(self.ready)
+            for t in (self.template_ids, self.template_scores, self.counts, self.q_ids, self.feat_ids, self.dists, self.conf, self.coord_2d,
+                      self.coord_3d, self.query_tfidf, self.word_ids):
+                if t is not None and t.is_cuda:
+                    t.record_stream(cur)
         return self
 
     def corresp_list(self, b: int, debug: bool = False) -> List[Dict]:

@@ -206,10 +206,11 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_dty
     return out
 
 
-def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int):
+def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, variant: int = 0):
+    """variant: bf16 work split (FP_ATTN_VARIANT in the header; all bit-identical) -- 0 is what the pipeline runs."""
     require_cuda(qkv)
     bf = qkv.dtype == torch.bfloat16
     out = torch.zeros(qkv.shape[0], dim, dtype=qkv.dtype, device=qkv.device)
     call("fp_attention", ptr(qkv), qkv.stride(0), ptr(out), dim,
-         batch, n_tok, dim, heads, _lib.FP_BF16 if bf else _lib.FP_F32, stream())
+         batch, n_tok, dim, heads, (_lib.FP_BF16 if bf else _lib.FP_F32) | (int(variant) << 8), stream())
     return out

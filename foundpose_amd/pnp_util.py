@@ -38,10 +38,12 @@ def _intrinsics(camera) -> Tuple[float, float, float, float]:
 
 def solve_pnp_ransac_batch(coord_2d: torch.Tensor, coord_3d: torch.Tensor, counts: torch.Tensor, cameras: Sequence[Any],
                            pnp_ransac_iter: int = 1000, pnp_inlier_thresh: float = 3.0, pnp_required_ransac_conf: float = 0.99,
-                           pnp_refine_lm: bool = True, seed: int = 0, return_ransac_pose: bool = False) -> Dict[str, torch.Tensor]:
+                           pnp_refine_lm: bool = True, seed: int = 0, return_ransac_pose: bool = False,
+                           min_corresp: int = 6) -> Dict[str, torch.Tensor]:
     """coord_2d [B, n, K, 2], coord_3d [B, n, K, 3], counts [B, n] (MatchResult's padded layout); cameras: one per detection.
     -> dict of device tensors: success [B, n] bool, R [B, n, 3, 3] f64, t [B, n, 3] f64, quality [B, n] (RANSAC inliers),
-    inliers [B, n, K] bool (+ ransac_pose [B, n, 12])."""
+    inliers [B, n, K] bool (+ ransac_pose [B, n, 12]).  min_corresp: sets with fewer correspondences fail without being tried --
+    6 in the driver's loop (scripts/infer.py:555-559), 4 for a bare estimate_pose call (what cv2.solvePnPRansac needs)."""
     require_cuda(coord_2d, coord_3d, counts)
     B, n, K = coord_2d.shape[:3]
     dev = coord_2d.device
@@ -59,7 +61,7 @@ def solve_pnp_ransac_batch(coord_2d: torch.Tensor, coord_3d: torch.Tensor, count
     rp = torch.zeros(P, 12, dtype=torch.float64, device=dev) if return_ransac_pose else None
     lm_iters = 20 + (20 if pnp_refine_lm else 0)
     call("fp_pnp_ransac", ptr(c2), ptr(c3), ptr(cnt), ptr(cam), P, n, K, int(pnp_ransac_iter), float(pnp_inlier_thresh),
-         float(pnp_required_ransac_conf), lm_iters, MIN_CORRESP, int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(success), ptr(R), ptr(t), ptr(ninl), ptr(mask), ptr(rp), stream())
+         float(pnp_required_ransac_conf), lm_iters, int(min_corresp), int(seed) & 0xFFFFFFFFFFFFFFFF, ptr(success), ptr(R), ptr(t), ptr(ninl), ptr(mask), ptr(rp), stream())
     out = {"success": success.reshape(B, n).bool(), "R": R.reshape(B, n, 3, 3), "t": t.reshape(B, n, 3),
            "quality": ninl.reshape(B, n).to(torch.float64), "inliers": mask.reshape(B, n, K).bool()}
     if rp is not None:
@@ -103,7 +105,7 @@ def estimate_pose(corresp: Dict[str, Any], camera_c2w: Any, pnp_type: str, pnp_r
     if k < 4:
         return False, None, None, None, None
     out = solve_pnp_ransac_batch(c2.reshape(1, 1, k, 2), c3.reshape(1, 1, k, 3), torch.tensor([[k]], dtype=torch.int32, device="cuda"),
-                                 [camera_c2w], pnp_ransac_iter, pnp_inlier_thresh, pnp_required_ransac_conf, pnp_refine_lm, seed)
+                                 [camera_c2w], pnp_ransac_iter, pnp_inlier_thresh, pnp_required_ransac_conf, pnp_refine_lm, seed, min_corresp=4)
     if not bool(out["success"][0, 0]):
         return False, None, None, None, None
     inl = torch.nonzero(out["inliers"][0, 0]).to(torch.int32).cpu().numpy()

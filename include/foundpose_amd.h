@@ -283,7 +283,11 @@ int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* 
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);
-/* qkv [B*N, 3D] (q | k | v column blocks, head-major inside) -> out [B*N, D] */
+/* qkv [B*N, 3D] (q | k | v column blocks, head-major inside) -> out [B*N, D].
+ * dtype: FP_F32 / FP_BF16 (+ FP_F16X3, see fp_vit_forward), optionally OR-ed with FP_ATTN_VARIANT(v) to pick a bf16 work split
+ * (all bit-identical): 0 = 64 queries per wave, K/V by LDS-DMA (default), 1 = 32 queries per wave with register staging,
+ * 2 = the DMA kernel with 8 waves per 256-query block. */
+#define FP_ATTN_VARIANT(v) ((v) << 8)
 int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok,
                  int dim, int heads, int dtype, fp_stream_t stream);
 int fp_convert_f32_to_bf16(const float* in, void* out, int64_t n, fp_stream_t stream);

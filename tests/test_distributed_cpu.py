@@ -69,16 +69,58 @@ def test_gather_world2_gloo():
     assert np.array_equal(valid[order], ref)
 
 
-def test_pack_result_layout():
+def _match_result(B, n, K, id_base=0):
     from foundpose_amd.matching import MatchResult
+    g = torch.Generator().manual_seed(5 + id_base % 97)
+    return MatchResult(
+        template_ids=torch.arange(B * n).reshape(B, n).int(), template_scores=torch.rand(B, n, generator=g), counts=torch.full((B, n), K).int(),
+        q_ids=torch.arange(B * n * K).reshape(B, n, K).int(), feat_ids=(torch.arange(B * n * K).reshape(B, n, K) * 2 + id_base).int(),
+        dists=torch.rand(B, n, K, generator=g), conf=torch.rand(B, n, K, generator=g), coord_2d=torch.rand(B, n, K, 2, generator=g),
+        coord_3d=torch.rand(B, n, K, 3, generator=g))
+
+
+def test_pack_result_layout():
     B, n, K = 2, 5, 4
-    r = MatchResult(
-        template_ids=torch.arange(B * n).reshape(B, n).int(), template_scores=torch.rand(B, n), counts=torch.full((B, n), K).int(),
-        q_ids=torch.arange(B * n * K).reshape(B, n, K).int(), feat_ids=torch.arange(B * n * K).reshape(B, n, K).int() * 2,
-        dists=torch.rand(B, n, K), conf=torch.rand(B, n, K), coord_2d=torch.rand(B, n, K, 2), coord_3d=torch.rand(B, n, K, 3))
+    r = _match_result(B, n, K)
     rec = engine.pack_result(r)
-    assert rec.shape == (B, n * (3 + K * engine.RECORD_FLOATS_PER_CORRESP))
+    assert rec.shape == (B, n * (3 + K * engine.RECORD_FLOATS_PER_CORRESP)) and rec.dtype == torch.float32
     per = rec.reshape(B, n, 3 + K * 9)
-    assert torch.equal(per[..., 0], r.template_ids.float()) and torch.equal(per[..., 2], r.counts.float())
+    # integer fields travel bit-cast (exact for any int32), float fields as they are
+    assert torch.equal(per[..., 0].contiguous().view(torch.int32), r.template_ids) and torch.equal(per[..., 2].contiguous().view(torch.int32), r.counts)
     body = per[..., 3:].reshape(B, n, K, 9)
-    assert torch.equal(body[..., 0], r.q_ids.float()) and torch.equal(body[..., 6:9], r.coord_3d)
+    assert torch.equal(body[..., 0].contiguous().view(torch.int32), r.q_ids) and torch.equal(body[..., 6:9], r.coord_3d)
+
+
+def test_pack_unpack_round_trip_large_ids():
+    """BASELINE config 5's bank has N_f = 18.7 M > 2^24 features: nn_vertex_ids above 2^24 (and negative 'no template' ids)
+    must survive the record exactly -- a float conversion would round them to even."""
+    B, n, K = 3, 5, 7
+    r = _match_result(B, n, K, id_base=(1 << 24) + 1)   # odd ids above 2^24: not representable in fp32
+    r.template_ids[1, 3] = -1
+    r.feat_ids[2, 4, 6] = 2 ** 31 - 1
+    assert not torch.equal(r.feat_ids.float().to(torch.int32), r.feat_ids)   # the old conversion would have lost them
+    u = engine.unpack_result(engine.pack_result(r), n, K)
+    for f in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d"):
+        assert torch.equal(getattr(u, f), getattr(r, f)), f
+        assert getattr(u, f).dtype == getattr(r, f).dtype
+
+
+def _worker_large_ids(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    local = engine.pack_result(_match_result(2, 5, 6, id_base=18_707_508 - 200 + rank))   # config 5's N_f, ids around 18.7 M
+    u = engine.unpack_result(engine.gather_records(local, world), 5, 6)
+    ret[rank] = (u.feat_ids.numpy(), u.q_ids.numpy(), u.template_ids.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gather_world2_gloo_ids_above_2_24_exact():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_large_ids, args=(world, port, ret), nprocs=world, join=True)
+    want = torch.cat([_match_result(2, 5, 6, id_base=18_707_508 - 200 + r).feat_ids for r in range(world)]).numpy()
+    assert want.max() > (1 << 24)
+    for rank in range(world):
+        assert np.array_equal(ret[rank][0], want)   # every rank holds every rank's ids, bit for bit

@@ -59,7 +59,7 @@ def test_gen_repre_from_templates_dir_then_inference(tmp_path):
     assert r.templates.shape == (T, 3, S, S) and r.templates.dtype == torch.uint8 and len(r.template_cameras_cam_from_model) == T
     assert r.template_descs.shape == (T, 48) and r.feat_cluster_centroids.shape == (48, 64) and r.feat_cluster_idfs.shape == (48,)
     assert r.feat_opts.extractor_name == NAME and r.template_desc_opts.desc_type == "tfidf"
-    assert len(r.feat_raw_projectors) == 1 and r.feat_raw_projectors[0].components.shape == (64, 384) and r.feat_vis_projectors[0].components.shape == (3, 64)
+    assert len(r.feat_raw_projectors) == 1 and r.feat_raw_projectors[0].components.shape == (64, 384) and r.feat_vis_projectors[0].components.shape == (64, 384)   # the raw-feature PCA reused, like the reference (gen_repre.py:349-353)
     f2t = r.feat_to_template_ids.cpu().long()
     assert bool((f2t[1:] >= f2t[:-1]).all()) and int(f2t.max()) == T - 1
     # 3D registration: a template's vertices, moved back into its camera, project onto patch centres with the rendered depth

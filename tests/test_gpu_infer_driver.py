@@ -75,7 +75,9 @@ def test_infer_driver_synthetic_scene(tmp_path):
         assert all(isinstance(e[k], str) for k in ("scene_id", "img_id", "obj_id", "inst_id", "hypothesis_id", "score"))
         assert (e["scene_id"], e["img_id"], e["obj_id"], e["hypothesis_id"]) == ("1", "3", "1", "0") and e["cnos_time"] == 0.25
         assert np.array(e["R"]).shape == (3, 3) and np.array(e["t"]).shape == (3, 1) and float(e["score"]) > 0.9
-        assert set(e["time"]) == {"prep", "feat_extract_and_corresp", "pose_coarse"}
+        # the reference's per-stage keys (scripts/infer.py:464-633, persisted by utils/eval_util.py:327)
+        assert set(e["time"]) == {"prep", "feat_extract", "grid_sample", "proj", "corresp", "pose_coarse", "final_select"}
+        assert all(v >= 0.0 for v in e["time"].values()) and e["time"]["feat_extract"] > 0 and e["time"]["corresp"] > 0
     for e in est:  # instances are ordered by detection score -> inst_id b is box b
         b = int(e["inst_id"])
         T_m2c = np.eye(4)
@@ -87,3 +89,19 @@ def test_infer_driver_synthetic_scene(tmp_path):
     assert paths[-1].endswith("coarse_synth-estimated-poses.csv") and csv[0] == "scene_id,im_id,obj_id,score,R,t,time" and len(csv) == 3
     row = csv[1].split(",")
     assert row[:3] == ["1", "3", "1"] and len(row[4].split(" ")) == 9 and len(row[5].split(" ")) == 3 and float(row[6]) > 0.25
+
+    # ---- number of poses per (image, object) = num_preds_factor x inst_count of the test targets (infer.py:308-346)
+    dets_l = infer_pose_util.load_detections_in_bop_format(str(det_path))
+    rep = {1: repre_util.load_object_repre(rdir)}
+    o1 = opts._replace(num_preds_factor=1.0)
+
+    def run(tag, targets):
+        d = str(tmp_path / tag)
+        infer.infer(o1, frames, dets_l, rep, d, extractor=ex, num_target_insts=targets)
+        f = os.path.join(d, "1", "estimated-poses.json")
+        return json.load(open(f)) if os.path.exists(f) else []
+    two = run("t2", {1: {(1, 3): 2}})          # a multi-instance target: both detections get a pose
+    assert sorted(int(e["inst_id"]) for e in two) == [0, 1]
+    one = run("t1", {1: {(1, 3): 1}})          # one target instance: only the top-scoring detection
+    assert [int(e["inst_id"]) for e in one] == [0]
+    assert run("t0", {1: {(1, 3): 0}}) == [] and run("tmiss", {1: {(2, 9): 3}}) == [] and run("tobj", {5: {(1, 3): 2}}) == []

@@ -106,19 +106,16 @@ def test_attention_bf16_and_f32(B, N, heads):
 
 
 @pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 8), (3, 905, 2), (1, 256, 1), (2, 257, 4), (1, 321, 16)])
-def test_attention_bf16_work_splits_agree_bitwise(B, N, heads, monkeypatch):
+def test_attention_bf16_work_splits_agree_bitwise(B, N, heads):
     """The 64-queries-per-wave kernel (LDS-DMA staging) and the 32-queries-per-wave kernel issue the same MFMAs in the
     same order for every query: their outputs must be bit-identical (ragged tails, idle waves, both block mappings)."""
     from foundpose_amd import ops
     D = heads * 64
     g = torch.Generator().manual_seed(N + heads)
     q16 = (torch.randn(B * N, 3 * D, generator=g) * 1.5).to(torch.bfloat16).cuda()
-    monkeypatch.setenv("FP_ATTN_W64", "0")
-    o_a = ops.attention(q16, B, N, D, heads).clone()
-    monkeypatch.setenv("FP_ATTN_W64", "1")
-    o_b = ops.attention(q16, B, N, D, heads).clone()
-    monkeypatch.setenv("FP_ATTN_W64", "2")   # the DMA kernel with one 32-query block per wave, 8 waves per block
-    o_c = ops.attention(q16, B, N, D, heads)
+    o_a = ops.attention(q16, B, N, D, heads, variant=1).clone()   # 32 queries per wave, register staging
+    o_b = ops.attention(q16, B, N, D, heads, variant=0).clone()   # the pipeline's kernel
+    o_c = ops.attention(q16, B, N, D, heads, variant=2)           # the DMA kernel with one 32-query block per wave, 8 waves per block
     torch.cuda.synchronize()
     assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_c.view(torch.int16))
 
