@@ -12,8 +12,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
-FP_F32, FP_BF16, FP_FP8 = 0, 1, 2
-ABI_VERSION = 11
+FP_F32, FP_BF16, FP_FP8, FP_F16X3 = 0, 1, 2, 3
+SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 128.0, 64.0, 64.0  # FP_SPLIT_SCALE_* of the header
+ABI_VERSION = 12
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -30,7 +31,7 @@ class VitModel(C.Structure):
         ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
         ("ffn_swiglu", i32), ("weight_dtype", i32),
         ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
-        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("ln_fold", i32),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("patch_acc_scale", f32), ("ln_fold", i32),
     ]
 
 
@@ -67,6 +68,9 @@ _PROTOS = {
     "fp_ln_finalize": [vp, i32, i32, i32, i32, f32, vp, vp],
     "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, vp],
     "fp_quantize_fp8": [vp, i32, i64, f32, vp, vp],
+    "fp_gemm_split": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, f32, vp],
+    "fp_attention_split": [vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp],
+    "fp_layernorm_scaled": [vp, i32, vp, vp, f32, vp, i32, i32, f32, i32, i32, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],
     "fp_convert_f32_to_bf16": [vp, vp, i64, vp],

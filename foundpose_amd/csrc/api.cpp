@@ -200,7 +200,7 @@ int fp_pnp_ransac(const float* coord_2d, const float* coord_3d, const int32_t* c
 int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
                 fp_stream_t stream) {
   FP_REQUIRE(images && out, "fp_patchify: null pointer");
-  return patchify_launch(images, B, H, W, patch, out, ld_out, out_dtype, ST(stream));
+  return patchify_launch(images, B, H, W, patch, out, ld_out, out_dtype, ST(stream), out_dtype == FP_DTYPE_F16X3 ? FP_SPLIT_SCALE_ACT : 1.f);
 }
 
 int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
@@ -209,7 +209,7 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
   FP_REQUIRE(x && weight && bias && out, "fp_layernorm: null pointer");
   LayerNormArgs a;
   a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
-  a.out_dtype = out_dtype; a.dim = dim; a.out_rows = out_rows;
+  a.out_dtype = out_dtype; a.out_scale = 0.f; a.dim = dim; a.out_rows = out_rows;
   a.out_rows_per_img = out_rows_per_img > 0 ? out_rows_per_img : (out_rows > 0 ? out_rows : 1);
   a.in_rows_per_img = in_rows_per_img > 0 ? in_rows_per_img : a.out_rows_per_img;
   a.in_skip = in_skip;
@@ -293,6 +293,44 @@ int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, in
   return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
 }
 
+int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
+                  void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream) {
+  FP_REQUIRE(A && W && out, "fp_gemm_split: null pointer");
+  const int tile = (epilogue >> 8) & 0xfff;
+  epilogue &= 0xff;
+  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_split: bad tile override %d", tile);
+  FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
+                 epilogue == GEMM_EPI_BIAS_F32 || epilogue == GEMM_EPI_SWIGLU_BF16,
+             "fp_gemm_split: epilogue %d is not available through this entry point", epilogue);
+  GemmBf16Args a;
+  memset(&a, 0, sizeof(a));
+  a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
+  a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
+  a.tile_override = tile; a.acc_scale = acc_scale; a.out_scale = out_scale;
+  return gemm_split_launch(epilogue, a, ST(stream));
+}
+
+int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
+                       fp_stream_t stream) {
+  FP_REQUIRE(qkv && out, "fp_attention_split: null pointer");
+  AttnArgs a;
+  memset(&a, 0, sizeof(a));
+  a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
+  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = out_scale;
+  return attn_launch(a, FP_DTYPE_F16X3, ST(stream));
+}
+
+int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out, int out_dtype, float out_scale,
+                        int dim, int out_rows, fp_stream_t stream) {
+  FP_REQUIRE(x && weight && bias && out, "fp_layernorm_scaled: null pointer");
+  FP_REQUIRE(out_dtype == FP_DTYPE_FP8 || out_dtype == FP_DTYPE_F16X3, "fp_layernorm_scaled: the scaled outputs are fp8 bytes and split-fp16 rows");
+  LayerNormArgs a;
+  a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
+  a.out_dtype = out_dtype; a.out_scale = out_scale; a.dim = dim; a.out_rows = out_rows;
+  a.out_rows_per_img = out_rows > 0 ? out_rows : 1; a.in_rows_per_img = a.out_rows_per_img; a.in_skip = 0;
+  return layernorm_launch(a, ST(stream));
+}
+
 int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream) {
   FP_REQUIRE(in && out, "fp_quantize_fp8: null pointer");
   FP_REQUIRE(in_dtype == FP_F32 || in_dtype == FP_BF16, "fp_quantize_fp8: input must be fp32 or bf16");
@@ -364,8 +402,11 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   FP_REQUIRE(ws->patches && ws->x && ws->y && ws->qkv && ws->h, "fp_vit_forward: workspace buffer missing");
   hipStream_t st = ST(stream);
   const bool f8 = m->weight_dtype == FP_DTYPE_FP8;  // e4m3 block matrices; activations and patch embed stay bf16
+  const bool sp = m->weight_dtype == FP_DTYPE_F16X3;  // split-fp16 operands everywhere (near-exact mode): rows of 2 x halves
   const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
-  const int adt = bf ? FP_DTYPE_BF16 : FP_DTYPE_F32;
+  const int adt = sp ? FP_DTYPE_F16X3 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32);
+  const int em = sp ? 2 : 1;                          // stored elements per logical element of an operand row
+  FP_REQUIRE(!sp || (mode == VIT_FULL && m->patch_acc_scale > 0.f), "fp_vit_forward: the f16x3 mode runs full blocks and needs patch_acc_scale");
   FP_REQUIRE(!f8 || (ws->a8 && ws->m_pad % 256 == 0), "fp_vit_forward: the fp8 mode needs workspace a8 and m_pad %% 256 == 0");
   FP_REQUIRE(!f8 || ((ws->ld_y == 0 || (ws->ld_y >= m->dim && ws->ld_y % 16 == 0)) && (ws->ld_h == 0 || (ws->ld_h >= m->hidden && ws->ld_h % 16 == 0)) &&
                      (m->ld_w_dim == 0 || (m->ld_w_dim >= m->dim && m->ld_w_dim % 16 == 0)) && (m->ld_w_hidden == 0 || (m->ld_w_hidden >= m->hidden && m->ld_w_hidden % 16 == 0))),
@@ -373,9 +414,18 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
   if (mode != VIT_LAST_SELECTED) {
-  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, m->patch_k_pad, adt, st));
+  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
   TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
-  if (bf) {
+  if (sp) {
+    GemmBf16Args g;
+    memset(&g, 0, sizeof(g));
+    g.A = reinterpret_cast<const __bf16*>(ws->patches); g.lda = 2 * m->patch_k_pad;
+    g.W = reinterpret_cast<const __bf16*>(m->patch_w); g.ldw = 2 * m->patch_k_pad;
+    g.M = ws->m_patch_pad; g.N = D; g.K = m->patch_k_pad; g.M_valid = Mp; g.bias = m->patch_b;
+    g.out = ws->x; g.ldo = D; g.pos = m->pos_patch; g.tok_np = np; g.tok_n = ntok; g.tok_skip = 1 + m->registers;
+    g.acc_scale = m->patch_acc_scale;
+    TRY(gemm_split_launch(GEMM_EPI_TOKENS_F32, g, st));
+  } else if (bf) {
     GemmBf16Args g;
     memset(&g, 0, sizeof(g));
     g.A = reinterpret_cast<const __bf16*>(ws->patches); g.lda = m->patch_k_pad;
@@ -394,10 +444,11 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   }
 
   // row strides of the bf16 / fp32 operands (fp8 mode: dense)
-  const int ldy = (!f8 && ws->ld_y) ? ws->ld_y : D, ldh = (!f8 && ws->ld_h) ? ws->ld_h : m->hidden;
-  const int ldq = ws->ld_qkv ? ws->ld_qkv : 3 * D;
-  const int ldwd = (!f8 && m->ld_w_dim) ? m->ld_w_dim : D, ldwh = (!f8 && m->ld_w_hidden) ? m->ld_w_hidden : m->hidden;
-  FP_REQUIRE(ldy >= D && ldh >= m->hidden && ldwd >= D && ldwh >= m->hidden && ldy % 8 == 0 && ldh % 8 == 0 && ldwd % 8 == 0 && ldwh % 8 == 0 && ldq >= 3 * D && ldq % 8 == 0,
+  const int ldy = (!f8 && ws->ld_y) ? ws->ld_y : em * D, ldh = (!f8 && ws->ld_h) ? ws->ld_h : em * m->hidden;
+  const int ldq = ws->ld_qkv ? ws->ld_qkv : em * 3 * D;
+  const int ldwd = (!f8 && m->ld_w_dim) ? m->ld_w_dim : em * D, ldwh = (!f8 && m->ld_w_hidden) ? m->ld_w_hidden : em * m->hidden;
+  FP_REQUIRE(ldy >= em * D && ldh >= em * m->hidden && ldwd >= em * D && ldwh >= em * m->hidden && ldy % 8 == 0 && ldh % 8 == 0 && ldwd % 8 == 0 && ldwh % 8 == 0 &&
+                 ldq >= em * 3 * D && ldq % 8 == 0,
              "fp_vit_forward: operand row strides must cover the row and keep 16-byte alignment");
   LayerNormArgs ln;
   ln.out_scale = 0.f;
@@ -480,6 +531,35 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     }
     // x += ls1 * proj(attn(ln1(x)))
     ln.weight = b.ln1_w; ln.bias = b.ln1_b;
+    if (sp) {
+      // f16x3 block: every GEMM / attention operand is a split-fp16 row written by the kernel in front of it (LayerNorm, the
+      // qkv / GELU / SwiGLU epilogues, the attention kernel) with a fixed power-of-two scale; b.act_scale[j] = 1 / (scale of the
+      // input x scale of the matrix) undoes both in the epilogue of GEMM j.  The residual stream, LayerNorm and softmax are fp32.
+      auto sgemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
+                       float acc_scale, float out_scale) -> int {
+        GemmBf16Args g;
+        memset(&g, 0, sizeof(g));
+        g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
+        g.M = ws->m_pad; g.N = N; g.K = K; g.M_valid = Mtok; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+        g.acc_scale = acc_scale; g.out_scale = out_scale;
+        return gemm_split_launch(epi, g, st);
+      };
+      ln.out_scale = FP_SPLIT_SCALE_ACT;
+      TRY(layernorm_launch(ln, st));
+      TRY(sgemm(ws->y, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.act_scale[0], FP_SPLIT_SCALE_QKV));
+      AttnArgs as = at;
+      as.in_scale = FP_SPLIT_SCALE_QKV; as.out_scale = FP_SPLIT_SCALE_ACT;
+      TRY(attn_launch(as, FP_DTYPE_F16X3, st));
+      TRY(sgemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, b.act_scale[1], 0.f));
+      ln.weight = b.ln2_w; ln.bias = b.ln2_b;
+      TRY(layernorm_launch(ln, st));
+      if (m->ffn_swiglu)
+        TRY(sgemm(ws->y, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.act_scale[2], FP_SPLIT_SCALE_HID));
+      else
+        TRY(sgemm(ws->y, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.act_scale[2], FP_SPLIT_SCALE_HID));
+      TRY(sgemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, b.act_scale[3], 0.f));
+      continue;
+    }
     if (f8) {
       // fp8 block: every GEMM input is produced as e4m3 bytes by the kernel in front of it -- LayerNorm, attention and
       // the GELU / SwiGLU epilogue quantise with the block's static scales on their way out (ws->a8; the hidden

@@ -464,6 +464,216 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   }
 }
 
+// ---------------------------------------------------------------- split-fp16 (f16x3 mode): near-exact attention on the fp16 MFMA
+// Same structure as attn_bf16_w64_kernel<1> (8 waves x one 32-query block, K/V tiles by LDS-DMA, S^T = K Q^T so a lane owns one
+// query's scores, V^T by transpose reads), but every operand is a split-fp16 pair (common.hpp) and every product three MFMAs
+// (hi*hi + hi*lo + lo*hi, fp32 accumulate): q, k, v arrive as the split rows the qkv GEMM wrote (scale SQ each), P is split in
+// registers (scale 2^14; its row sum is taken from the unsplit fp32 values), the output leaves as a split row (scale out_scale).
+//   qkv row: [q | k | v], each 2D halves; head h = halves [128 h, 128 h + 128) of its part = two 32-d groups of [hi 32 | lo 32]
+//   K image [64 keys][256 B]: 16-B chunk p of row r holds chunk p ^ (r & 15)        (b128 fragment reads: 16 lanes, 16 rows, 16 slots)
+//   V image [64 keys][256 B]: 64-B unit  u of row r holds unit  u ^ (r & 3)         (transpose reads: a half-wave's four keys x 64 B
+//                                                                                    fall into the four bank quarters)
+constexpr float SPLIT_P_SCALE = 16384.f;
+
+__global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
+  __shared__ __attribute__((aligned(16))) char KV[2][2][16384];  // [stage][K | V]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+  int qt, head, img;
+  {
+    const int nqt = (a.n_tok + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    int pair;
+    if ((pairs & 7) == 0) {  // all query tiles of an (image, head) pair on one XCD (one L2), see attn_bf16_kernel
+      const int j = i >> 3;
+      qt = j % nqt;
+      pair = (j / nqt) * 8 + (i & 7);
+    } else {
+      qt = i % nqt;
+      pair = i / nqt;
+    }
+    head = pair % a.heads;
+    img = pair / a.heads;
+  }
+  const int N = a.n_tok, D = a.dim;
+  const _Float16* qkv = reinterpret_cast<const _Float16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  const int q0 = qt * 256 + wave * 32;
+  const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
+
+  // ---- staging: a DMA instruction moves 4 rows x 256 B; wave w issues row groups 2w, 2w + 1 of K and of V
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (unsigned)((size_t)N * a.ld_qkv * 2), 0x00020000);
+  const int sr = lane >> 4, sp = lane & 15;
+  const unsigned rowoff = (unsigned)(sr * a.ld_qkv) * 2u;
+  // K: row r = 4 G + sr of the tile -> r & 15 = 4 (G & 3) + sr, with G = 2 wave (+ 1)
+  const unsigned voff_k0 = rowoff + ((unsigned)(sp ^ (4 * ((2 * wave) & 3) + sr)) << 4);
+  const unsigned voff_k1 = rowoff + ((unsigned)(sp ^ (4 * ((2 * wave + 1) & 3) + sr)) << 4);
+  const unsigned voff_v = rowoff + ((unsigned)((((sp >> 2) ^ sr) << 2) | (sp & 3)) << 4);   // r & 3 = sr
+  const unsigned tile_stride = (unsigned)(64 * a.ld_qkv) * 2u, grp_stride = (unsigned)(4 * a.ld_qkv) * 2u;
+  const unsigned soff_k = (unsigned)(2 * D + head * 128) * 2u + 2u * wave * grp_stride, soff_v = soff_k + (unsigned)(2 * D) * 2u;
+  auto stage_tile = [&](int kt, int stage) {
+    const unsigned t = kt * tile_stride;
+    char* kd = KV[stage][0] + wave * 2048;
+    char* vd = KV[stage][1] + wave * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(vd + 1024), 16, voff_v, soff_v + t + grp_stride, 0, 0);
+  };
+  const int nkt = (N + 63) / 64;
+  stage_tile(0, 0);
+
+  // exp2 argument = score * head_dim^-0.5 * log2(e); the accumulated scores carry the operand scales in_scale^2
+  const float c = 0.125f * 1.44269504088896340736f / (a.in_scale * a.in_scale);
+  // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d] as (hi, lo)
+  f16x8 qh[4], ql[4];
+  {
+    const int q = q0 + l31;
+    const int qc = q < N ? q : N - 1;
+    const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
+      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
+      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
+    }
+  }
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  // transpose-read base inside the V image: key = kh*8 + kq, 16-d block vb, 8-B piece; the 64-B unit is XOR-ed with kq per read
+  const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
+  const int vrd0 = (kh * 8 + kq) * 256 + vb * 32 + (lane & 3) * 8;
+
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) as a builtin (see attn_bf16_w64_kernel)
+  __syncthreads();
+  auto tile = [&](int kt, auto ragged) {
+    constexpr bool RAGGED = decltype(ragged)::value;
+    const int key0 = kt * 64;
+    const char* Ks = KV[kt & 1][0];
+    const char* Vs = KV[kt & 1][1];
+    if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
+    if (active) {
+      // ---- S^T = K Q^T: sacc[ks][r] = score(query l31, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
+      f32x16 sacc[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
+        const int row = ks * 32 + l31;
+        const char* kr = Ks + row * 256;
+#pragma unroll
+        for (int ds = 0; ds < 4; ++ds) {
+          const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
+          const f16x8 kfh = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
+          const f16x8 kfl = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
+          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ds], sacc[ks], 0, 0, 0);
+          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ds], sacc[ks], 0, 0, 0);
+          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ds], sacc[ks], 0, 0, 0);
+        }
+      }
+      if constexpr (RAGGED) {  // mask the padded keys
+        const int lim = N - key0 - 4 * kh;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
+      }
+      // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
+      float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run, mx);
+      const bool grow = __any(m_new > m_run);
+      float alpha = 1.f;
+      if (grow) alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+      float psum = 0.f;
+      const float mc = m_new * c;
+      f16x8 ph[4], pl[4];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
+          sacc[ks][r] = p;
+          psum += p;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+          const int r0 = 8 * kk;
+          unsigned a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l;
+          split16_pack2(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
+          split16_pack2(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
+          split16_pack2(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
+          split16_pack2(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
+          auto h0 = __builtin_amdgcn_permlane32_swap(a0h, b0h, false, false);
+          auto h1 = __builtin_amdgcn_permlane32_swap(a1h, b1h, false, false);
+          auto l0 = __builtin_amdgcn_permlane32_swap(a0l, b0l, false, false);
+          auto l1 = __builtin_amdgcn_permlane32_swap(a1l, b1l, false, false);
+          ph[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(h0[0], h1[0], h0[1], h1[1]));
+          pl[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(l0[0], l1[0], l0[1], l1[1]));
+        }
+      }
+      if (grow) {
+        l_run *= alpha;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+      }
+      l_run += psum;
+      // ---- O^T += V^T P^T over 4 steps of 16 keys
+#pragma unroll
+      for (int kstep = 0; kstep < 4; ++kstep)
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;       // hi unit of d-group dt (+ 1024 B = 4 keys on)
+          const char* vpl = Vs + vrd0 + (((2 * dt + 1) ^ kq) << 6) + kstep * 4096;   // lo unit
+          const s16x4 h_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph));
+          const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
+          const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
+          const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
+          const f16x8 vfh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          const f16x8 vfl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl, ph[kstep], oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, pl[kstep], oacc[dt], 0, 0, 0);
+          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, ph[kstep], oacc[dt], 0, 0, 0);
+        }
+    }
+    if constexpr (!RAGGED) {
+      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
+      __syncthreads();
+    }
+  };
+  const int nfull = N / 64;
+  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
+  if (nfull < nkt) tile(nfull, std::true_type{});
+
+  if (active) {
+    const int q = q0 + l31;
+    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
+    if (q < N) {
+      _Float16* o = reinterpret_cast<_Float16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 128;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          unsigned h01, l01, h23, l23;
+          split16_pack2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, a.out_scale, h01, l01);
+          split16_pack2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv, a.out_scale, h23, l23);
+          _Float16* op = o + dt * 64 + 8 * g + 4 * kh;
+          *reinterpret_cast<uint2*>(op) = make_uint2(h01, h23);
+          *reinterpret_cast<uint2*>(op + 32) = make_uint2(l01, l23);
+        }
+    }
+  }
+}
+
 // ---------------------------------------------------------------- fp32 parity-mode attention
 // qkv fp32 [B*N, 3D]; one thread per query row; keys/values of the (image, head) streamed through LDS.
 __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
@@ -534,6 +744,12 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
     }
+  } else if (dtype == FP_DTYPE_F16X3) {
+    FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
+    FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 4 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
+    FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
+    FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
+    hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
     dim3 grid(cdiv(a.n_tok, 256), a.heads, a.batch);

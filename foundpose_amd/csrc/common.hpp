@@ -56,6 +56,26 @@ FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
 }
 
+// ---- split-fp16 operands of the f16x3 mode (near-exact fp32 products on the fp16 MFMA).
+// A logical fp32 row x[0..K) (K % 32 == 0) is stored as 2K halves: group g = k / 32 holds hi(x[32g .. 32g+31]) in halves
+// [64g, 64g + 32) and lo(...) in [64g + 32, 64g + 64), with hi = f16(s x), lo = f16(s x - hi) (round to nearest even, s a
+// power-of-two scale so that typical magnitudes sit well inside the fp16 normal range; saturating at +-65504).  hi + lo
+// carries 22 mantissa bits of s x; the product of two such operands is accumulated as hi*hi + hi*lo + lo*hi in fp32
+// (the dropped lo*lo term is <= 2^-22 relative).
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsigned& lo) {
+  a = __builtin_amdgcn_fmed3f(a * scale, -65504.f, 65504.f);
+  b = __builtin_amdgcn_fmed3f(b * scale, -65504.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(f32x2{a - hf[0], b - hf[1]}, f16x2);  // the residual is exact in fp32
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
+// position (in halves) of logical column c inside a split row; its lo half sits 32 halves further
+FP_DEVICE int split16_pos(int c) { return ((c >> 5) << 6) + (c & 31); }
+
 // ---- wave-level reductions (64 lanes)
 FP_DEVICE float wave_sum(float v) {
 #pragma unroll

@@ -96,9 +96,16 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 
 // F8OUT (GELU / SwiGLU epilogues of the fp8 kernels): the result is itself the input of the next fp8 GEMM and leaves as
 // e4m3(clamp(value * a.out_scale, +-448)) bytes, [M, N] (or [M, N/2]) with ldo in bytes -- no separate quantisation pass.
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false>
+// SP (f16x3 mode): the operands are split-fp16 rows (common.hpp): a row of K logical elements is 2K halves, a K-tile is the same
+// 128-B-per-row LDS image holding 32 k-values as [hi 32 | lo 32], the staging code is shared, and a K-tile is consumed by three
+// v_mfma_f32_32x32x16_f16 per accumulator and 16-wide k-step -- hi*hi, hi*lo, lo*hi -- i.e. 3x the MFMAs and 2x the operand
+// bytes of the bf16 kernel for products that carry 22 mantissa bits.  SPOUT: the BIAS / GELU / SwiGLU result is the next
+// GEMM's (or the attention's) operand and leaves as a split-fp16 row scaled by a.out_scale; GELU is the exact erf form here.
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
+  static_assert(!(SP && F8) && (!SPOUT || SP), "split-fp16 and fp8 operands exclude each other; a split output needs split operands");
+  static_assert(SPOUT == (SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "f16x3: the half-precision epilogues write split rows");
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr bool RESID = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_RESID_F32;  // fp32 residual read-modify-write epilogues
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
@@ -223,6 +230,41 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           }
+        } else if constexpr (SP) {
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {  // two 16-wide k-steps of the 32 k-values of this tile
+            if (more) {
+#pragma unroll
+              for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s2 * 2 * PER_KS + q, t + 1, nxt);
+            }
+            const int ch = s2 * 2 + kh;  // hi chunk of this lane's 8 k-values; the lo chunk sits 4 chunks (64 B) further
+            f16x8 ah[TM], al[TM], wh[TN], wl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int row = wm * (BM / WM) + i * 32 + l31;
+              ah[i] = __builtin_bit_cast(f16x8, read_frag(As, row, ch));
+              al[i] = __builtin_bit_cast(f16x8, read_frag(As, row, ch + 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const int row = wn * (BN / WN) + j * 32 + l31;
+              wh[j] = __builtin_bit_cast(f16x8, read_frag(Ws, row, ch));
+              wl[j] = __builtin_bit_cast(f16x8, read_frag(Ws, row, ch + 4));
+            }
+            // the two cross terms first (small), then hi*hi; TM*TN independent accumulators between two MFMAs of one chain
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+          }
         } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -263,7 +305,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     static_assert(!F8 || USE_SLAB, "the fp8 kernels exist for the slab epilogues only");
     if constexpr (USE_SLAB) {
     constexpr bool OUT_F32 = RESID || EPI == GEMM_EPI_TOKENS_F32 || EPI == GEMM_EPI_BIAS_F32;
-    constexpr int ESZ = OUT_F32 ? 4 : (F8OUT ? 1 : 2);
+    constexpr int ESZ = OUT_F32 ? 4 : (F8OUT ? 1 : (SPOUT ? 4 : 2));  // split rows: hi + lo half per column
     constexpr int OUT_COLS = EPI == GEMM_EPI_SWIGLU_BF16 ? BN / 2 : BN;  // SwiGLU folds column pairs
     constexpr int SLAB_ROWS = WM * 32, SLAB_STRIDE = OUT_COLS * ESZ + 16;  // +16 B: de-phases the rows across LDS banks
     constexpr int CHUNKS_PER_ROW = OUT_COLS * ESZ / 16, SLAB_CHUNKS = SLAB_ROWS * CHUNKS_PER_ROW, NT = NW * 64;
@@ -328,6 +370,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
+          if constexpr (SP) {  // undo the power-of-two operand scales (exact), then the bias
+            const float as = a.acc_scale;
+            v0 = fmaf(acc[tm][tn][4 * g + 0], as, bs.x); v1 = fmaf(acc[tm][tn][4 * g + 1], as, bs.y);
+            v2 = fmaf(acc[tm][tn][4 * g + 2], as, bs.z); v3 = fmaf(acc[tm][tn][4 * g + 3], as, bs.w);
+          }
           if constexpr (LN_FOLD_OK) {
             if (fold) {  // rstd * acc - (mean * rstd) * colsum + bias, two columns per v_pk_fma_f32
               const float4 cs = gam[tn][g];
@@ -344,18 +391,42 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
           }
           if constexpr (EPI == GEMM_EPI_GELU_BF16) {
-            const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
-            v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+            if constexpr (SP) {  // exact erf form (the fp32 path's, f32_tile.hip): this mode does not approximate
+              v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f)); v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
+              v2 = 0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752440f)); v3 = 0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752440f));
+            } else {
+              const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
+              v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+            }
           }
           if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
             const float4 gm = gam[tn][g];
             v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
           }
           if constexpr (EPI == GEMM_EPI_SWIGLU_BF16) {
-            const float h0 = v0 / (1.f + __builtin_amdgcn_exp2f(-v0 * 1.44269504088896340736f)) * v1;  // silu(x1) * x2
-            const float h1 = v2 / (1.f + __builtin_amdgcn_exp2f(-v2 * 1.44269504088896340736f)) * v3;
-            if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f);
+            float h0, h1;
+            if constexpr (SP) {  // exact expf form, like the fp32 path
+              h0 = v0 / (1.f + expf(-v0)) * v1;
+              h1 = v2 / (1.f + expf(-v2)) * v3;
+            } else {
+              h0 = v0 / (1.f + __builtin_amdgcn_exp2f(-v0 * 1.44269504088896340736f)) * v1;  // silu(x1) * x2
+              h1 = v2 / (1.f + __builtin_amdgcn_exp2f(-v2 * 1.44269504088896340736f)) * v3;
+            }
+            if constexpr (SPOUT) {
+              unsigned hi, lo;
+              split16_pack2(h0, h1, a.out_scale, hi, lo);
+              char* sp = srow + split16_pos(col >> 1) * 2;
+              *reinterpret_cast<unsigned*>(sp) = hi;
+              *reinterpret_cast<unsigned*>(sp + 64) = lo;
+            } else if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f);
             else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
+          } else if constexpr (SPOUT) {
+            unsigned h01, l01, h23, l23;
+            split16_pack2(v0, v1, a.out_scale, h01, l01);
+            split16_pack2(v2, v3, a.out_scale, h23, l23);
+            char* sp = srow + split16_pos(col) * 2;
+            *reinterpret_cast<uint2*>(sp) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(sp + 64) = make_uint2(l01, l23);
           } else if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
           else if constexpr (F8OUT) *reinterpret_cast<unsigned*>(srow + col) = pack_fp8x4(v0 * a.out_scale, v1 * a.out_scale, v2 * a.out_scale, v3 * a.out_scale);
           else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
@@ -373,7 +444,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 16;
           *reinterpret_cast<uint4*>(reinterpret_cast<unsigned char*>(a.out) + orow_it * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
         } else if constexpr (!OUT_F32) {
-          const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) + c * 8;
+          const int ncol = (EPI == GEMM_EPI_SWIGLU_BF16 ? n0 / 2 : n0) * (SPOUT ? 2 : 1) + c * 8;  // split rows: 2 halves per column
           *reinterpret_cast<uint4*>(reinterpret_cast<__bf16*>(a.out) + orow_it * a.ldo + ncol) = *reinterpret_cast<const uint4*>(sp);
         } else {
           float4 v = *reinterpret_cast<const float4*>(sp);
@@ -439,6 +510,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
+          if constexpr (SP) {
+            const float as = a.acc_scale;
+            v0 = fmaf(acc[tm][tn][4 * g + 0], as, bs.x); v1 = fmaf(acc[tm][tn][4 * g + 1], as, bs.y);
+            v2 = fmaf(acc[tm][tn][4 * g + 2], as, bs.z); v3 = fmaf(acc[tm][tn][4 * g + 3], as, bs.w);
+          }
           if constexpr (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16) {
             if constexpr (EPI == GEMM_EPI_GELU_BF16) {
               const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
@@ -474,7 +550,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   }
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   unsigned grid = (a.M / BM) * (a.N / BN);
@@ -491,15 +567,15 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;
-  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>, (int)lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT>, (int)lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
 
 // Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
 // otherwise 128x128 (4 waves, 2 blocks/CU).
-template <int EPI>
+template <int EPI, bool SP = false, bool SPOUT = false>
 int launch(const GemmBf16Args& a, hipStream_t st) {
   const int force = a.tile_override;
   const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
@@ -507,8 +583,8 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   //  hooked block's selected rows, proj 79 -> 67 us, fc2 207 -> 195 us; results do not depend on the tile)
   const int tiles_big = (a.M / 256) * (a.N / 256), cus = fp_num_cus();
   const bool use_big = big_ok && (force == 256 || (force == 0 && tiles_big >= cus && !(tiles_big > cus && tiles_big < cus + cus / 2)));
-  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4>(a, st);
-  return launch_cfg<EPI, 128, 128, 2, 2>(a, st);
+  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+  return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
 }
 
 }  // namespace
@@ -536,6 +612,31 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
     case GEMM_EPI_SWIGLU_BF16: return launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true>(a, st);
   }
   fp_set_error("gemm_fp8: epilogue %d is not available for fp8 operands", epi);
+  return FP_ERR_UNSUPPORTED;
+}
+
+// split-fp16 operands (f16x3 mode): a.K is the LOGICAL K; the kernel walks rows of 2K halves
+int gemm_split_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
+  GemmBf16Args a = a_in;
+  FP_REQUIRE(a.M > 0 && a.M % 128 == 0 && a.N > 0 && a.N % 128 == 0, "gemm_split: M (%d) and N (%d) must be positive multiples of 128", a.M, a.N);
+  FP_REQUIRE(a.K > 0 && a.K % 32 == 0, "gemm_split: K (%d) must be a multiple of 32", a.K);
+  FP_REQUIRE(a.bias != nullptr, "gemm_split: bias is required (pass zeros)");
+  FP_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= 2 * a.K && a.ldw >= 2 * a.K, "gemm_split: operand rows are 2K halves, 16-byte aligned");
+  FP_REQUIRE(a.acc_scale > 0.f, "gemm_split: acc_scale must be positive");
+  const bool half_out = epi == GEMM_EPI_BIAS_BF16 || epi == GEMM_EPI_GELU_BF16 || epi == GEMM_EPI_SWIGLU_BF16;
+  FP_REQUIRE(!half_out || (a.out_scale > 0.f && a.ldo % 8 == 0), "gemm_split: a split-fp16 output needs out_scale > 0 and ldo %% 8 == 0");
+  FP_REQUIRE(half_out || a.ldo % 4 == 0, "gemm_split: ldo must keep 16-byte alignment");
+  FP_REQUIRE(epi != GEMM_EPI_LS_RESID_F32 || a.gamma, "gemm_split: gamma required");
+  a.K *= 2;  // halves per row (hi + lo): one 64-half K-tile = 32 logical k
+  switch (epi) {
+    case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16, true, true>(a, st);
+    case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16, true, true>(a, st);
+    case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16, true, true>(a, st);
+    case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32, true, false>(a, st);
+    case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32, true, false>(a, st);
+    case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32, true, false>(a, st);
+  }
+  fp_set_error("gemm_split: epilogue %d is not available for split-fp16 operands", epi);
   return FP_ERR_UNSUPPORTED;
 }
 

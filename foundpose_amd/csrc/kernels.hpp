@@ -108,7 +108,8 @@ struct GemmBf16Args {
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
   int tile_override;          // 0 = auto, 128 / 256 = force that block tile (benchmarks, tests)
   unsigned rast_r, rast_gn;
-  float out_scale;            // fp8 kernels: > 0 -> the GELU / SwiGLU result leaves as e4m3(value * out_scale) bytes
+  float out_scale;            // fp8 kernels: > 0 -> the GELU / SwiGLU result leaves as e4m3(value * out_scale) bytes; f16x3: scale of a split-fp16 output
+  float acc_scale;            // f16x3 kernels: out = epi(acc * acc_scale + bias), acc_scale = 1 / (scale of A x scale of W)
   unsigned long long* dbg;    // optional [grid, 4] shader-clock stamps: start, prologue done, main loop done, epilogue drained
   // ---- LayerNorm folded into the GEMMs around it (bf16 ViT blocks, vit forward only):
   // producer (LS_RESID): besides the fp32 residual stream it writes xb = bf16(x) -- the next GEMM's A operand -- and per
@@ -122,10 +123,14 @@ struct GemmBf16Args {
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
+// f16x3 mode: A [M, 2K] and W [N, 2K] split-fp16 rows (common.hpp) behind the __bf16 pointers, a.K = the logical K (multiple of 32),
+// lda / ldw in halves; out = epi(acc * a.acc_scale + bias); the BIAS / GELU (exact erf) / SwiGLU epilogues write split-fp16 rows
+// again ([M, 2N] halves, values scaled by a.out_scale), LS_RESID / TOKENS / BIAS_F32 write fp32
+int gemm_split_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
 
 // ---------------------------------------------------------------- dtypes of the C ABI
-enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2 };
+enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2, FP_DTYPE_F16X3 = 3 };
 
 // ---------------------------------------------------------------- attn.hip
 struct AttnArgs {
@@ -140,6 +145,7 @@ struct AttnArgs {
   // bf16 work split (bit-identical outputs): 0 = 64 queries per wave, K/V by LDS-DMA (default); 1 = 32 queries per wave, register
   // staging (the cross-check); 2 = the DMA kernel with one 32-query block per wave, 8 waves per 256-query block
   int variant;
+  float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 
@@ -167,7 +173,7 @@ int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, i
 int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st);
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
-                    int out_dtype, hipStream_t st);
+                    int out_dtype, hipStream_t st, float out_scale = 1.f);  // out_scale: FP_DTYPE_F16X3 rows only
 int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
 int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st);

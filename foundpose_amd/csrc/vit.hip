@@ -74,6 +74,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
           if constexpr (VEC == 4)
             *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.out) + (size_t)row * a.ld_out + c) =
                 pack_fp8x4(y[0] * a.out_scale, y[1] * a.out_scale, y[2] * a.out_scale, y[3] * a.out_scale);
+        } else if (a.out_dtype == FP_DTYPE_F16X3) {  // split-fp16 row (common.hpp): the next GEMM's A operand in the f16x3 mode
+          _Float16* o = reinterpret_cast<_Float16*>(a.out) + (size_t)row * a.ld_out + split16_pos(c);
+          unsigned h01, l01;
+          split16_pack2(y[0], y[1], a.out_scale, h01, l01);
+          if constexpr (VEC == 4) {
+            unsigned h23, l23;
+            split16_pack2(y[2], y[3], a.out_scale, h23, l23);
+            *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
+            *reinterpret_cast<uint2*>(o + 32) = make_uint2(l01, l23);
+          } else {
+            *reinterpret_cast<unsigned*>(o) = h01;
+            *reinterpret_cast<unsigned*>(o + 32) = l01;
+          }
         } else if (a.out_dtype == FP_DTYPE_BF16) {
           __bf16* o = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c;
           if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
@@ -231,8 +244,10 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
 // a per-workgroup x -> (gx, px) table (no per-pixel division); the gw output rows then leave as whole 16-byte chunks.
 // (History: one thread per element 120 us, one per 14-pixel run 117 us, a strip in input layout with index divisions in
 //  both phases 92 us.)
-template <typename T>
-__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld) {
+// SPLIT (f16x3 mode): T = _Float16 and a row is the split-fp16 image (common.hpp) of the normalised pixels times `scale`; ld = 2 x
+// the padded column count.
+template <typename T, bool SPLIT = false>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte chunk
   const int gw = W / P, gh = H / P, lds_ld = ld + V;  // + one chunk per row: the patches' rows start in different banks
@@ -244,10 +259,17 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
     const int gx = x / P;
     xtab[x] = (unsigned short)((gx << 8) | (x - gx * P));
   }
-  const int pad = ld - ncols;  // zero columns behind the pixels
-  for (int id = tid; id < gw * pad; id += 256) {
-    const int gx = id / pad;
-    tile[(size_t)gx * lds_ld + ncols + (id - gx * pad)] = (T)0.f;
+  if constexpr (SPLIT) {  // hi and lo halves of the padding columns are scattered over the row: clear all of it
+    for (int id = tid; id < gw * ld; id += 256) {
+      const int gx = id / ld;
+      tile[(size_t)gx * lds_ld + (id - gx * ld)] = (T)0.f;
+    }
+  } else {
+    const int pad = ld - ncols;  // zero columns behind the pixels
+    for (int id = tid; id < gw * pad; id += 256) {
+      const int gx = id / pad;
+      tile[(size_t)gx * lds_ld + ncols + (id - gx * pad)] = (T)0.f;
+    }
   }
   __syncthreads();
   const float* img_b = img + (size_t)b * 3 * H * W;
@@ -278,7 +300,16 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
           const int x = xb + lane + 64 * i;
           if (x < W) {
             const unsigned t = xtab[x];
-            tile[(size_t)(t >> 8) * lds_ld + r * P + (t & 255u)] = (T)((v[h][i] - mean) / stdv);  // T.Normalize: sub then div
+            const float nv = (v[h][i] - mean) / stdv;  // T.Normalize: sub then div
+            if constexpr (SPLIT) {
+              const float sv = nv * scale;
+              const _Float16 hi = (_Float16)sv;
+              T* d = tile + (size_t)(t >> 8) * lds_ld + split16_pos(r * P + (int)(t & 255u));
+              d[0] = hi;
+              d[32] = (_Float16)(sv - (float)hi);
+            } else {
+              tile[(size_t)(t >> 8) * lds_ld + r * P + (t & 255u)] = (T)nv;
+            }
           }
         }
       }
@@ -466,6 +497,8 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   const int grid = wgs < 2048 ? wgs : 2048;  // 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
   FP_REQUIRE(a.out_dtype != FP_DTYPE_FP8 || (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0 && a.out_scale > 0.f),
              "layernorm: fp8 output needs dim %% 256 == 0 and a positive scale");
+  FP_REQUIRE(a.out_dtype != FP_DTYPE_F16X3 || (a.ld_out >= 2 * a.dim && a.ld_out % 4 == 0 && a.out_scale > 0.f),
+             "layernorm: a split-fp16 output row is 2 * dim halves and needs a positive scale");
   if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0)
     hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, st, a);
   else
@@ -515,22 +548,27 @@ int ln_sample_launch(const float* x, int ld_x, const float* weight, const float*
 }
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
-                    int out_dtype, hipStream_t st) {
+                    int out_dtype, hipStream_t st, float out_scale) {
   FP_REQUIRE(height % patch == 0 && width % patch == 0, "patchify: image %dx%d is not a multiple of the patch size %d", height, width, patch);
   FP_REQUIRE(ld_out >= 3 * patch * patch, "patchify: ld_out too small");
   const unsigned grid = (unsigned)(batch * (height / patch));  // one workgroup per row of patches
   if (grid == 0) return FP_OK;
-  const size_t esz = out_dtype == FP_DTYPE_BF16 ? 2 : 4;
+  const bool split = out_dtype == FP_DTYPE_F16X3;  // ld_out = halves per row = 2 x the padded column count (a multiple of 32)
+  FP_REQUIRE(!split || (ld_out % 64 == 0 && ld_out >= 2 * ((3 * patch * patch + 31) / 32 * 32)), "patchify: a split-fp16 row is 2 x the columns padded to 32");
+  const size_t esz = out_dtype == FP_DTYPE_F32 ? 4 : 2;
   FP_REQUIRE(ld_out % (16 / esz) == 0, "patchify: ld_out must keep 16-byte rows");
   const size_t lds = (size_t)(width / patch) * (ld_out + 16 / esz) * esz + (size_t)width * 2;  // the row of patches in output layout + the x table
   FP_REQUIRE(lds <= 160 * 1024 && patch <= 255 && width / patch <= 255, "patchify: a row of patches (%d x %d columns) does not fit LDS", width / patch, ld_out);
-  static FpDeviceOnce attr_b, attr_f;
+  static FpDeviceOnce attr_b, attr_f, attr_s;
   fp_allow_dynamic_lds(attr_b, &patchify_kernel<__bf16>, 160 * 1024);
   fp_allow_dynamic_lds(attr_f, &patchify_kernel<float>, 160 * 1024);
-  if (out_dtype == FP_DTYPE_BF16)
-    hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out);
+  fp_allow_dynamic_lds(attr_s, &patchify_kernel<_Float16, true>, 160 * 1024);
+  if (split)
+    hipLaunchKernelGGL((patchify_kernel<_Float16, true>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, out_scale);
+  else if (out_dtype == FP_DTYPE_BF16)
+    hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out, 1.f);
   else
-    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out);
+    hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out, 1.f);
   FP_CHECK_LAUNCH("patchify");
   return FP_OK;
 }

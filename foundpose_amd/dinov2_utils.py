@@ -65,8 +65,14 @@ class DinoFeatureExtractor(torch.nn.Module):
             raise NotImplementedError("use_graph replays the token path only")
         if not 0 <= self.layer < self.arch.depth:
             raise ValueError(f"layer {self.layer} out of range for {self.version}")
-        if precision not in ("bf16", "fp32", "fp8"):
-            raise ValueError("precision must be 'bf16', 'fp32' or 'fp8'")
+        if precision not in ("bf16", "fp32", "fp8", "f16x3"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3' or 'fp8'")
+        # "f16x3": the near-exact mode.  The reference computes in fp32 (scripts/infer.py:468-473); the fp32-input MFMA runs at 1/16
+        # of the fp16 rate, so this mode carries every GEMM / attention operand as a (hi, lo) pair of fp16 numbers (22 mantissa
+        # bits) and builds each product from three fp16 MFMAs with fp32 accumulation (include/foundpose_amd.h "split-fp16 rows").
+        # Residual stream, LayerNorm, softmax, GELU (exact erf) stay fp32: features at the fp32 path's own noise level, ~3.5x its speed.
+        if precision == "f16x3" and (self.arch.dim % 128 or self.arch.hidden % 128):
+            raise NotImplementedError(f"precision='f16x3' needs dim and hidden to be multiples of 128 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
         if precision == "fp8" and (self.arch.dim % 256 or self.arch.hidden % 256):
             raise NotImplementedError(f"precision='fp8' needs dim and hidden to be multiples of 256 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
         # fp8 mode (BASELINE config 5): e4m3 block matrices quantised per output channel, GEMM inputs quantised per tensor
@@ -105,6 +111,8 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def _prepare(self, dev: torch.device) -> None:
         a, sd = self.arch, self._sd
+        if self.precision == "f16x3":
+            return self._prepare_split(dev)
         wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
         w: Dict[str, torch.Tensor] = {}
 
@@ -220,6 +228,77 @@ class DinoFeatureExtractor(torch.nn.Module):
         if self.precision == "fp8" and self.act_scales is not None:
             self._to_fp8()
 
+    def _prepare_split(self, dev: torch.device) -> None:
+        """Weights of the f16x3 mode: every matrix as split-fp16 rows of s_w W (s_w a power of two that brings the largest weight
+        to ~2^14: typical weights then sit ~2^11, their lo halves far above the fp16 subnormal range), act_scale = 1 / (s_in s_w)."""
+        from . import ops
+        a, sd = self.arch, self._sd
+        w: Dict[str, torch.Tensor] = {}
+        pad = int(os.environ.get("FP_LD_PAD", "64"))
+        if pad % 8:
+            raise ValueError("FP_LD_PAD must be a multiple of 8")
+        self._ld_pad, self._ld_pad8, self._ld_pad_qkv = pad, 0, 0
+
+        def f32(key):
+            return sd[key].to(dev, torch.float32)
+
+        def vec(key):
+            w[key] = f32(key).reshape(-1).contiguous()
+            return w[key]
+
+        def mat(name, W):  # -> (split rows, scale)
+            sw = ops.pow2_scale(W)
+            w[name] = ops.split16_pack(W, sw, pad)
+            return w[name], sw
+
+        kp = 3 * a.patch * a.patch
+        kpad = (kp + 63) // 64 * 64
+        pw = torch.zeros(a.dim, kpad, dtype=torch.float32, device=dev)
+        pw[:, :kp] = f32("patch_embed.proj.weight").reshape(a.dim, kp)
+        spw = ops.pow2_scale(pw)
+        w["patch_w"] = ops.split16_pack(pw, spw)
+        vec("patch_embed.proj.bias")
+        vec("norm.weight")
+        vec("norm.bias")
+        blocks = (_lib.VitBlock * a.depth)()
+        S_ACT, S_HID = _lib.SPLIT_SCALE_ACT, _lib.SPLIT_SCALE_HID
+        for i in range(a.depth):
+            p = f"blocks.{i}."
+            b = blocks[i]
+            b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
+            b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))
+            b.ls1, b.ls2 = ptr(vec(p + "ls1.gamma")), ptr(vec(p + "ls2.gamma"))
+            if a.ffn == "mlp":
+                fc1_w, fc1_b = f32(p + "mlp.fc1.weight"), vec(p + "mlp.fc1.bias")
+                fc2_w, fc2_b = f32(p + "mlp.fc2.weight"), vec(p + "mlp.fc2.bias")
+            else:  # SwiGLU: rows of w12 interleaved (x1_j, x2_j) like the other modes
+                w12, b12 = f32(p + "mlp.w12.weight"), f32(p + "mlp.w12.bias")
+                hdn = w12.shape[0] // 2
+                fc1_w = torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1)
+                w[p + "b12i"] = fc1_b = torch.stack([b12[:hdn], b12[hdn:]], 1).reshape(-1).contiguous()
+                fc2_w, fc2_b = f32(p + "mlp.w3.weight"), vec(p + "mlp.w3.bias")
+            mats = [("qkv", f32(p + "attn.qkv.weight"), vec(p + "attn.qkv.bias"), S_ACT), ("proj", f32(p + "attn.proj.weight"), vec(p + "attn.proj.bias"), S_ACT),
+                    ("fc1", fc1_w, fc1_b, S_ACT), ("fc2", fc2_w, fc2_b, S_HID)]
+            for j, (field, W, bias, s_in) in enumerate(mats):
+                ws_, sw = mat(p + field + ".split", W)
+                setattr(b, field + "_w", ptr(ws_))
+                setattr(b, field + "_b", ptr(bias))
+                b.act_scale[j] = 1.0 / (s_in * sw)
+        m = _lib.VitModel()
+        m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
+        m.ffn_swiglu = int(a.ffn != "mlp")
+        m.weight_dtype = _lib.FP_F16X3
+        m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
+        m.patch_acc_scale = 1.0 / (S_ACT * spw)
+        m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
+        m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
+        m.ld_w_dim, m.ld_w_hidden = (2 * a.dim + pad, 2 * a.hidden + pad) if pad else (0, 0)
+        m.ln_fold = 0
+        self._w, self._model, self._blocks, self._device = w, m, blocks, dev
+        self._grids.clear()
+        self._ws.clear()
+        self._graphs.clear()
+
     def _grid_tables(self, gh: int, gw: int):
         key = (gh, gw)
         if key not in self._grids:
@@ -236,16 +315,18 @@ class DinoFeatureExtractor(torch.nn.Module):
         key = (B, gh, gw, torch.cuda.current_stream().cuda_stream)  # one workspace per stream: concurrent sub-batches
         if key not in self._ws:
             a, dev = self.arch, self._device
-            adt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+            sp = self.precision == "f16x3"
+            adt = torch.float32 if self.precision == "fp32" else (torch.float16 if sp else torch.bfloat16)
+            em = 2 if sp else 1  # stored elements per logical element of an operand row (split rows: hi + lo halves)
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
             m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
             mp_pad = (B * np_ + 255) // 256 * 256
             bufs = [
-                torch.zeros(mp_pad, self._model.patch_k_pad, dtype=adt, device=dev),
+                torch.zeros(mp_pad, em * self._model.patch_k_pad, dtype=adt, device=dev),
                 torch.zeros(m_pad, a.dim, dtype=torch.float32, device=dev),
-                torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev),
-                torch.zeros(m_pad, 3 * a.dim + self._ld_pad_qkv, dtype=adt, device=dev),
-                torch.zeros(m_pad, a.hidden + self._ld_pad, dtype=adt, device=dev),
+                torch.zeros(m_pad, em * a.dim + self._ld_pad, dtype=adt, device=dev),
+                torch.zeros(m_pad, em * 3 * a.dim + self._ld_pad_qkv, dtype=adt, device=dev),
+                torch.zeros(m_pad, em * a.hidden + self._ld_pad, dtype=adt, device=dev),
             ]
             if self.precision == "fp8":
                 p8 = self._ld_pad8
@@ -257,10 +338,10 @@ class DinoFeatureExtractor(torch.nn.Module):
                 ws.xb, ws.stats = ptr(bufs[-2]), ptr(bufs[-1])
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
             ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
-            ws.ld_y, ws.ld_h = (a.dim + self._ld_pad, a.hidden + self._ld_pad) if self._ld_pad else (0, 0)
+            ws.ld_y, ws.ld_h = (em * a.dim + self._ld_pad, em * a.hidden + self._ld_pad) if self._ld_pad else (0, 0)
             if self.precision == "fp8" and self._ld_pad8:  # byte strides of a8 and of the hidden bytes kept in h
                 ws.ld_y, ws.ld_h = a.dim + self._ld_pad8, a.hidden + self._ld_pad8
-            ws.ld_qkv = 3 * a.dim + self._ld_pad_qkv
+            ws.ld_qkv = em * 3 * a.dim + self._ld_pad_qkv
             ws.m_pad, ws.m_patch_pad = m_pad, mp_pad
             self._ws[key] = (ws, bufs)
         return self._ws[key]
@@ -360,7 +441,10 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, bufs = self._workspace(B, gh, gw)
         call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
         ntok, fi = 1 + a.registers + gh * gw, {"query": 0, "key": 1, "value": 2}[self.facet]
-        f = bufs[3][:B * ntok, fi * a.dim:(fi + 1) * a.dim].float()
+        if self.precision == "f16x3":  # split rows (hi + lo halves, scale FP_SPLIT_SCALE_QKV) -> fp32
+            f = ops.split16_unpack(bufs[3][:B * ntok, fi * 2 * a.dim:(fi + 1) * 2 * a.dim].contiguous(), _lib.SPLIT_SCALE_QKV)
+        else:
+            f = bufs[3][:B * ntok, fi * a.dim:(fi + 1) * a.dim].float()
         f = f.reshape(B, ntok, a.heads, a.head_dim).permute(0, 1, 3, 2).reshape(B, ntok, a.dim)
         tok = torch.cat([f[:, :1], f[:, 1 + a.registers:]], dim=1)
         if self.apply_norm:

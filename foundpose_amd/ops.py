@@ -214,3 +214,72 @@ def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, v
     call("fp_attention", ptr(qkv), qkv.stride(0), ptr(out), dim,
          batch, n_tok, dim, heads, (_lib.FP_BF16 if bf else _lib.FP_F32) | (int(variant) << 8), stream())
     return out
+
+
+# ---------------------------------------------------------------- split-fp16 rows (the f16x3 near-exact mode, include/foundpose_amd.h)
+def pow2_scale(t: torch.Tensor, target: float = 16384.0) -> float:
+    """Largest power of two s with max|t| * s <= target (16384 leaves a factor 4 of head room below the fp16 maximum)."""
+    import math
+    amax = float(t.abs().max())
+    if not math.isfinite(amax) or amax <= 0.0:
+        return 1.0
+    return float(2.0 ** math.floor(math.log2(target / amax)))
+
+
+def split16_pack(x: torch.Tensor, scale: float = 1.0, pad: int = 0) -> torch.Tensor:
+    """fp32 [rows, K] (K % 32 == 0) -> fp16 [rows, 2K] split rows (groups of 32: [hi 32 | lo 32]) of scale * x; `pad` extra halves of row
+    stride (the returned tensor is then a view of a wider buffer).  Host-side preparation of weights and test operands; inside the
+    pipeline the producing kernels write this layout themselves."""
+    rows, K = x.shape
+    if K % 32:
+        raise ValueError("split16_pack: the row length must be a multiple of 32")
+    xs = (x.float() * scale).clamp(-65504.0, 65504.0)
+    hi = xs.half()
+    lo = (xs - hi.float()).half()
+    out = torch.stack([hi.reshape(rows, K // 32, 32), lo.reshape(rows, K // 32, 32)], 2).reshape(rows, 2 * K)
+    if pad == 0:
+        return out.contiguous()
+    buf = torch.zeros(rows, 2 * K + pad, dtype=torch.float16, device=x.device)
+    buf[:, :2 * K] = out
+    return buf[:, :2 * K]
+
+
+def split16_unpack(xs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """Inverse of split16_pack (up to its 2^-22 rounding): fp16 [rows, 2K] -> fp32 [rows, K] = (hi + lo) / scale (summed in fp64)."""
+    rows, K2 = xs.shape
+    g = xs.reshape(rows, K2 // 64, 2, 32).double()
+    return ((g[:, :, 0] + g[:, :, 1]) / scale).reshape(rows, K2 // 2).float()
+
+
+def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: float, gamma=None, out=None, epilogue: int = 0,
+               out_scale: float = 1.0, m_valid: Optional[int] = None, tile: int = 0) -> torch.Tensor:
+    """a [M, 2K], w [N, 2K] split rows (fp16); -> epilogue 0 / 1 / 6: split rows [M, 2N] (6: [M, N]) scaled by out_scale; 3 / 5: fp32 [M, N]."""
+    require_cuda(a, w, bias)
+    if a.dtype != torch.float16 or w.dtype != torch.float16:
+        raise ValueError("gemm_split operands are fp16 split rows")
+    M, K = a.shape[0], a.shape[1] // 2
+    N = w.shape[0]
+    if out is None:
+        if epilogue in (3, 5):
+            out = torch.zeros(M, N, dtype=torch.float32, device=a.device)
+        else:
+            out = torch.zeros(M, N if epilogue == 6 else 2 * N, dtype=torch.float16, device=a.device)
+    call("fp_gemm_split", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(gamma),
+         ptr(out), out.stride(0), epilogue | (tile << 8), float(acc_scale), float(out_scale), stream())
+    return out
+
+
+def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float) -> torch.Tensor:
+    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows."""
+    require_cuda(qkv)
+    out = torch.zeros(qkv.shape[0], 2 * dim, dtype=torch.float16, device=qkv.device)
+    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale), float(out_scale), stream())
+    return out
+
+
+def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_scale: float, eps: float = 1e-6) -> torch.Tensor:
+    require_cuda(x, weight, bias)
+    rows, D = x.shape
+    out = torch.empty(rows, 2 * D, dtype=torch.float16, device=x.device)
+    call("fp_layernorm_scaled", ptr(x), x.stride(0), ptr(weight), ptr(bias), eps, ptr(out), 2 * D, _lib.FP_F16X3, float(out_scale), D, rows, stream())
+    return out

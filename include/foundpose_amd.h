@@ -24,9 +24,22 @@ extern "C" {
 
 typedef void* fp_stream_t; /* hipStream_t */
 
-enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only) */
+enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only;
+                                                               FP_F16X3: split-fp16 rows, see below) */
 
-#define FP_ABI_VERSION 11
+/* ---- split-fp16 rows (the "f16x3" near-exact mode) --------------------------------------------------------------------
+ * The reference computes the backbone in fp32 (scripts/infer.py:468-473).  The fp32-input MFMA runs at 1/16 of the fp16 /
+ * bf16 rate on this part, so the near-exact mode carries every GEMM / attention operand as a PAIR of fp16 numbers and builds
+ * each product from three fp16 MFMAs with fp32 accumulation: x ~ (hi + lo) / s, hi = f16(s x), lo = f16(s x - hi) (22 mantissa
+ * bits; s a power of two that places typical magnitudes well inside the fp16 normal range, saturation at +-65504), and
+ * a b = hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo lo term is <= 2^-22 relative).
+ * Storage: a logical row of K values (K % 32 == 0) is 2K halves: group g = k / 32 holds hi(x[32g .. 32g + 31]) in halves
+ * [64g, 64g + 32) and lo(...) in [64g + 32, 64g + 64).  Fixed scales of the activation rows inside fp_vit_forward: */
+#define FP_SPLIT_SCALE_ACT 128.f /* LayerNorm outputs, attention outputs, normalised pixels of the patch rows */
+#define FP_SPLIT_SCALE_QKV 64.f  /* q, k, v rows written by the qkv GEMM */
+#define FP_SPLIT_SCALE_HID 64.f  /* hidden activations written by the GELU / SwiGLU epilogue */
+
+#define FP_ABI_VERSION 12
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -145,6 +158,9 @@ typedef struct {
    * act_scale[0..3] quantise the inputs of qkv, proj, fc1, fc2 (static per-tensor scales from a calibration batch) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s;
   float act_scale[4];
+  /* weight_dtype == FP_F16X3: the four matrices are split-fp16 rows ([N, 2K] halves) of s_w W with a power-of-two s_w per
+   * matrix, and act_scale[0..3] = 1 / (scale of the GEMM's input rows x s_w) for qkv, proj, fc1, fc2: the epilogue computes
+   * acc * act_scale + bias.  ls1 / ls2 are applied as usual. */
   /* fp_vit_model.ln_fold only: fp32 [N] sums of the rows of the (gain-folded, bf16-rounded) qkv_w / fc1_w */
   const float *qkv_colsum, *fc1_colsum;
 } fp_vit_block;
@@ -165,6 +181,7 @@ typedef struct {
   int ld_w_dim, ld_w_hidden;  /* row strides (elements) of the block matrices with K = dim (qkv, proj, fc1) and with
                                  K = hidden (fc2); 0 = dense (dim / hidden).  A stride that is not a multiple of 2 KiB
                                  keeps the 8 rows of a staging instruction off one L2 channel */
+  float patch_acc_scale;   /* FP_F16X3 only: 1 / (FP_SPLIT_SCALE_ACT x scale of the split patch_w [D, 2 * patch_k_pad]) */
   int ln_fold;             /* FP_BF16 only.  1: the two LayerNorms of a block are folded into the GEMMs around them -- no
                               LayerNorm kernel runs inside the blocks.  qkv_w / fc1_w then hold W * diag(ln weight) (bf16),
                               qkv_b / fc1_b hold b + W ln_bias, *_colsum the row sums of those matrices; proj_w / fc2_w hold
@@ -279,6 +296,18 @@ int fp_ln_finalize(const float* stats, int parts, int stats_stride, int rows, in
 int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                 const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream);
 /* out[i] = e4m3(clamp(in[i] * scale, +-448)), round to nearest even; in fp32 or bf16 (in_dtype FP_F32 / FP_BF16) */
+/* Split-fp16 GEMM (f16x3): A [M, 2K] and W [N, 2K] halves (split rows, scales s_a and s_w), K the LOGICAL depth (multiple of 32),
+ * lda / ldw in halves.  v = acc * acc_scale + bias with acc_scale = 1 / (s_a s_w), then the epilogue numbered as for
+ * fp_gemm_bf16: 0 (bias), 1 (GELU, the exact erf form here) and 6 (SwiGLU) write a split row again ([M, 2N] -- SwiGLU: [M, N] --
+ * halves, values x out_scale, ldo in halves); 3 (out += gamma v) and 5 (bias) write fp32. */
+int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
+                  void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
+/* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, scale in_scale) -> out [B*N, 2D] halves (scale out_scale) */
+int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
+                       fp_stream_t stream);
+/* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes) or FP_F16X3 (split row of y * out_scale) */
+int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out, int out_dtype, float out_scale,
+                        int dim, int out_rows, fp_stream_t stream);
 int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream);
 /* exact-fp32 MFMA GEMM; epilogue: 0 store, 4 bias, 5 bias+gelu, 6 LayerScale residual, 8 SwiGLU (as above) */
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,

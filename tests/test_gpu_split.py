@@ -1,0 +1,210 @@
+"""The near-exact "f16x3" mode (split-fp16 operands, three fp16 MFMAs per product, fp32 accumulation): each kernel against an fp64
+reference of the SAME fp32 operation at fp32-level tolerances, then the extractor against the CPU oracle and against the
+library's exact-fp32 mode.  What it stands in for: the reference's fp32 backbone arithmetic (/root/reference/scripts/infer.py:468-473
+through utils/dinov2_utils.py:257) at ~3.5x the speed of the fp32-input MFMA path."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from foundpose_amd import _lib, ops, synthetic
+from foundpose_amd.vit_config import ARCHS, VitArch
+from oracle import vit as ov
+
+pytestmark = pytest.mark.gpu
+
+
+def rel_err(a, b):
+    return float((a.double() - b.double()).abs().max() / b.double().abs().max())
+
+
+def test_split16_pack_unpack_round_trip_and_layout():
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(7, 96, generator=g) * torch.logspace(-4, 3, 96)[None, :]).cuda()
+    s = ops.pow2_scale(x)
+    assert s == 2.0 ** math.floor(math.log2(16384.0 / float(x.abs().max())))
+    p = ops.split16_pack(x, s)
+    assert p.shape == (7, 192) and p.dtype == torch.float16
+    # group g of 32 columns = halves [64 g, 64 g + 32) hi, [64 g + 32, 64 g + 64) lo
+    hi = (x * s).half()
+    assert torch.equal(p[:, 64:96], hi[:, 32:64]) and torch.equal(p[:, 96:128], ((x * s) - hi.float()).half()[:, 32:64])
+    back = ops.split16_unpack(p, s)
+    big = x.abs() * s > 0.25      # lo is a normal fp16 number there: 22 mantissa bits
+    assert float(((back - x).abs() / x.abs())[big].max()) < 2.0 ** -21
+    assert float((back - x).abs()[~big].max()) * s <= 2.0 ** -24   # below: the fp16 subnormal spacing (absolute)
+    padded = ops.split16_pack(x, s, pad=64)
+    assert padded.stride(0) == 192 + 64 and torch.equal(padded, p)
+
+
+def test_mfma_f16_subnormal_inputs_are_honoured():
+    """Hardware fact the scales of the mode do not depend on (they keep lo halves normal) but worth pinning: fp16 subnormal MFMA inputs
+    are multiplied, not flushed."""
+    M, K, N = 256, 64, 128
+    a = torch.full((M, K), 2.0 ** -20, device="cuda")          # fp16 subnormal (min normal 2^-14), exactly representable
+    w = torch.full((N, K), 1024.0, device="cuda")
+    out = ops.gemm_split(ops.split16_pack(a), ops.split16_pack(w), torch.zeros(N, device="cuda"), 1.0, epilogue=5)
+    want = K * 2.0 ** -20 * 1024.0
+    assert torch.allclose(out, torch.full_like(out, want), rtol=1e-6), f"subnormal operands flushed? got {float(out[0, 0])}, want {want}"
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(256, 256, 1024, 256), (256, 384, 96, 128), (512, 1024, 4096, 0), (128, 128, 32, 0)])
+def test_gemm_split_fp32_epilogue_vs_fp64(M, N, K, tile):
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g, device="cuda") * 1.7
+    a[:, 3] *= 40.0                                                     # an outlier channel, as LayerNorm outputs have
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.02
+    bias = torch.randn(N, generator=g, device="cuda")
+    sa, sw = 128.0, ops.pow2_scale(w)
+    out = ops.gemm_split(ops.split16_pack(a, sa), ops.split16_pack(w, sw, pad=64), bias, 1.0 / (sa * sw), epilogue=5, tile=tile)
+    ref = a.double() @ w.double().T + bias.double()
+    mag = a.double().abs() @ w.double().abs().T                         # sum |a_k w_k|: what a rounding error scales with
+    err = float(((out.double() - ref).abs() / mag).max())
+    # per-product error <= ~3 * 2^-22, plus the fp32 accumulation of K terms; the bf16 path sits at 2^-8
+    assert err < 2.0 ** -20, err
+    exact32 = ops.gemm_f32(a, w, bias, epilogue=4)                      # the exact-fp32 MFMA path (k-ascending fmaf chains)
+    err32 = float(((exact32.double() - ref).abs() / mag).max())
+    assert err < 4 * err32 + 2.0 ** -23, (err, err32)                   # same league as fp32 arithmetic itself
+
+
+@pytest.mark.parametrize("tile", [128, 256])
+def test_gemm_split_epilogues(tile):
+    g = torch.Generator(device="cuda").manual_seed(tile)
+    M, K, N, mv = 512, 256, 512, 391
+    a = torch.randn(M, K, generator=g, device="cuda")
+    w = torch.randn(N, K, generator=g, device="cuda") * 0.05
+    bias = torch.randn(N, generator=g, device="cuda") * 0.3
+    gamma = torch.rand(N, generator=g, device="cuda") + 0.5
+    sa, sw = 128.0, ops.pow2_scale(w)
+    A, W = ops.split16_pack(a, sa), ops.split16_pack(w, sw)
+    lin = a.double() @ w.double().T + bias.double()
+    # 0: bias -> split rows (scale 64), padding rows untouched
+    o0 = ops.gemm_split(A, W, bias, 1.0 / (sa * sw), epilogue=0, out_scale=64.0, m_valid=mv, tile=tile)
+    assert o0.shape == (M, 2 * N) and rel_err(ops.split16_unpack(o0[:mv], 64.0), lin[:mv]) < 2e-6
+    assert not bool(o0[mv:].any())
+    # 1: exact-erf GELU -> split rows
+    o1 = ops.gemm_split(A, W, bias, 1.0 / (sa * sw), epilogue=1, out_scale=64.0, tile=tile)
+    assert rel_err(ops.split16_unpack(o1, 64.0), torch.nn.functional.gelu(lin)) < 2e-6
+    # 6: SwiGLU on interleaved columns -> split rows [M, N/2 logical]
+    o6 = ops.gemm_split(A, W, bias, 1.0 / (sa * sw), epilogue=6, out_scale=64.0, tile=tile)
+    sw_ref = torch.nn.functional.silu(lin[:, 0::2]) * lin[:, 1::2]
+    assert o6.shape == (M, N) and rel_err(ops.split16_unpack(o6, 64.0), sw_ref) < 2e-6
+    # 3: x += gamma * (.) in place on the fp32 stream
+    x0 = torch.randn(M, N, generator=g, device="cuda")
+    x = x0.clone()
+    ops.gemm_split(A, W, bias, 1.0 / (sa * sw), gamma=gamma, out=x, epilogue=3, m_valid=mv, tile=tile)
+    assert rel_err(x[:mv], x0[:mv].double() + gamma.double() * lin[:mv]) < 2e-6 and torch.equal(x[mv:], x0[mv:])
+
+
+def test_gemm_split_saturates_instead_of_overflowing():
+    """A value beyond 65504 / scale cannot be represented in the fp16 pair: it saturates (finite), it never becomes inf / NaN."""
+    M, K, N = 128, 32, 128
+    a = torch.zeros(M, K, device="cuda")
+    a[:, 0] = 1.0
+    w = torch.zeros(N, K, device="cuda")
+    w[:, 0] = 5000.0
+    out = ops.gemm_split(ops.split16_pack(a), ops.split16_pack(w, 1.0), torch.zeros(N, device="cuda"), 1.0, epilogue=0, out_scale=64.0)
+    v = ops.split16_unpack(out, 64.0)
+    assert bool(torch.isfinite(out.float()).all()) and torch.allclose(v, torch.full_like(v, 65504.0 / 64.0), rtol=1e-3)
+
+
+def test_layernorm_split_vs_torch():
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for D in (384, 1024):
+        x = torch.randn(300, D, generator=g, device="cuda") * 3 + 0.5
+        wt, b = torch.rand(D, generator=g, device="cuda") + 0.5, torch.randn(D, generator=g, device="cuda") * 0.1
+        got = ops.split16_unpack(ops.layernorm_split(x, wt, b, 128.0), 128.0)
+        ref = torch.nn.functional.layer_norm(x.double(), (D,), wt.double(), b.double(), 1e-6)
+        exact = ops.layernorm(x, wt, b, torch.float32)
+        assert rel_err(got, ref) < 2 * rel_err(exact, ref) + 2.0 ** -21
+
+
+def _ref_attention(q, k, v, B, N, heads):
+    """q, k, v fp64 [B*N, D] -> softmax(q k^T / 8) v, [B*N, D]"""
+    D = q.shape[1]
+    sh = lambda t: t.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
+    p = torch.softmax(sh(q) @ sh(k).transpose(-1, -2) * 0.125, dim=-1)
+    return (p @ sh(v)).permute(0, 2, 1, 3).reshape(B * N, D)
+
+
+@pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 4), (3, 905, 2), (1, 256, 1), (2, 257, 3), (1, 64, 16)])
+def test_attention_split_vs_fp64(B, N, heads):
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(N + heads)
+    qkv = torch.randn(B * N, 3 * D, generator=g, device="cuda") * 1.5
+    qkv[:, 5] *= 6.0   # a dominant q dimension: peaked softmax rows
+    packed = torch.cat([ops.split16_pack(qkv[:, i * D:(i + 1) * D].contiguous(), 64.0) for i in range(3)], dim=1)
+    out = ops.split16_unpack(ops.attention_split(packed, B, N, D, heads, 64.0, 128.0), 128.0)
+    q, k, v = (qkv[:, i * D:(i + 1) * D].double() for i in range(3))
+    ref = _ref_attention(q, k, v, B, N, heads)
+    o32 = ops.attention(qkv, B, N, D, heads)   # the fp32 VALU kernel of the exact mode
+    e, e32 = rel_err(out, ref), rel_err(o32, ref)
+    assert e < 5e-6 and e < 4 * e32 + 1e-6, (e, e32)
+
+
+def test_attention_split_forced_rescale_and_constant_rows():
+    """Online-softmax corner cases: a key late in the sequence that dominates every earlier one (the running max jumps at a chosen
+    tile and everything accumulated so far is rescaled), and all-equal scores (uniform attention)."""
+    B, N, heads, D = 1, 300, 1, 64
+    g = torch.Generator(device="cuda").manual_seed(1)
+    qkv = torch.randn(N, 3 * D, generator=g, device="cuda")
+    qkv[200, D:2 * D] = qkv[7, 0:D] * 4.0          # key 200 aligned with query 7: its score towers over the rest
+    packed = torch.cat([ops.split16_pack(qkv[:, i * D:(i + 1) * D].contiguous(), 64.0) for i in range(3)], dim=1)
+    out = ops.split16_unpack(ops.attention_split(packed, B, N, D, heads, 64.0, 128.0), 128.0)
+    ref = _ref_attention(*(qkv[:, i * D:(i + 1) * D].double() for i in range(3)), B, N, heads)
+    assert rel_err(out, ref) < 5e-6
+    qkv[:, :2 * D] = 0.0                           # q = k = 0: uniform attention -> the mean of v
+    packed = torch.cat([ops.split16_pack(qkv[:, i * D:(i + 1) * D].contiguous(), 64.0) for i in range(3)], dim=1)
+    out = ops.split16_unpack(ops.attention_split(packed, B, N, D, heads, 64.0, 128.0), 128.0)
+    assert rel_err(out, qkv[:, 2 * D:].double().mean(0, keepdim=True).expand(N, D)) < 5e-6
+
+
+TINY = VitArch("tiny-reg", dim=128, depth=3, heads=2, ffn="mlp", hidden=512, registers=4, pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
+TINY_G = VitArch("tinyg-reg", dim=128, depth=2, heads=2, ffn="swiglu", hidden=384, registers=4, pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
+
+
+@pytest.mark.parametrize("arch,layer,size,B", [(TINY, 2, 56, 3), (TINY_G, 1, 70, 2), (ARCHS["vits14-reg"], 9, 224, 2), (ARCHS["vits14-reg"], 9, 420, 1)])
+def test_extractor_f16x3_at_fp32_noise_level(arch, layer, size, B):
+    """Features of the f16x3 mode against the fp32 CPU oracle: as close as the library's exact-fp32 mode is (both carry fp32
+    accumulation noise, in different summation orders), two orders of magnitude closer than the bf16 mode."""
+    from foundpose_amd import feature_util
+    name = f"dinov2_version={arch.name}_stride=14_facet=token_layer={layer}_norm=1"
+    sd = synthetic.make_vit_state_dict(arch, seed=5)
+    imgs = synthetic.make_crops(B, size, seed=2)
+    ref = ov.extractor_forward(sd, arch, imgs, layer, True)
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        ex = feature_util.make_feature_extractor(name, state_dict=sd, arch=arch, precision=prec).to("cuda")
+        o = ex(imgs.cuda())
+        outs[prec] = (o["feature_maps"].cpu(), o["cls_tokens"].cpu())
+    e32, e3 = rel_err(outs["fp32"][0], ref["feature_maps"]), rel_err(outs["f16x3"][0], ref["feature_maps"])
+    assert e3 < 5e-5 and e3 < 3 * e32 + 1e-5, (e3, e32)
+    assert rel_err(outs["f16x3"][1], ref["cls_tokens"]) < 5e-5
+    assert rel_err(outs["f16x3"][0], outs["fp32"][0]) < 5e-5
+
+
+def test_extractor_f16x3_vitl_518_metric_config_and_batch_invariance():
+    """The bench configuration (ViT-L/14-reg, layer 18, 518 x 518): against the oracle on one crop, and crop 3 of a batch of 8 equals
+    that crop run alone bit for bit (a row's arithmetic never depends on the batch)."""
+    from foundpose_amd import feature_util
+    arch = ARCHS["vitl14-reg"]
+    name = "dinov2_version=vitl14-reg_stride=14_facet=token_layer=18_norm=1"
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    imgs = synthetic.make_crops(8, 518, seed=0)
+    ref = ov.extractor_forward(sd, arch, imgs[3:4], 18, True)["feature_maps"]
+    ex = feature_util.make_feature_extractor(name, state_dict=sd, precision="f16x3").to("cuda")
+    one = ex(imgs[3:4].cuda())["feature_maps"].clone()
+    assert rel_err(one.cpu(), ref) < 5e-5
+    batch = ex(imgs.cuda())["feature_maps"]
+    assert torch.equal(batch[3], one[0])
+
+
+def test_extractor_f16x3_facets_vs_fp32_mode():
+    from foundpose_amd import feature_util
+    sd = synthetic.make_vit_state_dict(TINY, seed=9)
+    imgs = synthetic.make_crops(2, 56, seed=4).cuda()
+    for facet in ("key", "query", "value"):
+        name = f"dinov2_version=tiny-reg_stride=14_facet={facet}_layer=2_norm=1"
+        a = feature_util.make_feature_extractor(name, state_dict=sd, arch=TINY, precision="fp32").to("cuda")(imgs)["feature_maps"]
+        b = feature_util.make_feature_extractor(name, state_dict=sd, arch=TINY, precision="f16x3").to("cuda")(imgs)["feature_maps"]
+        assert rel_err(b, a) < 2e-5
