@@ -76,6 +76,10 @@ def main():
     ap.add_argument("--mask", default="disc", choices=["disc", "full"],
                     help="detection masks: the centred disc of radius 0.35 S (SURVEY 8d, the headline) or the full crop (worst case: every patch is a query point)")
     ap.add_argument("--overlap", action="store_true", help="matching of batch i on a second stream beside the backbone of batch i+1 (engine overlap_matching; measured +0.3...0.8 %%, not the default)")
+    ap.add_argument("--parity-precision", default="f16x3", choices=["f16x3", "fp32", "none"],
+                    help="the near-exact mode timed next to the headline as `parity_mode` (f16x3: split-fp16 operands, three fp16 MFMAs per product; "
+                         "fp32: the exact-fp32 MFMA mode) with its index agreement against oracle A and the fp32 mode")
+    ap.add_argument("--parity-steps", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
     ap.add_argument("--cpu-detections", type=int, default=3)
@@ -183,6 +187,18 @@ def main():
                          "note": "the hooked block computes attention queries, proj and the MLP for the patch tokens under the sampling taps of the query "
                                  "points only (keys / values: all tokens); sampled features are bit-identical (tests/test_gpu_vit.py, tests/test_gpu_parity_e2e.py)"})
 
+    # ---- the near-exact mode, driver-timed like the headline (same inputs, same engine code, `--parity-steps` steps after one warm-up)
+    pm = None
+    if args.parity_precision != "none" and args.parity_precision != args.precision:
+        ex_pm = ex32 if args.parity_precision == "fp32" else feature_util.make_feature_extractor(name, seed=1234, precision=args.parity_precision).to(dev)
+        eng_pm = fe.FoundPoseEngine(ex_pm, bank, 14.0, 5, 300, tie_order=args.tie_order)
+        step(eng_pm)
+        el_pm, (_, last_pm) = timed(eng_pm, args.parity_steps)
+        pm = {"precision": args.parity_precision, "value": round(world * B * args.parity_steps / el_pm, 2), "unit": "detections/s",
+              "ms_per_step": round(1e3 * el_pm / args.parity_steps, 3), "steps": args.parity_steps, "n_gpus": world,
+              "what": ("split-fp16 operands (hi + lo: 22 mantissa bits), every product = three fp16 MFMAs with fp32 accumulation, fp32 residual stream / "
+                       "LayerNorm / softmax / exact-erf GELU; all blocks on all tokens" if args.parity_precision == "f16x3"
+                       else "exact-fp32 MFMA GEMMs (k-ascending fmaf chains) + fp32 attention")}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
         M = (B * n_tok + 255) // 256 * 256
@@ -306,12 +322,25 @@ def main():
         parity["pose_vs_planted"] = {"found": int(best["found"].sum()), "max_abs_dR": float(eR.max()), "max_rel_dt": float(et.max()),
                                      "within_1e-4": int(((eR < 1e-4) & (et < 1e-4)).sum()), "pnp_ms_per_batch": round(ms_pnp, 3),
                                      "settings": "400 RANSAC iterations, 10 px, confidence 0.99, LM refinement (configs/infer/lmo.json)"}
+        lists_pm = [last_pm.corresp_list(b) for b in range(B)] if pm is not None else None
+        if pm is not None:
+            pm["planted"] = workload.planted_stats(lists_pm, wl.targets.tolist())
         if not args.no_parity:  # the library's fp32 mode on every detection of the batch (same bank, same tie order)
             eng32 = fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order=args.tie_order)
             res32 = eng32.infer_batch(images, masks, det_obj)
-            parity["vs_fp32_mode"] = workload.parity_stats(lists, [res32.corresp_list(b) for b in range(B)])
+            lists32 = [res32.corresp_list(b) for b in range(B)]
+            parity["vs_fp32_mode"] = workload.parity_stats(lists, lists32)
+            if pm is not None and args.parity_precision != "fp32":
+                pm["vs_fp32_mode"] = workload.parity_stats(lists_pm, lists32)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            result["cpu_baseline"], parity["vs_oracle_a"] = cpu_baseline(arch, args, bank, wl, lists)
+            result["cpu_baseline"], parity["vs_oracle_a"], ora = cpu_baseline(arch, args, bank, wl, lists)
+            if pm is not None:
+                pm["vs_oracle_a"] = workload.parity_stats(lists_pm[:len(ora)], ora)
+        if pm is not None:  # north_star's index bar, stated as booleans next to the mode's throughput
+            pm["index_exact_vs_oracle_a"] = ("vs_oracle_a" in pm and pm["vs_oracle_a"]["corresp_equal"] == pm["vs_oracle_a"]["slots_compared"]
+                                             and pm["vs_oracle_a"]["templates_equal"] == pm["vs_oracle_a"]["detections"]) if "vs_oracle_a" in pm else None
+            pm["index_exact_vs_fp32_mode"] = (pm["vs_fp32_mode"]["corresp_equal"] == pm["vs_fp32_mode"]["slots_compared"]) if "vs_fp32_mode" in pm else None
+            result["parity_mode"] = pm
         result["parity"] = parity
         print(json.dumps(result), flush=True)
     if world > 1:
@@ -362,7 +391,7 @@ def cpu_baseline(arch, args, bank, wl, gpu_lists):
     ora = [baseline.exact_matching(qp.numpy(), qf.numpy(), small, fetch, 5, 300, "torch" if args.tie_order == "torch" else "canonical") for qp, qf in feats]
     par = workload.parity_stats(gpu_lists[:n], ora)
     par["oracle"] = f"oracle A: fp32 CPU features of {n} detection(s) through oracle/match.py (pinned to the reference fixtures), tie order '{args.tie_order}'"
-    return base, par
+    return base, par, ora
 
 
 if __name__ == "__main__":
