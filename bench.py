@@ -36,6 +36,12 @@ PMC_TRAFFIC = {
 PMC_TRAFFIC_SOURCE = "profiles/r2_pmc_traffic.txt (tools/pmc_bench.sh over `python bench.py`, commit 9432c61)"
 
 
+def synthetic_disc_patches(size):
+    """Query patches of the default disc mask (radius 0.35 S)."""
+    from foundpose_amd import synthetic
+    return int(synthetic.make_disc_mask(size)[7::14, 7::14].sum())
+
+
 def vit_flops_per_crop(arch, size, layer):
     np_ = (size // arch.patch) ** 2
     n = 1 + arch.registers + np_
@@ -75,6 +81,8 @@ def main():
                     help="run the hooked block on every token (default: only on the patch tokens the query points sample; same outputs bit for bit)")
     ap.add_argument("--mask", default="disc", choices=["disc", "full"],
                     help="detection masks: the centred disc of radius 0.35 S (SURVEY 8d, the headline) or the full crop (worst case: every patch is a query point)")
+    ap.add_argument("--words", type=int, default=0, help="visual words of the bank (default 2048 = configs/gen_repre/lmo.json; with --mask full 4224, so that the 1369 "
+                                                        "distinct textures of a full crop still get three instance words each, like the headline workload)")
     ap.add_argument("--overlap", action="store_true", help="matching of batch i on a second stream beside the backbone of batch i+1 (engine overlap_matching; measured +0.3...0.8 %%, not the default)")
     ap.add_argument("--parity-precision", default="f16x3", choices=["f16x3", "fp32", "none"],
                     help="the near-exact mode timed next to the headline as `parity_mode` (f16x3: split-fp16 operands, three fp16 MFMAs per product; "
@@ -118,8 +126,11 @@ def main():
     # ---- planted workload: the fp32 mode of the library produces the features that are planted (the reference's arithmetic)
     ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to(dev)
     full_mask = torch.ones(args.size, args.size, dtype=torch.uint8) if args.mask == "full" else None
-    wl = workload.build_planted_workload(ex32, B, args.size, args.objects, args.templates, 256, 2048, seed=7, crop_seed=rank, mask=full_mask,
-                                         words_per_texture=1 if args.mask == "full" else workload.WORDS_PER_TEXTURE)
+    W_words = args.words or (4224 if args.mask == "full" else 2048)
+    n_patches = (args.size // 14) ** 2 if args.mask == "full" else int(synthetic_disc_patches(args.size))
+    wpt = workload.WORDS_PER_TEXTURE if W_words // workload.WORDS_PER_TEXTURE >= n_patches else 1
+    wl = workload.build_planted_workload(ex32, B, args.size, args.objects, args.templates, 256, W_words, seed=7, crop_seed=rank, mask=full_mask,
+                                         words_per_texture=wpt)
     bank = DeviceBank(wl.repres, device=dev)
     images, masks, det_obj = wl.crops, wl.masks, wl.det_obj     # inputs resident in HBM before timing
     extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
@@ -244,17 +255,17 @@ def main():
         # ---- HBM roofline of the template retrieval (descriptors of the object's templates read once per 32 detections)
         from foundpose_amd._lib import call, cosine_scratch_floats, ptr, stream
         Bq = min(max(1, B // args.objects), 128)   # detections of one object in a batch (the kernel serves them in chunks of 32)
-        desc_n = ops.normalize_rows(torch.rand(Bq, 2048, device=dev))
+        desc_n = ops.normalize_rows(torch.rand(Bq, W_words, device=dev))
         seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
         nt = torch.full((Bq,), args.templates, dtype=torch.int32, device=dev)
         sims = torch.empty(cosine_scratch_floats(Bq, args.templates), device=dev)
         sc, ids = torch.empty(Bq, 5, device=dev), torch.empty(Bq, 5, dtype=torch.int32, device=dev)
         tie_mode = 1 if args.tie_order == "torch" else 0
         knn = lambda mode: time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
-                                                    1, args.templates, 2048, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)  # the first object's templates
+                                                    1, args.templates, W_words, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)  # the first object's templates
         ms_knn, ms_knn_other = knn(tie_mode), knn(1 - tie_mode)
-        knn_bytes = args.templates * 2048 * 4 + Bq * 2048 * 4 + Bq * args.templates * 4   # bank (read once) + queries + finished scores
-        knn_flops = 2.0 * Bq * args.templates * 2048
+        knn_bytes = args.templates * W_words * 4 + Bq * W_words * 4 + Bq * args.templates * 4   # bank (read once) + queries + finished scores
+        knn_flops = 2.0 * Bq * args.templates * W_words
         # the same call at BASELINE config 5's bank size (50 000 templates, one 32-detection pass): the stream is long enough to
         # amortise launch + ring fill, which dominate at 10 000 templates (82 MB = 10 us of HBM time)
         T5 = 50000
@@ -274,10 +285,10 @@ def main():
             "value": round(det_per_s, 2), "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic (seeded crops assembled from 682 noise patch textures, disc masks, random-init ViT weights, planted bank: each crop's "
-                                             "fp32 features sit with graded noise in 5 consecutive templates, the rest are random texture sets; words = 3 instances per texture)",
+                                             "fp32 features sit with graded noise in 5 consecutive templates, the rest are random texture sets; words = instances of the textures, see config.workload)",
             "config": {"workload": f"{args.version} layer {args.layer} ({args.layer + 1} of {arch.depth} blocks executed, early exit after the hooked block" + (", the hooked block on the sampled tokens only" if select_on else "") + "), "
                                    f"{args.size}x{args.size} crops, batch {B}/GPU, {args.objects} object(s) x {args.templates} templates "
-                                   f"(N_f={bank.feats.shape[0]}), 2048 words, PCA {arch.dim}->256, top-5 templates, top-300 buddies, {args.mask} mask Q={int(masks[0, 7::14, 7::14].sum())}, "
+                                   f"(N_f={bank.feats.shape[0]}), {W_words} words ({wpt} per texture), PCA {arch.dim}->256, top-5 templates, top-300 buddies, {args.mask} mask Q={int(masks[0, 7::14, 7::14].sum())}, "
                                    f"tie order '{args.tie_order}'" + (" (the reference's torch.topk order, replayed on the device)" if args.tie_order == "torch" else ""),
                        "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step",
                        "tie_order": args.tie_order},

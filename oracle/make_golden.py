@@ -204,6 +204,31 @@ def gen_extractor(ref):
     print("extractor_vits14reg_518", fm.shape, float(np.abs(fm).mean()))
 
 
+def gen_extractor_420(ref):
+    """(c) ViT-S/14-reg at 420 x 420 -- the reference's shipped LM-O geometry (configs/infer/lmo.json:6-12) -- where the 37 x 37 pos-embed
+    table is interpolated to 30 x 30.  The `-reg` hub entries run upstream's interpolate_pos_encoding with interpolate_antialias=True
+    and interpolate_offset=0.0, i.e. F.interpolate(size=(30, 30), mode="bicubic", antialias=True); the stand-in backbone
+    (transformers' Dinov2WithRegisters, config image_size 518 = the table) interpolates with exactly those arguments, so this
+    fixture pins the interpolated table as well as the wrapper."""
+    from foundpose_amd.vit_config import ARCHS
+    arch = ARCHS["vits14-reg"]
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    imgs = synthetic.make_crops(1, 420, seed=3)
+    ex = _make_ref_extractor(ref, arch, sd, 518, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1")
+    with torch.no_grad():
+        o = ex(imgs)
+    fm = t2n(o["feature_maps"]).astype(np.float32)
+    assert fm.shape == (1, 384, 30, 30)
+    np.savez_compressed(
+        os.path.join(OUT, "extractor_vits14reg_420.npz"),
+        weights_seed=np.int64(1234), image_seed=np.int64(3),
+        input_checksum=checksum(imgs, sd["blocks.9.attn.qkv.weight"], sd["pos_embed"]),
+        fmap_sub=fm[:, ::4, ::2, ::2], cls=t2n(o["cls_tokens"]).astype(np.float32),
+        fmap_mean=np.float64(fm.mean()), fmap_abs_mean=np.float64(np.abs(fm).mean()),
+    )
+    print("extractor_vits14reg_420", fm.shape, float(np.abs(fm).mean()))
+
+
 # ------------------------------------------------------------------ composite hot section
 def gen_hot_section(ref):
     """infer.py:468-542 driven through the reference's functions on a tiny extractor."""
@@ -466,6 +491,7 @@ def main():
     gen_match(ref)
     gen_points(ref)
     gen_extractor(ref)
+    gen_extractor_420(ref)
     gen_hot_section(ref)
     gen_crop(ref)
     gen_lift(ref)
@@ -473,4 +499,12 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1:  # python -m oracle.make_golden gen_extractor_420 ... : regenerate single fixtures
+        if not ref_shim.reference_available():
+            sys.exit("reference not present; fixtures can only be generated in the build container")
+        os.makedirs(OUT, exist_ok=True)
+        _ref = ref_shim.import_reference()
+        for _name in sys.argv[1:]:
+            globals()[_name](_ref)
+    else:
+        main()

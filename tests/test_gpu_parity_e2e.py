@@ -87,6 +87,40 @@ def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, temp
     assert pbf["corresp_overlap"] >= 0.9 and full["corresp_overlap"] >= 0.9
 
 
+def test_config1_lmo_geometry_vs_oracle_a():
+    """BASELINE config 1 = the reference's shipped LM-O options (configs/infer/lmo.json:6-17): ViT-S/14-reg layer 9, one 420 x 420
+    crop, a 100-template bank, exact k-NN, batch of one.  The engine in its exact (fp32) and near-exact (f16x3) modes against oracle A
+    (fp32 CPU features with the interpolated pos-embed pinned by extractor_vits14reg_420.npz -> oracle/match.py, the reference's
+    tie order) index for index; the bf16 mode's agreement is reported and held to the same templates."""
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1"   # configs/infer/lmo.json:12
+    arch = ARCHS["vits14-reg"]
+    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    wl = workload.build_planted_workload(ex32, 1, 420, 1, 100, seed=21, crop_seed=4)
+    assert wl.crops.shape == (1, 3, 420, 420)
+    bank = DeviceBank(wl.repres)
+    runs = {"fp32": _run(fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order="torch"), wl, 1)}
+    for prec in ("f16x3", "bf16"):
+        ex = feature_util.make_feature_extractor(name, seed=1234, precision=prec).to("cuda")
+        runs[prec] = _run(fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch"), wl, 1)
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    repre = wl.repres[0]
+    proj = repre.feat_raw_projectors[0]
+    qp, qf = baseline.oracle_a_features(sd, arch, 9, wl.crops[0].cpu(), wl.masks[0].cpu(), proj.components.cpu(), proj.mean.cpu())
+    f2t = repre.feat_to_template_ids.cpu().long()
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.bincount(f2t, minlength=100), 0)])
+    fv = repre.feat_vectors.cpu()
+    small = {"feat_cluster_centroids": repre.feat_cluster_centroids.cpu().numpy(), "feat_cluster_idfs": repre.feat_cluster_idfs.cpu().numpy(),
+             "template_descs": repre.template_descs.cpu().numpy(), "template_desc_opts": repre.template_desc_opts._asdict()}
+    ora = [baseline.exact_matching(qp.numpy(), qf.numpy(), small, lambda t: (fv[int(off[t]):int(off[t + 1])].numpy(), int(off[t])), 5, 300, "torch")]
+    stats = {k: workload.parity_stats(v, ora) for k, v in runs.items()}
+    print("\n[config1] " + "  ".join(f"{k} vs oracle A: {v}" for k, v in stats.items()))
+    t0 = int(wl.targets[0])
+    assert [int(c["template_id"]) for c in ora[0]] == [t0 + r for r in range(5)]        # the oracle itself finds the planted answer
+    for k in ("fp32", "f16x3"):
+        assert stats[k]["templates_equal"] == 1 and stats[k]["corresp_equal"] == stats[k]["slots_compared"] == 5, (k, stats[k])
+    assert stats["bf16"]["templates_equal"] == 1 and stats["bf16"]["corresp_overlap"] >= 0.9
+
+
 def test_token_selection_changes_nothing_end_to_end(monkeypatch):
     """The engine's default path computes the hooked block for the sampled tokens only; with FP_TOKEN_SELECT=0 it runs the
     block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark

@@ -179,6 +179,22 @@ def test_extractor_vits14reg_518_vs_reference_wrapper_fixture(precision, tol):
     np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("f16x3", 5e-5), ("bf16", 8e-2)])
+def test_extractor_vits14reg_420_vs_reference_wrapper_fixture(precision, tol):
+    """BASELINE config 1's geometry (the reference's shipped LM-O options, configs/infer/lmo.json:6-12): 420 x 420 crops take the
+    pos-embed table interpolated 37 x 37 -> 30 x 30 with the `-reg` hub flags (size mode, bicubic, antialias = True, offset 0).
+    The fixture is the reference wrapper's own output at that size."""
+    g = load_golden("extractor_vits14reg_420")
+    imgs = synthetic.make_crops(1, 420, seed=int(g["image_seed"])).cuda()
+    ex = _extractor(None, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1", int(g["weights_seed"]), precision)
+    o = ex(imgs)
+    fm = o["feature_maps"].cpu().numpy()
+    assert fm.shape == (1, 384, 30, 30)
+    scale = np.abs(g["fmap_sub"]).max()
+    np.testing.assert_allclose(fm[:, ::4, ::2, ::2], g["fmap_sub"], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
+
+
 def test_extractor_batch_invariance_and_420():
     """Each image of a batch gets the same features as when run alone; 420x420 crops take the interpolated pos-embed."""
     ex = _extractor(None, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1", 1234, "bf16")

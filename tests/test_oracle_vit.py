@@ -37,6 +37,22 @@ def test_extractor_vits14reg_518_matches_reference_wrapper():
     np.testing.assert_allclose(o["cls_tokens"].numpy(), g["cls"], rtol=0, atol=5e-5)
 
 
+def test_extractor_vits14reg_420_matches_reference_wrapper():
+    """The shipped LM-O geometry (configs/infer/lmo.json:6-12): 420 x 420 crops, pos-embed interpolated 37 x 37 -> 30 x 30 with the
+    `-reg` hub flags (size mode, bicubic, antialias).  Pins the oracle's interpolation to the reference wrapper's fixture."""
+    g = load_golden("extractor_vits14reg_420")
+    spec = parse_extractor_name("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1")
+    sd = synthetic.make_vit_state_dict(spec.arch, seed=int(g["weights_seed"]))
+    imgs = synthetic.make_crops(1, 420, seed=int(g["image_seed"]))
+    assert np.isclose(checksum(imgs, sd["blocks.9.attn.qkv.weight"], sd["pos_embed"]), g["input_checksum"], atol=1e-6)
+    o = ov.extractor_forward(sd, spec.arch, imgs, spec.layer, True)
+    fm = o["feature_maps"].numpy()
+    assert fm.shape == (1, 384, 30, 30)
+    np.testing.assert_allclose(fm[:, ::4, ::2, ::2], g["fmap_sub"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(o["cls_tokens"].numpy(), g["cls"], rtol=0, atol=5e-5)
+    assert abs(float(fm.mean()) - float(g["fmap_mean"])) < 1e-5
+
+
 def test_name_grammar_defaults():
     s = parse_extractor_name("dinov2_vitl14")
     assert (s.version, s.layer, s.stride, s.facet, s.apply_norm) == ("vitl14", 9, 14, "token", True)
