@@ -263,6 +263,33 @@ def shard_detections(num_det: int, world_size: int, rank: int) -> Tuple[int, int
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def shard_rows(num_det: int, world_size: int) -> int:
+    """Rows every rank contributes to the gather: the largest shard (the tail shards are padded up to it)."""
+    return (num_det + world_size - 1) // world_size
+
+
+def pad_records(local: torch.Tensor, rows: int) -> torch.Tensor:
+    """Pads a rank's records to `rows` rows (all_gather wants equal contributions).  Padding rows carry template id -1 (bit-cast,
+    like every integer field) and zeros; the receiver drops them by POSITION (gathered_valid_index), never by content."""
+    if local.shape[0] > rows:
+        raise ValueError(f"{local.shape[0]} records do not fit a shard of {rows}")
+    if local.shape[0] == rows:
+        return local
+    pad = torch.zeros(rows - local.shape[0], local.shape[1], dtype=local.dtype, device=local.device)
+    pad.view(torch.int32)[:, 0] = -1
+    return torch.cat([local, pad], 0)
+
+
+def gathered_valid_index(num_det: int, world_size: int) -> torch.Tensor:
+    """Positions, in the gathered [world_size * shard_rows, ...] tensor, of detections 0 .. num_det-1 in order."""
+    per = shard_rows(num_det, world_size)
+    idx = []
+    for r in range(world_size):
+        lo, hi = shard_detections(num_det, world_size, r)
+        idx += [r * per + i for i in range(hi - lo)]
+    return torch.tensor(idx, dtype=torch.int64)
+
+
 def gather_records(local: torch.Tensor, world_size: int) -> torch.Tensor:
     """The one exchange step of the path: all-gather of the per-detection records over RCCL (xGMI).
     Every rank contributes the same number of rows (the driver pads the tail shard)."""

@@ -27,3 +27,20 @@ def test_bench_two_ranks_dry_run():
     assert "cpu_baseline" not in d and "roofline" in d      # the CPU baseline is timed at N = 1 only
     assert d["ranks_seen"] == 2                              # both ranks' records arrived in the gather
     assert d["config"]["tie_order"] == "torch" and d["parity"]["planted"]["planted_top1"] == 8
+
+
+def test_uneven_shards_through_the_real_engine():
+    """37 detections over 2 ranks (shards of 19 and 18, cut inside an object group): the real FoundPoseEngine on each shard, then
+    pack_result -> pad_records -> gather_records -> unpack_result; every gathered detection equals the single-process result bit for
+    bit and the one padding row is dropped by position (tests/multirank_worker.py)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29537", os.path.join(ROOT, "tests", "multirank_worker.py"), "37"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["shard"] == [0, 19] and d["rows"] == 38 and d["padding_rows"] == 1
+    assert d["mismatched_fields"] == [], d
+    assert d["planted"]["planted_top5_in_order"] == 37
