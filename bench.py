@@ -225,6 +225,10 @@ def main():
             w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
             bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
             out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
+            if args.precision == "f16x3":   # split-fp16 operands: the algorithmic FLOPs are those of the fp32 product (3 MFMAs each)
+                a3, w3 = ops.split16_pack(a.float(), 128.0, 64), ops.split16_pack(w.float(), ops.pow2_scale(w.float()), 64)
+                o3 = torch.zeros(M, n, dtype=torch.float32, device=dev) if epi == 3 else torch.zeros(M, n if epi == 6 else 2 * n, dtype=torch.float16, device=dev)
+                return time_kernel(lambda: ops.gemm_split(a3, w3, bias, 1e-6, gamma=gamma, out=o3, epilogue=epi, out_scale=64.0, m_valid=mv))
             if args.precision == "fp8":
                 a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
                 col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)

@@ -49,8 +49,9 @@ _PROTOS = {
     "fp_knn_l2": [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "fp_tfidf_build": [vp, vp, i32, vp, i32, vp, i32, i32, f32, i32, vp, vp, f32, vp],
     "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp],
-    "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32,
+    "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
                           vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
+    "fp_pack_records": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
     "fp_pnp_ransac": [vp, vp, vp, vp, i32, i32, i32, i32, f64, f64, i32, i32, u64, vp, vp, vp, vp, vp, vp, vp],
     "fp_sample_bilinear": [vp, i64, i64, i64, i64, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_pca_project": [vp, i32, i32, vp, i32, vp, vp, vp],

@@ -124,7 +124,7 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
-                      const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
+                      const int32_t* tpl_ids, const int32_t* tpl_base, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
                       void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
                       float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d, int tie_mode,
                       fp_stream_t stream) {
@@ -142,13 +142,13 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   F32TileArgs a = zero_tile_args();
   a.A = query_feats; a.lda = d; a.B = bank_feats; a.ldb = d; a.K = d;
   a.a_seg_off = q_off; a.pair_a_div = n_slots;
-  a.b_seg_off = tpl_off; a.pair_b_seg = tpl_ids;
+  a.b_seg_off = tpl_off; a.pair_b_seg = tpl_ids; a.pair_b_base = tpl_base;
   a.a_sqnorm = query_sqnorm; a.b_sqnorm = bank_sqnorm;
   a.row_best = row_best; a.row_stride = q_max; a.col_best = col_best; a.col_stride = p_max; a.best_parts = 1;
   TRY(f32_tile_launch(F32_EPI_DIST_ARGMIN, a, q_max, p_max, pairs, ST(stream)));
   CyclicArgs c;
   memset(&c, 0, sizeof(c));
-  c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_off = tpl_off; c.feat_base = feat_base;
+  c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_base = tpl_base; c.tpl_off = tpl_off; c.feat_base = feat_base;
   c.points = query_points; c.vertices = vertices;
   c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max;
   c.row_parts = row_parts; c.col_parts = col_parts;
@@ -156,6 +156,14 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   c.out_count = out_count; c.out_q_ids = out_q_ids; c.out_feat_ids = out_feat_ids; c.out_dists = out_dists;
   c.out_conf = out_conf; c.out_coord_2d = out_coord_2d; c.out_coord_3d = out_coord_3d;
   return launch_cyclic_select(c, pairs, ST(stream));
+}
+
+int fp_pack_records(const int32_t* template_ids, const float* template_scores, const int32_t* counts, const int32_t* q_ids, const int32_t* feat_ids,
+                    const float* dists, const float* conf, const float* coord_2d, const float* coord_3d, int num_det, int n_slots, int k_max, float* out,
+                    fp_stream_t stream) {
+  FP_REQUIRE(template_ids && template_scores && counts && q_ids && feat_ids && dists && conf && coord_2d && coord_3d && out, "fp_pack_records: null pointer");
+  FP_REQUIRE(num_det >= 0 && n_slots >= 1 && k_max >= 1, "fp_pack_records: bad sizes");
+  return launch_pack_records(template_ids, template_scores, counts, q_ids, feat_ids, dists, conf, coord_2d, coord_3d, num_det, n_slots, k_max, out, ST(stream));
 }
 
 int fp_sample_bilinear(const float* fmap, int64_t stride_img, int64_t stride_c, int64_t stride_h, int64_t stride_w,

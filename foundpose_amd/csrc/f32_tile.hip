@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void f32_tile_kernel(F32TileArgs a) {
   if (a.b_seg_off) {
     int s = a.pair_b_seg ? (int)a.pair_b_seg[pair] : pair;
     if (s < 0) return;  // empty slot
+    if (a.pair_b_base) s += a.pair_b_base[a.pair_a_div > 0 ? pair / a.pair_a_div : pair];  // segment ids local to the A segment's group (object)
     b_off = a.b_seg_off[s];
     b_cnt = a.b_seg_off[s + 1] - b_off;
   }

@@ -24,6 +24,7 @@ struct F32TileArgs {
   // ragged grouping (device tables, may be null): pair -> segment of A rows / B rows
   const int* a_seg_off; const int* pair_a_seg; int pair_a_div;  // pair_a_div > 0: segment = pair / pair_a_div
   const int* b_seg_off; const int* pair_b_seg;
+  const int* pair_b_base;  // may be null; else pair_b_seg values are relative: + pair_b_base[pair / pair_a_div]
   // epilogue operands
   float* out; int ldo; long long out_pair_stride; int out_row_global;  // out_row_global: row index = a_off + i
   const float* a_sqnorm; const float* b_sqnorm;
@@ -42,7 +43,8 @@ int f32_tile_launch(int epi, const F32TileArgs& a, int max_m, int max_n, int pai
 // ---------------------------------------------------------------- match.hip
 struct CyclicArgs {
   const int* q_off;        // [B+1] query-point segment per detection
-  const int* tpl_ids;      // [B*n_slots] global template id per (detection, slot); <0 = empty slot
+  const int* tpl_ids;      // [B*n_slots] template id per (detection, slot); <0 = empty slot; global, or object-local with tpl_base
+  const int* tpl_base;     // [B] first template of the detection's object (null: tpl_ids are global)
   const int* tpl_off;      // [T_total+1] feature segment per template
   const int* feat_base;    // [B] first feature row of the detection's object (ids are reported object-local)
   const float* points;     // [sumQ, 2]
@@ -178,6 +180,8 @@ int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* toke
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
 int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st);
 int launch_knn_merge(const unsigned long long* cand, int rows, int ncand, int k, float* out_d2, int* out_idx, hipStream_t st);
+int launch_pack_records(const int* tpl_ids, const float* scores, const int* counts, const int* q_ids, const int* feat_ids, const float* dists, const float* conf,
+                        const float* c2d, const float* c3d, int num_det, int n, int K, float* out, hipStream_t st);
 int launch_unpack_best(const unsigned long long* best, long long n, float* d2, int* idx, hipStream_t st);
 
 struct CosineArgs {

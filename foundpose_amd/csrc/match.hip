@@ -716,7 +716,8 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   const int pair = blockIdx.x, tid = threadIdx.x;
   const int det = pair / a.n_slots;
   const int q0 = a.q_off[det], Q = a.q_off[det + 1] - q0;
-  const int tpl = a.tpl_ids[pair];
+  int tpl = a.tpl_ids[pair];
+  if (tpl >= 0 && a.tpl_base) tpl += a.tpl_base[det];
   const int kk = min(a.top_k, Q);
   // an empty slot (fewer templates than n_slots) or a template without features yields no correspondences
   const bool live = tpl >= 0 && a.tpl_off[tpl + 1] > a.tpl_off[tpl] && Q > 0;
@@ -916,6 +917,45 @@ __global__ void sqrt_inplace_kernel(float* x, long long n) {
 }
 
 }  // namespace
+
+namespace {
+// The fixed-size record of a detection for the final gather (engine.pack_result): n x (template id, score, count) then n x K x
+// (query id, feature id, distance, confidence, x, y, X, Y, Z), every field one 32-bit word; integers keep their bit patterns.
+__global__ __launch_bounds__(256) void pack_records_kernel(const int* __restrict__ tpl_ids, const float* __restrict__ scores, const int* __restrict__ counts,
+                                                           const int* __restrict__ q_ids, const int* __restrict__ feat_ids, const float* __restrict__ dists,
+                                                           const float* __restrict__ conf, const float* __restrict__ c2d, const float* __restrict__ c3d,
+                                                           int n, int K, unsigned* __restrict__ out) {
+  const int pair = blockIdx.x;  // (detection, slot)
+  unsigned* rec = out + (size_t)pair * (3 + (size_t)K * 9);
+  if (threadIdx.x == 0) {
+    rec[0] = (unsigned)tpl_ids[pair];
+    rec[1] = __float_as_uint(scores[pair]);
+    rec[2] = (unsigned)counts[pair];
+  }
+  for (int k = threadIdx.x; k < K; k += 256) {
+    const size_t o = (size_t)pair * K + k;
+    unsigned* r = rec + 3 + (size_t)k * 9;
+    r[0] = (unsigned)q_ids[o];
+    r[1] = (unsigned)feat_ids[o];
+    r[2] = __float_as_uint(dists[o]);
+    r[3] = __float_as_uint(conf[o]);
+    r[4] = __float_as_uint(c2d[o * 2]);
+    r[5] = __float_as_uint(c2d[o * 2 + 1]);
+    r[6] = __float_as_uint(c3d[o * 3]);
+    r[7] = __float_as_uint(c3d[o * 3 + 1]);
+    r[8] = __float_as_uint(c3d[o * 3 + 2]);
+  }
+}
+}  // namespace
+
+int launch_pack_records(const int* tpl_ids, const float* scores, const int* counts, const int* q_ids, const int* feat_ids, const float* dists, const float* conf,
+                        const float* c2d, const float* c3d, int num_det, int n, int K, float* out, hipStream_t st) {
+  if (num_det * n == 0) return FP_OK;
+  hipLaunchKernelGGL(pack_records_kernel, dim3(num_det * n), dim3(256), 0, st, tpl_ids, scores, counts, q_ids, feat_ids, dists, conf, c2d, c3d, n, K,
+                     reinterpret_cast<unsigned*>(out));
+  FP_CHECK_LAUNCH("pack_records");
+  return FP_OK;
+}
 
 int launch_sqnorm_rows(const float* x, long long n, int d, int ld, float* out, hipStream_t st) {
   FP_REQUIRE(d % 4 == 0 && ld % 4 == 0, "sqnorm_rows: d and ld must be multiples of 4");

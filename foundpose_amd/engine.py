@@ -237,6 +237,14 @@ def pack_result(res: MatchResult) -> torch.Tensor:
     reference) are BIT-CAST int32 -> fp32, not converted: a bank with more than 2^24 features (BASELINE config 5:
     N_f = 18.7 M) has ids a float conversion would round.  unpack_result is the inverse."""
     B, n, K = res.q_ids.shape
+    if res.q_ids.is_cuda:  # one kernel writes the record (no torch cat / stack launches in the step)
+        c = lambda t, dt: t if (t.dtype == dt and t.is_contiguous()) else t.to(dt).contiguous()
+        i32, f32 = torch.int32, torch.float32
+        out = torch.empty(B, n * (3 + K * RECORD_FLOATS_PER_CORRESP), dtype=f32, device=res.q_ids.device)
+        call("fp_pack_records", ptr(c(res.template_ids, i32)), ptr(c(res.template_scores, f32)), ptr(c(res.counts, i32)), ptr(c(res.q_ids, i32)),
+             ptr(c(res.feat_ids, i32)), ptr(c(res.dists, f32)), ptr(c(res.conf, f32)), ptr(c(res.coord_2d, f32)), ptr(c(res.coord_3d, f32)), B, n, K,
+             ptr(out), stream())
+        return out
     as_f = lambda t: t.to(torch.int32).contiguous().view(torch.float32)
     head = torch.stack([as_f(res.template_ids), res.template_scores, as_f(res.counts)], -1)  # [B,n,3]
     body = torch.cat([as_f(res.q_ids).unsqueeze(-1), as_f(res.feat_ids).unsqueeze(-1), res.dists.unsqueeze(-1),

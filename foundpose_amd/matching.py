@@ -155,8 +155,7 @@ def match_batch(
          ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
 
     # ---- cyclic best buddies against the retrieved templates + correspondence assembly (the kernel pads its records itself)
-    t_glob = torch.where(t_ids >= 0, t_ids + tpl_base[:, None], t_ids).contiguous()
-    pairs = B * n
+    pairs = B * n   # (the kernels add the object's first template to the object-local ids themselves)
     scratch = torch.empty(cyclic_scratch_bytes(pairs, q_max, bank.p_max) // 8, dtype=torch.int64, device=dev)
     counts = torch.empty(B, n, dtype=torch.int32, device=dev)
     q_ids = torch.empty(B, n, K, dtype=torch.int32, device=dev)
@@ -166,7 +165,7 @@ def match_batch(
     c2d = torch.empty(B, n, K, 2, dtype=torch.float32, device=dev)
     c3d = torch.empty(B, n, K, 3, dtype=torch.float32, device=dev)
     call("fp_cyclic_buddies", ptr(qf), ptr(q_sqn), ptr(qp), ptr(q_off), B, q_max, ptr(bank.feats), ptr(bank.feat_sqn),
-         ptr(bank.tpl_off), bank.p_max, ptr(bank.vertices), ptr(t_glob), ptr(feat_base), n, bank.feat_dim, K, K,
+         ptr(bank.tpl_off), bank.p_max, ptr(bank.vertices), ptr(t_ids), ptr(tpl_base), ptr(feat_base), n, bank.feat_dim, K, K,
          ptr(scratch), ptr(counts), ptr(q_ids), ptr(feat_ids), ptr(dists), ptr(conf), ptr(c2d), ptr(c3d), tie_mode, stream())
     return MatchResult(t_ids, t_scores, counts, q_ids, feat_ids, dists, conf, c2d, c3d,
                        query_tfidf=desc if keep_debug else None,

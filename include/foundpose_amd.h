@@ -96,7 +96,8 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
  * utils/corresp_util.py:34-70,107-155).
  *   query_feats [sumQ,d], query_sqnorm [sumQ], query_points [sumQ,2], q_off [B+1]
  *   bank_feats [N_f,d] sorted by template, bank_sqnorm [N_f], tpl_off [T_total+1], vertices [N_f,3]
- *   tpl_ids [B*n_slots] GLOBAL template ids (object's first template + local id), <0 = empty slot
+ *   tpl_ids [B*n_slots] template ids, <0 = empty slot: object-local (as fp_cosine_topk reports them) when tpl_base [B] = first
+ *   template of each detection's object is given, GLOBAL ids when tpl_base is NULL
  *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
  *   scratch: FP_CYCLIC_SCRATCH_BYTES(B * n_slots, q_max, p_max) bytes (one slice of nearest-neighbour keys per 128 x 128
  *   distance tile; nothing has to be preset)
@@ -109,10 +110,18 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,
-                      const int32_t* tpl_ids, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
+                      const int32_t* tpl_ids, const int32_t* tpl_base, const int32_t* feat_base, int n_slots, int d, int top_k, int k_max,
                       void* scratch, int32_t* out_count, int32_t* out_q_ids, int32_t* out_feat_ids,
                       float* out_dists, float* out_conf, float* out_coord_2d, float* out_coord_3d, int tie_mode,
                       fp_stream_t stream);
+
+/* The fixed-size record of each detection for the one exchange step of a multi-GPU run (an RCCL all-gather of these rows):
+ * out [num_det, n_slots * (3 + 9 * k_max)] 32-bit words typed fp32 -- per slot (template id, score, count), then per correspondence
+ * (query id, feature id = nn_vertex_ids, distance, confidence, x, y, X, Y, Z).  Integer fields keep their bit patterns (ids above
+ * 2^24 survive). */
+int fp_pack_records(const int32_t* template_ids, const float* template_scores, const int32_t* counts, const int32_t* q_ids, const int32_t* feat_ids,
+                    const float* dists, const float* conf, const float* coord_2d, const float* coord_3d, int num_det, int n_slots, int k_max, float* out,
+                    fp_stream_t stream);
 
 /* Coarse pose of every (detection, template slot) pair from its 2D-3D correspondences: estimate_pose
  * (utils/pnp_util.py:20-84 = cv2.solvePnPRansac(..., SOLVEPNP_ITERATIVE) + cv2.solvePnPRefineLM on the inliers), the call

@@ -105,7 +105,7 @@ def main():
                  f_ids=torch.empty(Bq, n_top, K, dtype=torch.int32, device=dev), dists=torch.empty(Bq, n_top, K, device=dev),
                  conf=torch.empty(Bq, n_top, K, device=dev), c2d=torch.empty(Bq, n_top, K, 2, device=dev), c3d=torch.empty(Bq, n_top, K, 3, device=dev))
         ms = timeit(lambda: call("fp_cyclic_buddies", ptr(qf), ptr(qn), ptr(pts), ptr(q_off), Bq, Q, ptr(feats), ptr(fn), ptr(tpl_off), p_max,
-                                 ptr(verts), ptr(tpl_ids), ptr(feat_base), n_top, d, K, K, ptr(scratch), ptr(o["counts"]), ptr(o["q_ids"]),
+                                 ptr(verts), ptr(tpl_ids), None, ptr(feat_base), n_top, d, K, K, ptr(scratch), ptr(o["counts"]), ptr(o["q_ids"]),
                                  ptr(o["f_ids"]), ptr(o["dists"]), ptr(o["conf"]), ptr(o["c2d"]), ptr(o["c3d"]), 1, stream()))
         live = float((pc[tpl_ids.cpu().long()].double() * Q).sum())
         print(f"cyclic_buddies {Bq} x {n_top} pairs, Q={Q}, P=300..450 (p_max {p_max}): {ms*1e3:8.1f} us whole call "
