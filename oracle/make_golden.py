@@ -483,6 +483,95 @@ def gen_wrappers(ref):
     print("wrappers.npz templates", out["template_ids"], "repre.pth bytes", os.path.getsize(os.path.join(rdir, "repre.pth")))
 
 
+# ------------------------------------------------------------------ result formats
+def results_inputs():
+    """Seeded stand-ins for what the driver hands the evaluator: per object a few instances, each with a pose in the crop camera's
+    world, the original and the crop camera, the per-stage times and a correspondence set (with repeated query ids: the score is
+    the many-to-many aware inlier ratio)."""
+    rng = np.random.default_rng(42)
+    out = []
+    for lid, n_inst in ((1, 3), (2, 2)):
+        verts = rng.normal(0, 40.0, (500, 3))
+        for j in range(n_inst):
+            ang = rng.normal(0, 1.0, 3)
+            th = np.linalg.norm(ang)
+            k = ang / th
+            Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+            R = np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+            t = np.array([rng.normal(0, 20), rng.normal(0, 20), 900 + 100 * rng.random()])
+            T_oc = np.eye(4)
+            T_oc[:3, 3] = [5.0 * j, -3.0, 1.0]                       # the original camera sits off the world origin
+            a = 0.05 * (j + 1)
+            T_cc = np.eye(4)
+            T_cc[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])   # the crop camera looks at the object
+            n_c = 60
+            vid = rng.integers(0, 500, n_c)
+            qid = rng.integers(0, 25, n_c)                            # repeated query ids
+            f, c = (700.0, 705.0), (210.0, 208.0)
+            Tm2c = np.linalg.inv(T_cc) @ np.block([[R, t[:, None]], [np.zeros((1, 3)), np.ones((1, 1))]])
+            pc = verts[vid] @ Tm2c[:3, :3].T + Tm2c[:3, 3]
+            uv = np.stack([f[0] * pc[:, 0] / pc[:, 2] + c[0], f[1] * pc[:, 1] / pc[:, 2] + c[1]], 1)
+            uv[::3] += rng.normal(0, 30.0, uv[::3].shape)              # a third of the matches are outliers
+            times = {k_: float(v) for k_, v in zip(("prep", "feat_extract", "grid_sample", "proj", "corresp", "pose_coarse", "final_select"),
+                                                   rng.random(7) * 0.05)}
+            out.append(dict(lid=lid, scene_id=3 + lid, im_id=10 * j + 1, inst_id=j, verts=verts, R=R, t=t, T_oc=T_oc, T_cc=T_cc, f=f, c=c,
+                            nn_vertex_ids=vid, coord_2d=uv, coord_2d_ids=qid, times=times, cnos_time=0.125 * (j + 1)))
+    return out
+
+
+def gen_results(ref):
+    """estimated-poses.json through the reference's EvaluatorPose.update_without_anno / save_results_json (utils/eval_util.py:231-355)
+    and the BOP19 csv through the reference's scripts/prepare_bop_submission.py run on those files; the fixture keeps both outputs."""
+    import importlib
+    import runpy
+    import shutil
+    import tempfile
+    import types as _types
+    bop = _types.ModuleType("bop_toolkit_lib")
+    tmp = tempfile.mkdtemp()
+    for sub in ("inout", "config", "dataset_params", "misc", "renderer", "visibility", "pose_error"):
+        m = _types.ModuleType(f"bop_toolkit_lib.{sub}")
+        setattr(bop, sub, m)
+        sys.modules[f"bop_toolkit_lib.{sub}"] = m
+    sys.modules["bop_toolkit_lib"] = bop
+    for name, attrs in (("skimage", ()), ("skimage.color", ("label2rgb",)), ("skimage.feature", ("canny",)), ("skimage.morphology", ("binary_dilation",)),
+                        ("imageio", ()), ("trimesh", ()), ("pyrender", ()), ("distinctipy", ())):   # visualisation-only imports of html_util / eval_errors
+        if name not in sys.modules:
+            try:
+                importlib.import_module(name)
+            except Exception:
+                m = _types.ModuleType(name)
+                for a_ in attrs:
+                    setattr(m, a_, None)
+                sys.modules[name] = m
+    bop.config.output_path, bop.config.datasets_path = tmp, tmp
+    bop.dataset_params.get_model_params = lambda datasets_path, dataset_name: {"obj_ids": [1, 2]}
+    eu = importlib.import_module("utils.eval_util")
+    structs = importlib.import_module("utils.structs")
+    out_dir = os.path.join(tmp, "inference", "lmo_v1")
+    dst = os.path.join(OUT, "results_ref")
+    shutil.rmtree(dst, ignore_errors=True)
+    for lid in (1, 2):
+        ev = eu.EvaluatorPose([lid])
+        for d in results_inputs():
+            if d["lid"] != lid:
+                continue
+            mk = lambda T: structs.PinholePlaneCameraModel(width=420, height=420, f=d["f"], c=d["c"], T_world_from_eye=T)
+            ev.detection_times[(d["scene_id"], d["im_id"])] = d["cnos_time"]
+            ev.update_without_anno(scene_id=d["scene_id"], im_id=d["im_id"], inst_id=d["inst_id"], hypothesis_id=0, object_repre_vertices=d["verts"],
+                                   obj_lid=lid, object_pose_m2w=structs.ObjectPose(R=d["R"], t=d["t"].reshape(3, 1)), orig_camera_c2w=mk(d["T_oc"]),
+                                   camera_c2w=mk(d["T_cc"]), time_per_inst=d["times"],
+                                   corresp={"nn_vertex_ids": d["nn_vertex_ids"], "coord_2d": d["coord_2d"], "coord_2d_ids": d["coord_2d_ids"]}, inlier_radius=10)
+        os.makedirs(os.path.join(out_dir, str(lid)), exist_ok=True)
+        ev.save_results_json(os.path.join(out_dir, str(lid), "estimated-poses.json"))
+        os.makedirs(os.path.join(dst, str(lid)), exist_ok=True)
+        shutil.copy(os.path.join(out_dir, str(lid), "estimated-poses.json"), os.path.join(dst, str(lid), "estimated-poses.json"))
+    runpy.run_path(os.path.join(ref_shim.REF_ROOT, "scripts", "prepare_bop_submission.py"), run_name="__main__")
+    shutil.copy(os.path.join(out_dir, "coarse_lmo-estimated-poses.csv"), os.path.join(dst, "coarse_lmo-estimated-poses.csv"))
+    shutil.rmtree(tmp, ignore_errors=True)
+    print("results_ref", sorted(os.listdir(dst)), open(os.path.join(dst, "coarse_lmo-estimated-poses.csv")).read().count("\n") + 1, "csv lines")
+
+
 def main():
     if not ref_shim.reference_available():
         sys.exit("reference not present; fixtures can only be generated in the build container")
@@ -496,6 +585,7 @@ def main():
     gen_crop(ref)
     gen_lift(ref)
     gen_wrappers(ref)
+    gen_results(ref)
 
 
 if __name__ == "__main__":
