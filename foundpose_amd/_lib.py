@@ -49,6 +49,7 @@ _PROTOS = {
     "fp_knn_l2": [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp],
     "fp_tfidf_build": [vp, vp, i32, vp, i32, vp, i32, i32, f32, i32, vp, vp, f32, vp],
     "fp_cosine_topk": [vp, vp, vp, i32, i32, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp],
+    "fp_cosine_topk_prefiltered": [vp, vp, vp, i32, i32, vp, vp, vp, i32, i32, i32, i32, vp, vp, vp, i32, vp],
     "fp_cyclic_buddies": [vp, vp, vp, vp, i32, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32,
                           vp, vp, vp, vp, vp, vp, vp, vp, i32, vp],
     "fp_pack_records": [vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, vp, vp],
@@ -109,6 +110,11 @@ def lib() -> C.CDLL:
 def cosine_scratch_floats(num_det: int, max_templates: int) -> int:
     """FP_COSINE_SCRATCH_FLOATS of include/foundpose_amd.h."""
     return 2 * num_det * max_templates + 17 * num_det + 2
+
+
+def cosine_prefilter_scratch_floats(num_det: int, max_templates: int) -> int:
+    """FP_COSINE_PREFILTER_SCRATCH_FLOATS of include/foundpose_amd.h."""
+    return cosine_scratch_floats(num_det, max_templates) + 3 * num_det * max_templates + 32 * num_det + 16
 
 
 def cyclic_scratch_bytes(pairs: int, q_max: int, p_max: int) -> int:

@@ -80,6 +80,8 @@ class DeviceBank:
             raise ValueError("all objects of one bank must use the same number of visual words")
         d_all = torch.cat(descs, 0) if len(descs) > 1 else descs[0]
         self.descs_n = ops.normalize_rows(d_all, 1e-8)  # cosine_similarity's per-operand normalisation, once
+        # fp16 copy for the first pass of the prefiltered retrieval (fp_cosine_topk_prefiltered): candidates come from it, scores never do
+        self.descs_bf = self.descs_n.to(torch.float16).contiguous() if (self.num_words % 1024 == 0 and self.num_words <= 4096) else None
         self.tpl_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         self.obj_tpl_off = torch.tensor([o.tpl_base for o in self.objects] + [tpl_base], dtype=torch.int32, device=dev)
         self.num_templates_total = tpl_base

@@ -121,6 +121,31 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
   return launch_topn_rows(scratch_sims, max_templates, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, tie_mode, ST(stream));
 }
 
+int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det, int max_det_per_obj,
+                               const float* bank_n, const void* bank_n_bf16, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,
+                               int n_top, float* scratch, float* out_scores, int32_t* out_ids, int tie_mode, fp_stream_t stream) {
+  FP_REQUIRE(desc_n && det_seg_off && det_num_templates && bank_n && bank_n_bf16 && obj_tpl_off && scratch && out_scores && out_ids,
+             "fp_cosine_topk_prefiltered: null pointer");
+  FP_REQUIRE(num_obj >= 1 && max_templates >= 1 && n_top >= 1, "fp_cosine_topk_prefiltered: bad sizes");
+  if (num_det == 0) return FP_OK;
+  const int force = (tie_mode >> 8) & 1;  // FP_COSINE_FORCE_PREFILTER: the two-stage form whatever the size (tests, measurements)
+  tie_mode &= 0xff;
+  FP_REQUIRE(tie_mode == 0 || tie_mode == 1, "fp_cosine_topk_prefiltered: tie_mode must be 0 (canonical) or 1 (torch)");
+  if (num_words % 16 != 0)  // the generic exact path
+    return fp_cosine_topk(desc_n, det_seg_off, det_num_templates, num_det, max_det_per_obj, bank_n, obj_tpl_off, num_obj, max_templates, num_words, n_top,
+                          scratch, out_scores, out_ids, tie_mode, stream);
+  CosineArgs c;
+  memset(&c, 0, sizeof(c));
+  c.force_prefilter = force;
+  c.desc_n = desc_n; c.bank_n = bank_n; c.bank_bf16 = bank_n_bf16; c.det_seg_off = det_seg_off; c.obj_tpl_off = obj_tpl_off; c.W = num_words;
+  c.sims = scratch; c.ld_sims = max_templates;
+  c.cand = reinterpret_cast<unsigned long long*>(scratch + (size_t)num_det * max_templates + ((size_t)num_det * max_templates & 1));
+  c.need_replay = reinterpret_cast<int*>(scratch + 2 * (size_t)num_det * max_templates + 16 * (size_t)num_det + 2);
+  float* extra = scratch + FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) + (FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) & 1);
+  return launch_cosine_topk_prefiltered(c, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores, out_ids, tie_mode, extra,
+                                        ST(stream));
+}
+
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,

@@ -195,9 +195,14 @@ struct CosineArgs {
   unsigned long long* cand;  // [num_det, grid.x, n_top] candidate keys of the fused kernel (null: not wanted)
   int n_top;                 // candidates per (workgroup, detection): the caller's n_top, + 1 in the torch tie order
   int* need_replay;          // [num_det] torch tie order: 1 = the row has a tie among its best n_top + 1 scores
+  const void* bank_bf16;     // [T_total, W] bf16 copy of bank_n (prefiltered retrieval only)
+  int force_prefilter;       // prefiltered retrieval: take the two-stage form whatever the size (tests, measurements)
+  const int* run_flag;       // may be null; else the kernel runs only if *run_flag != 0 (exact fallback of the prefiltered retrieval)
 };
 int launch_cosine_topk(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
+int launch_cosine_topk_prefiltered(const CosineArgs& a, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+                                   const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, float* extra_scratch, hipStream_t st);
 int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int* row_len, int n_top, float* out_scores,
                      int* out_ids, int tie_mode, hipStream_t st, const int* need_replay = nullptr);
 

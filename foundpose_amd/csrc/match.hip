@@ -177,16 +177,22 @@ constexpr int COS_SLOTS = FP_COS_SLOTS;
 constexpr int COS_RED_BUFS = COS_SLOTS <= 3 ? 2 : 1;  // a 4-slot ring leaves LDS for one reduction buffer (second barrier per block)
 constexpr int COS_RING_BYTES = 8 * COS_SLOTS * 4096;
 
-template <int NQ>
+// BF = the approximate first pass of the prefiltered retrieval (fp_cosine_topk_prefiltered): the bank is its fp16 copy (half the
+// bytes), the queries are rounded to fp16 on their way into the registers, one v_mfma_f32_16x16x32_f16 takes the place of four
+// fp32 MFMAs (1/16 of the matrix time); the "scores" it leaves in a.sims are within COS_PREFILTER_EPS of the exact ones.
+// (fp16, not bf16: rows are L2-normalised, so every element is <= 1 and the 11-bit mantissa gives a 4x tighter bound.)
+template <int NQ, bool BF = false>
 __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [8 waves][3][4 KiB] ring | red[2][8 slices][NQ][4][68] floats
+  if (a.run_flag && *a.run_flag == 0) return;  // exact fallback of the prefiltered retrieval: runs only if some row asked for it
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int obj = blockIdx.y;
   const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
   const int d0 = a.det_seg_off[obj] + blockIdx.z * (NQ * 16);
   const int nd = min(NQ * 16, a.det_seg_off[obj + 1] - d0);
   if (nd <= 0) return;  // block-uniform: no detection rows, nothing to emit
-  const int wslice = a.W >> 3, nch = wslice >> 6;  // 64-word chunks per slice (1..4)
+  constexpr int ESZ = BF ? 2 : 4;                  // bytes per bank element
+  const int wslice = a.W >> 3, nch = (wslice * ESZ) >> 8;  // 256-byte chunks (64 fp32 / 128 fp16 words) per slice (1..4)
   const int i = lane & 15, g = lane >> 4;
   char* ring = smem + wave * (COS_SLOTS * 4096);
   float* red = reinterpret_cast<float*>(smem + COS_RING_BYTES);
@@ -206,11 +212,21 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
         qv[c * 4 + j][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < nch && total > 0)
-          qv[c * 4 + j][q] = *reinterpret_cast<const float4*>(a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + wave * wslice + (c * 4 + j) * 16 + g * 4);
+        if (c < nch && total > 0) {
+          const float* qrow = a.desc_n + (size_t)(d0 + min(q * 16 + i, nd - 1)) * a.W + wave * wslice;
+          if constexpr (BF) {  // piece (c*4+j): 8 consecutive words at 32 (c*4+j) + 8 g, rounded to fp16 (RNE)
+            const float4 lo = *reinterpret_cast<const float4*>(qrow + (c * 4 + j) * 32 + g * 8);
+            const float4 hi = *reinterpret_cast<const float4*>(qrow + (c * 4 + j) * 32 + g * 8 + 4);
+            auto pk = [](float x, float y) { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{x, y}, f16x2)); };
+            qv[c * 4 + j][q] = __builtin_bit_cast(float4, make_uint4(pk(lo.x, lo.y), pk(lo.z, lo.w), pk(hi.x, hi.y), pk(hi.z, hi.w)));
+          } else {
+            qv[c * 4 + j][q] = *reinterpret_cast<const float4*>(qrow + (c * 4 + j) * 16 + g * 4);
+          }
+        }
       }
 
-  const float* slice_base = a.bank_n + (size_t)tb * a.W + wave * wslice;
+  // (byte addressing: a bank row is W * ESZ bytes, this wave's slice starts wave * wslice * ESZ bytes into it)
+  const char* slice_base = reinterpret_cast<const char*>(BF ? a.bank_bf16 : (const void*)a.bank_n) + ((size_t)tb * a.W + (size_t)wave * wslice) * ESZ;
   int it_blk = first, it_ch = 0, it_slot = 0;
   auto issue = [&]() {
 #ifdef FP_COS_NO_DMA
@@ -221,7 +237,7 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
     for (int q4 = 0; q4 < 4; ++q4) {
       const int row = 4 * q4 + g;                     // lane -> (row of the block, physical 16-B slot i)
       const int piece = i ^ row;                      // logical piece that must land in slot i of this row
-      const float* src = slice_base + (size_t)min(t0 + row, T - 1) * a.W + it_ch * 64 + piece * 4;
+      const char* src = slice_base + (size_t)min(t0 + row, T - 1) * a.W * ESZ + it_ch * 256 + piece * 16;
       __builtin_amdgcn_global_load_lds((cos_gbl_cvoid*)src, (cos_lds_void*)(ring + it_slot * 4096 + q4 * 1024), 16, 0, 2 /* nt */);
     }
     if (++it_ch == nch) { it_ch = 0; it_blk += stride; }
@@ -263,6 +279,13 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // fragments are in registers before the slot is handed back
         if (cc + COS_SLOTS < total) issue();
 #ifndef FP_COS_NO_MFMA  // (measurement builds, tools/cos_ablate.sh: the kernel without its matrix work)
+        if constexpr (BF) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+              acc[q] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, av[j]), __builtin_bit_cast(f16x8, qv[ch * 4 + j][q]), acc[q], 0, 0, 0);
+        } else
 #pragma unroll
         for (int j = 0; j < 4; ++j) {  // two alternating accumulator chains (NQ = 2)
 #pragma unroll
@@ -337,34 +360,136 @@ __global__ __launch_bounds__(512) void cosine_fused_kernel(CosineArgs a) {
   }
 }
 
-// Canonical top-n of each row from the candidate keys of cosine_fused_kernel: one wave per detection, per-lane sorted
-// lists over a strided share of the ncand keys, then n rounds of wave-wide arg-best.  The score travels inside the key.
-// need_replay (torch tie order): the workgroups emitted n_top + 1 candidates; if the best n_top + 1 scores of the row are
-// strictly decreasing, the top-n SET and its ORDER are unique, so every correct top-k -- torch.topk's partial_sort /
-// nth_element + sort included -- returns exactly this list and the row's replay is skipped (flag 0).  Any equal pair, a
-// +-0 pair or a NaN among them sets the flag and topn_rows_strict_kernel redoes the row from the scores.
-__global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
-                                                         float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay) {
+// ------------------------------------------------------------------ prefiltered retrieval: exact re-scoring of the candidates
+// fp_cosine_topk_prefiltered = (1) cosine_fused_kernel<NQ, true>: approximate scores s~ from the fp16 bank and the best n + 1
+// approximate keys of every workgroup.  Error bound for L2-normalised rows q, d (elements <= 1, W <= 4096 words): an element rounds
+// to fp16 with |x~ - x| <= 2^-11 |x| + 2^-25 (normal range / subnormal spacing), so with Cauchy-Schwarz on unit rows
+//   |sum q~ d~ - sum q d| <= 2 (2^-11 sum |q||d| + 2^-25 sqrt(W)) + (cross terms <= 2^-22 + ...) <= 2^-10 + 3.8e-6 + 2.4e-7 = 9.81e-4;
+// the fp16 x fp16 products are exact in fp32; their accumulation (order and rounding inside the MFMA unspecified: one ulp = 2^-23
+// of a running sum <= 1.001 per addition, W additions) adds <= 4.9e-4.  COS_PREFILTER_EPS = 2^-10 * 1.5625 = 1.526e-3 >= 1.47e-3.
+// (2) this kernel: v = the (n + 1)-th best approximate score of the detection; every template of the exact top n + 1 has
+// s~ >= v - 2 EPS (n + 1 templates have s >= v - EPS, so the exact (n + 1)-th best is >= v - EPS, and a template at or above it
+// has s~ >= v - 2 EPS): those candidates -- however many -- get their EXACT score, computed with the fused kernel's own MFMA
+// sequence (same instruction, same operand order, slice sums added in slice order => the same bits); (3) cosine_final_kernel:
+// top n of the exact keys.  The strict (torch) tie order needs the whole row only when the best n + 1 exact scores contain a tie:
+// those rows raise a flag, and the exact single-pass kernel + replay run behind it (they exit at once otherwise).
+constexpr float COS_PREFILTER_EPS = 0.00152587890625f;  // 2^-10 * 1.5625
+constexpr int COS_PARTS = 8;                         // a detection's template range is scanned by 8 workgroups
+constexpr int COS_LIST_CAP = 8192;                   // candidates one workgroup can hold (a part is at most T / 8 templates: T <= 65536)
+
+__global__ __launch_bounds__(512) void cosine_rescore_kernel(CosineArgs a, const unsigned long long* __restrict__ wg_keys, int keys_per_det, int n_emit,
+                                                             const float* __restrict__ approx, unsigned long long* __restrict__ exact_keys,
+                                                             int* __restrict__ exact_cnt, int key_stride) {
+  __shared__ unsigned long long wmin[8];
+  __shared__ int list[COS_LIST_CAP];
+  __shared__ int cnt_s;
+  __shared__ float red[8][16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int part = blockIdx.x, det = blockIdx.y;
+  int obj = 0;
+  while (det >= a.det_seg_off[obj + 1]) ++obj;
+  const int tb = a.obj_tpl_off[obj], T = a.obj_tpl_off[obj + 1] - tb;
+  // ---- (a) the n_emit-th best approximate key of the detection (keys ascend with falling score)
+  unsigned long long k[4];
+  const unsigned long long* kp = wg_keys + (size_t)det * keys_per_det;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) k[e] = tid + 512 * e < keys_per_det ? kp[tid + 512 * e] : ~0ull;
+  unsigned long long nth = ~0ull;
+  for (int r = 0; r < n_emit; ++r) {
+    unsigned long long m = k[0] < k[1] ? k[0] : k[1];
+    const unsigned long long m2 = k[2] < k[3] ? k[2] : k[3];
+    m = m < m2 ? m : m2;
+    m = wave_min_u64(m);
+    if (lane == 0) wmin[wave] = m;
+    __syncthreads();
+    unsigned long long b = wmin[0];
+#pragma unroll
+    for (int w = 1; w < 8; ++w) b = wmin[w] < b ? wmin[w] : b;
+    __syncthreads();
+    nth = b;
+    if (b == ~0ull) break;  // fewer than n_emit templates: everything is a candidate
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (k[e] == b) k[e] = ~0ull;  // (template ids are unique: exactly one holder)
+  }
+  float thr = -INFINITY;
+  if (nth != ~0ull) {
+    const unsigned kb = ~(unsigned)(nth >> 32);
+    const float v = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+    thr = v - 2.f * COS_PREFILTER_EPS;  // NaN (a NaN score ranks first) -> no comparison below is true -> every template is re-scored
+  }
+  // ---- (b) this part's candidates
+  if (tid == 0) cnt_s = 0;
+  __syncthreads();
+  const int tp = (T + COS_PARTS - 1) / COS_PARTS, t_lo = part * tp, t_hi = min(T, t_lo + tp);
+  const float* arow = approx + (size_t)det * a.ld_sims;
+  for (int t = t_lo + tid; t < t_hi; t += 512)
+    if (!(arow[t] < thr)) list[atomicAdd(&cnt_s, 1)] = t;
+  __syncthreads();
+  const int cnt = cnt_s;
+  // ---- (c) exact scores, 16 candidates at a time: wave s = k-slice s, the fused kernel's MFMA sequence on gathered rows
+  const int wslice = a.W >> 3, i = lane & 15, g = lane >> 4;
+  const float* qs = a.desc_n + (size_t)det * a.W + wave * wslice + 4 * g;
+  unsigned long long* out = exact_keys + ((size_t)det * COS_PARTS + part) * key_stride;  // (key_stride >= every object's part length)
+  for (int c0 = 0; c0 < cnt; c0 += 16) {
+    const int trow = list[min(c0 + i, cnt - 1)];
+    const float* ap = a.bank_n + (size_t)(tb + trow) * a.W + wave * wslice + 4 * g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int j0 = 0; j0 < wslice / 16; j0 += 8) {  // eight 16-word steps per batch: all 16 loads in flight before the chain consumes them
+      f32x4 av[8];
+      float4 bv[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        av[u] = *reinterpret_cast<const f32x4*>(ap + 16 * (j0 + u));
+        bv[u] = *reinterpret_cast<const float4*>(qs + 16 * (j0 + u));
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][0], bv[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][1], bv[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][2], bv[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][3], bv[u].w, acc, 0, 0, 0);
+      }
+    }
+    // D[template 4g + r][column lane & 15]; every column holds the same detection: column 0 reports
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) red[wave][4 * g + r] = acc[r];
+    }
+    __syncthreads();
+    if (tid < 16 && c0 + tid < cnt) {
+      float v = red[0][tid];
+#pragma unroll
+      for (int sl = 1; sl < 8; ++sl) v += red[sl][tid];  // slice sums added in slice order
+      out[c0 + tid] = ((unsigned long long)order_key(v != v ? __uint_as_float(0x7fc00000u) : v, true) << 32) | (unsigned)list[c0 + tid];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) exact_cnt[det * COS_PARTS + part] = cnt;
+}
+
+// Top n of a detection's exact candidate keys (one wave per detection), the tie test of cand_merge_kernel, and the flag that
+// releases the exact single-pass fallback when a row of the strict (torch) order has a tie among its best n + 1 scores.
+__global__ __launch_bounds__(256) void cosine_final_kernel(const unsigned long long* __restrict__ exact_keys, const int* __restrict__ exact_cnt, int rows, int n_top,
+                                                           float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay,
+                                                           int* __restrict__ any_flag, int key_stride) {
   const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   const int lane = threadIdx.x & 63;
-  const unsigned long long* c = cand + (size_t)row * ncand;
   unsigned long long best[COS_NMAX];
 #pragma unroll
   for (int s = 0; s < COS_NMAX; ++s) best[s] = ~0ull;
-  for (int j0 = lane; j0 < ncand; j0 += 256) {
-    unsigned long long k[4];
+  // lane = (part, j): the first 8 keys of every part in ONE round of loads (a part rarely holds more); longer parts loop
+  const int p = lane >> 3, j0 = lane & 7;
+  const unsigned long long* c = exact_keys + ((size_t)row * COS_PARTS + p) * key_stride;
+  const int n = exact_cnt[row * COS_PARTS + p];
+  for (int j = j0; j < n; j += 8) {
+    unsigned long long key = c[j];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) k[e] = j0 + 64 * e < ncand ? c[j0 + 64 * e] : ~0ull;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      unsigned long long key = k[e];
-#pragma unroll
-      for (int s = 0; s < COS_NMAX; ++s) {
-        const unsigned long long lo = key < best[s] ? key : best[s];
-        key = key < best[s] ? best[s] : key;
-        best[s] = lo;
-      }
+    for (int s = 0; s < COS_NMAX; ++s) {
+      const unsigned long long lo = key < best[s] ? key : best[s];
+      key = key < best[s] ? best[s] : key;
+      best[s] = lo;
     }
   }
   float prev = 0.f;
@@ -376,7 +501,7 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long lon
       if (lane == 0 && s < n_top) { out_idx[(size_t)row * n_top + s] = -1; out_val[(size_t)row * n_top + s] = -INFINITY; }
       continue;
     }
-    const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits
+    const unsigned kb = ~(unsigned)(b >> 32);
     const float val = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
     if (val != val || (s > 0 && !(prev > val))) tie = 1;  // wave-uniform
     prev = val;
@@ -388,6 +513,71 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long lon
 #pragma unroll
       for (int t = 0; t + 1 < COS_NMAX; ++t) best[t] = best[t + 1];
       best[COS_NMAX - 1] = ~0ull;
+    }
+  }
+  if (need_replay && lane == 0) {
+    need_replay[row] = tie;
+    if (tie) atomicOr(any_flag, 1);
+  }
+}
+
+// Canonical top-n of each row from the candidate keys of cosine_fused_kernel: one wave per detection, per-lane sorted
+// lists over a strided share of the ncand keys, then n rounds of wave-wide arg-best.  The score travels inside the key.
+// need_replay (torch tie order): the workgroups emitted n_top + 1 candidates; if the best n_top + 1 scores of the row are
+// strictly decreasing, the top-n SET and its ORDER are unique, so every correct top-k -- torch.topk's partial_sort /
+// nth_element + sort included -- returns exactly this list and the row's replay is skipped (flag 0).  Any equal pair, a
+// +-0 pair or a NaN among them sets the flag and topn_rows_strict_kernel redoes the row from the scores.
+__global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
+                                                         float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay) {
+  // One 256-thread block per detection (a wave per detection walked the keys in six dependent rounds of loads: 8 us of latency):
+  // every thread takes its keys in ONE round of loads, each wave extracts its best n + 1 with wave-wide minima, wave 0 merges the four lists.
+  __shared__ unsigned long long wbest[4][COS_NMAX];
+  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const unsigned long long* c = cand + (size_t)row * ncand;
+  unsigned long long k[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) k[e] = tid + 256 * e < ncand ? c[tid + 256 * e] : ~0ull;
+  for (int j = tid + 2048; j < ncand; j += 256) {  // (more than 2048 keys: not a shape the launcher produces; fold the rest in)
+    const unsigned long long key = c[j];
+    int worst = 0;
+#pragma unroll
+    for (int e = 1; e < 8; ++e) worst = k[e] > k[worst] ? e : worst;
+    if (key < k[worst]) k[worst] = key;
+  }
+  const int rounds = need_replay ? n_top + 1 : n_top;  // <= COS_NMAX
+  for (int s = 0; s < rounds; ++s) {
+    unsigned long long m = k[0];
+#pragma unroll
+    for (int e = 1; e < 8; ++e) m = k[e] < m ? k[e] : m;
+    const unsigned long long b = wave_min_u64(m);
+    if (lane == 0) wbest[wave][s] = b;
+    if (b != ~0ull) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (k[e] == b) k[e] = ~0ull;  // keys carry the unique template id: exactly one holder
+    }
+  }
+  __syncthreads();
+  if (wave != 0) return;
+  unsigned long long mine = lane < 4 * rounds ? wbest[lane / rounds][lane % rounds] : ~0ull;
+  float prev = 0.f;
+  int tie = 0;
+  for (int s = 0; s < rounds; ++s) {
+    const unsigned long long b = wave_min_u64(mine);
+    if (b == ~0ull) {
+      if (lane == 0 && s < n_top) { out_idx[(size_t)row * n_top + s] = -1; out_val[(size_t)row * n_top + s] = -INFINITY; }
+      continue;
+    }
+    const unsigned kb = ~(unsigned)(b >> 32);  // order_key inverted: the score's own bits
+    const float val = __uint_as_float((kb & 0x80000000u) ? (kb ^ 0x80000000u) : ~kb);
+    if (val != val || (s > 0 && !(prev > val))) tie = 1;  // wave-uniform
+    prev = val;
+    if (mine == b) {
+      if (s < n_top) {
+        out_idx[(size_t)row * n_top + s] = (int)(b & 0xffffffffu);
+        out_val[(size_t)row * n_top + s] = val;
+      }
+      mine = ~0ull;
     }
   }
   if (need_replay && lane == 0) need_replay[row] = tie;
@@ -1051,6 +1241,66 @@ int launch_topn_rows(const float* sims, int ld, int rows, int max_len, const int
 }
 
 int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+                       const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st);
+
+// scratch (floats) of the prefiltered retrieval, behind the FP_COSINE_SCRATCH_FLOATS region of the exact path:
+//   approx [num_det, T] | exact keys [num_det, 8 parts, ceil(T / 8)] u64 | counts [num_det, 8] | any_flag
+int launch_cosine_topk_prefiltered(const CosineArgs& a_in, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
+                                   const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, float* extra_scratch, hipStream_t st) {
+  CosineArgs a = a_in;
+  // Three dependent launches of ~10 us of latency each: the two-stage form pays for itself once the single-pass kernel has more than
+  // ~250 MB of fp32 bank to stream -- many templates, or several 32-detection passes over them (measured: 10 000 templates x 32
+  // detections 39 vs 40 us, 50 000 x 128 147 vs 319 us); below that the single-pass kernel stays the faster exact answer.
+  const bool worth = a.force_prefilter || (size_t)max_templates * (size_t)cdiv(max_det_per_obj, 32) >= 30000;
+  const bool ok = worth && a.bank_bf16 && a.W % 1024 == 0 && a.W <= 4096 && max_templates <= COS_PARTS * COS_LIST_CAP && n_top + 1 <= COS_NMAX && max_det_per_obj >= 1;
+  if (!ok) return launch_cosine_topk(a_in, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores, out_ids, tie_mode, st);
+  const int tp = cdiv(max_templates, COS_PARTS);
+  float* approx = extra_scratch;
+  unsigned long long* exact_keys = reinterpret_cast<unsigned long long*>(approx + (size_t)num_det * max_templates + ((size_t)num_det * max_templates & 1));
+  int* exact_cnt = reinterpret_cast<int*>(exact_keys + (size_t)num_det * COS_PARTS * tp);
+  int* any_flag = exact_cnt + (size_t)num_det * COS_PARTS;
+  a.k_slices = 8;
+  const int nblk = cdiv(max_templates, 16), n_emit = n_top + 1;
+  const int nq = max_det_per_obj <= 16 ? 1 : 2;
+  const int chunks = cdiv(max_det_per_obj, nq * 16);
+  const int per = fp_num_cus() / (num_obj * chunks);
+  const int gx = per < 1 ? 1 : (per > nblk ? nblk : per);
+  FP_REQUIRE(gx * n_emit <= 2048, "cosine_topk_prefiltered: too many candidate keys per detection");
+  if (tie_mode == 1) {
+    hipError_t e = hipMemsetAsync(any_flag, 0, sizeof(int), st);
+    if (e != hipSuccess) { fp_set_error("cosine_topk_prefiltered: memset: %s", hipGetErrorString(e)); return FP_ERR_HIP; }
+  }
+  // (1) approximate pass over the fp16 bank
+  CosineArgs b = a;
+  b.sims = approx; b.n_top = n_emit; b.run_flag = nullptr;  // (b.cand: the exact path's key region, free until its fallback runs)
+  const size_t lds = COS_RING_BYTES + (size_t)COS_RED_BUFS * 8 * nq * 4 * COS_RED_PITCH * 4;
+  static FpDeviceOnce attr1, attr2;
+  fp_allow_dynamic_lds(attr1, &cosine_fused_kernel<1, true>, COS_RING_BYTES + COS_RED_BUFS * 8 * 1 * 4 * COS_RED_PITCH * 4);
+  fp_allow_dynamic_lds(attr2, &cosine_fused_kernel<2, true>, COS_RING_BYTES + COS_RED_BUFS * 8 * 2 * 4 * COS_RED_PITCH * 4);
+  dim3 grid(gx, num_obj, chunks);
+  if (nq == 1) hipLaunchKernelGGL((cosine_fused_kernel<1, true>), grid, dim3(512), lds, st, b);
+  else hipLaunchKernelGGL((cosine_fused_kernel<2, true>), grid, dim3(512), lds, st, b);
+  FP_CHECK_LAUNCH("cosine_fused<fp16>");
+  // (2) candidates above (n+1)-th best - 2 eps, exact scores; (3) top n of the exact keys (+ tie flags in the strict order)
+  hipLaunchKernelGGL(cosine_rescore_kernel, dim3(COS_PARTS, num_det), dim3(512), 0, st, a, b.cand, gx * n_emit, n_emit, approx, exact_keys, exact_cnt, tp);
+  FP_CHECK_LAUNCH("cosine_rescore");
+  hipLaunchKernelGGL(cosine_final_kernel, dim3(cdiv(num_det, 4)), dim3(256), 0, st, exact_keys, exact_cnt, num_det, n_top,
+                     out_scores, out_ids, tie_mode == 1 ? a.need_replay : nullptr, any_flag, tp);
+  FP_CHECK_LAUNCH("cosine_final");
+  if (tie_mode == 0) return FP_OK;  // canonical order: (score, lowest id) is decided by the exact keys
+  // strict (torch) order: rows with a tie among their best n + 1 scores need the whole row of exact scores for the replay
+  CosineArgs f = a;
+  f.cand = nullptr; f.run_flag = any_flag;
+  static FpDeviceOnce attr3, attr4;
+  fp_allow_dynamic_lds(attr3, &cosine_fused_kernel<1>, COS_RING_BYTES + COS_RED_BUFS * 8 * 1 * 4 * COS_RED_PITCH * 4);
+  fp_allow_dynamic_lds(attr4, &cosine_fused_kernel<2>, COS_RING_BYTES + COS_RED_BUFS * 8 * 2 * 4 * COS_RED_PITCH * 4);
+  if (nq == 1) hipLaunchKernelGGL(cosine_fused_kernel<1>, grid, dim3(512), lds, st, f);
+  else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, f);
+  FP_CHECK_LAUNCH("cosine_fused(fallback)");
+  return launch_topn_rows(a.sims, a.ld_sims, num_det, max_templates, det_num_templates, n_top, out_scores, out_ids, 1, st, a.need_replay);
+}
+
+int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max_det_per_obj, int max_templates, int n_top,
                        const int* det_num_templates, float* out_scores, int* out_ids, int tie_mode, hipStream_t st) {
   CosineArgs a = a_in;
   FP_REQUIRE(a.W % 16 == 0, "cosine_topk: num_words %% 16 == 0 required on this path");
@@ -1079,7 +1329,7 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);
     FP_CHECK_LAUNCH("cosine_fused");
     if (want_cand) {
-      hipLaunchKernelGGL(cand_merge_kernel, dim3(cdiv(num_det, 4)), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
+      hipLaunchKernelGGL(cand_merge_kernel, dim3(num_det), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
                          tie_mode == 1 ? a.need_replay : nullptr);
       FP_CHECK_LAUNCH("cand_merge");
       if (tie_mode == 0) return FP_OK;

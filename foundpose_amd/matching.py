@@ -6,13 +6,14 @@ utils/template_util.py:126-176); the reference processes one detection at a time
 Detections must be grouped by object (ascending object index) so the bank is streamed once per object group.
 """
 
+import os
 from dataclasses import dataclass
 from typing import Dict, List, Optional, Sequence
 
 import torch
 
 from . import ops
-from ._lib import call, cosine_scratch_floats, cyclic_scratch_bytes, ptr, stream, require_cuda
+from ._lib import call, cosine_prefilter_scratch_floats, cosine_scratch_floats, cyclic_scratch_bytes, ptr, stream, require_cuda
 from .bank import DeviceBank
 
 
@@ -148,11 +149,16 @@ def match_batch(
     # ---- template retrieval: cosine vs the object's template descriptors, top-n
     # detections are sorted by object, so object o's detections are rows det_seg_h[o]:det_seg_h[o+1]
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
-    sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
-    call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
-         ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
+    if getattr(bank, "descs_bf", None) is not None and os.environ.get("FP_COSINE_PREFILTER", "1") != "0":  # env: A/B switch (same outputs bit for bit)
+        sims = torch.empty(cosine_prefilter_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)
+        call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n), ptr(bank.descs_bf),
+             ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
+    else:
+        sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys
+        call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
+             ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
 
     # ---- cyclic best buddies against the retrieved templates + correspondence assembly (the kernel pads its records itself)
     pairs = B * n   # (the kernels add the object's first template to the object-local ids themselves)

@@ -91,6 +91,22 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
                    const float* bank_n, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,
                    int n_top, float* scratch_sims, float* out_scores, int32_t* out_ids, int tie_mode, fp_stream_t stream);
 
+/* The same retrieval, same outputs bit for bit, in two stages (what match_batch calls): a first pass over an fp16 copy of the bank
+ * (bank_n_f16 [T_total, num_words], round to nearest even; half the bytes, 1/16 of the matrix time) leaves approximate scores,
+ * provably within eps = 2^-10 x 1.5625 of the exact ones for L2-normalised rows (bound derived in csrc/match.hip); every template within 2 eps of the (n_top + 1)-th best approximate score
+ * -- a superset of the exact top n_top + 1, however large -- is then re-scored with the exact fp32 chain of fp_cosine_topk, and the
+ * top n_top of those exact scores is the answer.  tie_mode 1: a row whose best n_top + 1 exact scores contain a tie needs its whole
+ * row for the replay of torch.topk's order; such rows release fp_cosine_topk's single-pass kernel and the replay behind a device-side
+ * flag (both exit at once otherwise).  The three dependent launches cost ~10 us of latency each, so the two-stage form is taken only
+ * when the single pass would stream more than ~250 MB (max_templates x ceil(max_det_per_obj / 32) >= 30 000; tie_mode |
+ * FP_COSINE_FORCE_PREFILTER forces it); otherwise, and when num_words is not a multiple of 1024 (<= 4096), for more than 65536
+ * templates per object or n_top > 7, the call IS fp_cosine_topk.  scratch: FP_COSINE_PREFILTER_SCRATCH_FLOATS(num_det, max_templates) floats. */
+#define FP_COSINE_FORCE_PREFILTER 256
+#define FP_COSINE_PREFILTER_SCRATCH_FLOATS(num_det, max_templates) (FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) + 3 * (size_t)(num_det) * (size_t)(max_templates) + 32 * (size_t)(num_det) + 16)
+int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det, int max_det_per_obj,
+                               const float* bank_n, const void* bank_n_f16, const int32_t* obj_tpl_off, int num_obj, int max_templates, int num_words,
+                               int n_top, float* scratch, float* out_scores, int32_t* out_ids, int tie_mode, fp_stream_t stream);
+
 /* Cyclic best-buddy matching of every detection against its n_slots retrieved templates and assembly of the
  * 2D-3D correspondences (cyclic_buddies_matching + the gather in establish_correspondences,
  * utils/corresp_util.py:34-70,107-155).

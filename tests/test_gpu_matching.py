@@ -662,3 +662,99 @@ def test_strict_topn_adversarial_rows(T, order):
         tv, ti = torch.topk(S[b], 5, sorted=True)
         assert ids[b].cpu().tolist() == ti.tolist(), (order, b)
         assert torch.equal(sc[b].cpu(), tv)
+
+
+# ------------------------------------------------------------------ prefiltered retrieval == single-pass retrieval, bit for bit
+def _both_retrievals(desc_n, bank_n, seg, tpl_off, nt, n_top, tie_mode, max_det):
+    """-> ((scores, ids) of fp_cosine_topk, (scores, ids) of fp_cosine_topk_prefiltered) on the same inputs."""
+    from foundpose_amd._lib import call, cosine_prefilter_scratch_floats, cosine_scratch_floats, ptr, stream
+    B, W = desc_n.shape
+    T = int((tpl_off[1:] - tpl_off[:-1]).max())
+    bank_bf = bank_n.to(torch.float16).contiguous()
+    out = []
+    for pre in (False, True):
+        sims = torch.full((cosine_prefilter_scratch_floats(B, T) if pre else cosine_scratch_floats(B, T),), float("nan"), device="cuda")  # poisoned scratch
+        sc, ids = torch.empty(B, n_top, device="cuda"), torch.empty(B, n_top, dtype=torch.int32, device="cuda")
+        if pre:
+            call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(seg), ptr(nt), B, max_det, ptr(bank_n), ptr(bank_bf), ptr(tpl_off), tpl_off.shape[0] - 1, T, W,
+                 n_top, ptr(sims), ptr(sc), ptr(ids), tie_mode | 256, stream())   # | FP_COSINE_FORCE_PREFILTER: the two-stage form at every size
+        else:
+            call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), B, max_det, ptr(bank_n), ptr(tpl_off), tpl_off.shape[0] - 1, T, W, n_top, ptr(sims), ptr(sc),
+                 ptr(ids), tie_mode, stream())
+        torch.cuda.synchronize()
+        out.append((sc.clone(), ids.clone()))
+    return out
+
+
+def _assert_same(a, b, what):
+    assert torch.equal(a[1], b[1]), f"{what}: ids differ\n{a[1]}\n{b[1]}"
+    assert torch.equal(a[0].view(torch.int32), b[0].view(torch.int32)), f"{what}: scores differ"
+
+
+@pytest.mark.parametrize("tie_mode", [0, 1])
+@pytest.mark.parametrize("T,W,B", [(10000, 2048, 32), (3000, 1024, 7), (800, 4096, 40), (16, 2048, 3), (3, 2048, 2), (50000, 2048, 32)])
+def test_prefiltered_retrieval_equals_single_pass(T, W, B, tie_mode):
+    """The two-stage retrieval (fp16 candidate pass + exact re-scoring) returns the single-pass kernel's scores and ids bit for bit: tf-idf-like
+    sparse banks at the metric's size and config 5's, more than 32 detections of an object (two chunks), fewer templates than n_top + 1."""
+    from foundpose_amd import ops
+    bank_n = _full_size_bank(T, W, seed=T + W)
+    g = torch.Generator(device="cuda").manual_seed(B)
+    desc_n = ops.normalize_rows(torch.rand(B, W, generator=g, device="cuda") * (torch.rand(B, W, generator=g, device="cuda") < 0.05) + 1e-4)
+    desc_n[0] = bank_n[T // 2]                                  # one query is a bank row: score 1 at the top
+    seg = torch.tensor([0, B], dtype=torch.int32, device="cuda")
+    off = torch.tensor([0, T], dtype=torch.int32, device="cuda")
+    nt = torch.full((B,), T, dtype=torch.int32, device="cuda")
+    a, b = _both_retrievals(desc_n, bank_n, seg, off, nt, 5, tie_mode, B)
+    _assert_same(a, b, f"T={T} W={W} B={B} tie_mode={tie_mode}")
+    if T >= 5:
+        assert int(b[1][0, 0]) == T // 2
+
+
+@pytest.mark.parametrize("tie_mode", [0, 1])
+def test_prefiltered_retrieval_adversarial_rows(tie_mode):
+    """Rows built against the candidate logic: (a) duplicated templates at the top (exact ties -> the strict order releases the fallback),
+    (b) a tie across the cut, (c) every template identical (everything is a candidate and everything ties), (d) a dense band of
+    near-equal scores around rank 6 (hundreds of candidates inside 2 eps), (e) all scores exactly zero, (f) a NaN in a descriptor."""
+    from foundpose_amd import ops
+    rng = np.random.default_rng(7)
+    T, W = 2000, 2048
+    base = (rng.random((T, W)) * (rng.random((T, W)) < 0.03)).astype(np.float32)
+    base[:, 0] += 1e-3
+    q = (rng.random(W) * (rng.random(W) < 0.1)).astype(np.float32) + 1e-4
+    order = np.argsort(-(base / np.linalg.norm(base, axis=1, keepdims=True)) @ (q / np.linalg.norm(q)))
+    bank_a = base.copy(); bank_a[order[1]] = bank_a[order[0]]; bank_a[order[3]] = bank_a[order[2]]
+    bank_b = base.copy(); bank_b[order[5]] = bank_b[order[4]]
+    bank_c = np.repeat(base[:1], T, 0)
+    bank_d = base.copy()
+    for r in range(5, 405):                                      # 400 templates = rank-6 template + a tiny perturbation
+        bank_d[order[r]] = base[order[5]] * (1.0 + 1e-4 * rng.standard_normal(W).astype(np.float32))
+    qz = np.zeros(W, np.float32); qz[W // 2:] = 1.0
+    bank_e = base.copy(); bank_e[:, W // 2:] = 0.0
+    cases = [("a", bank_a, q), ("b", bank_b, q), ("c", bank_c, q), ("d", bank_d, q), ("e", bank_e, qz)]
+    seg, off, nt = cu(np.array([0, 1], np.int32)), cu(np.array([0, T], np.int32)), cu(np.full(1, T, np.int32))
+    for name, bk, qq in cases:
+        bank_n, q_n = ops.normalize_rows(cu(bk)), ops.normalize_rows(cu(qq[None]))
+        a, b = _both_retrievals(q_n, bank_n, seg, off, nt, 5, tie_mode, 1)
+        _assert_same(a, b, f"case {name} tie_mode={tie_mode}")
+    bank_n = ops.normalize_rows(cu(base))
+    bank_n[order[2], 7] = float("nan")                           # (f) a NaN score ranks first in both paths
+    a, b = _both_retrievals(ops.normalize_rows(cu(q[None])), bank_n, seg, off, nt, 5, tie_mode, 1)
+    assert torch.equal(a[1], b[1]) and torch.equal(a[0].isnan(), b[0].isnan()) and torch.equal(a[0].nan_to_num(7.0), b[0].nan_to_num(7.0))
+
+
+def test_prefiltered_retrieval_multi_object_groups():
+    """Three objects with different template counts, detections grouped by object (one of them with no detection): the prefiltered call
+    serves every (object, chunk) pair like the single-pass call."""
+    from foundpose_amd import ops
+    Ts, W = [700, 2500, 64], 2048
+    bank_n = torch.cat([_full_size_bank(t, W, seed=11 + i) for i, t in enumerate(Ts)])
+    off = torch.tensor([0, 700, 3200, 3264], dtype=torch.int32, device="cuda")
+    dets = [35, 0, 4]                                           # 35 detections of object 0 (two chunks), none of object 1, four of object 2
+    B = sum(dets)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    desc_n = ops.normalize_rows(torch.rand(B, W, generator=g, device="cuda") * (torch.rand(B, W, generator=g, device="cuda") < 0.05) + 1e-4)
+    seg = torch.tensor([0, 35, 35, 39], dtype=torch.int32, device="cuda")
+    nt = torch.tensor([700] * 35 + [64] * 4, dtype=torch.int32, device="cuda")
+    for tie_mode in (0, 1):
+        a, b = _both_retrievals(desc_n, bank_n, seg, off, nt, 5, tie_mode, 35)
+        _assert_same(a, b, f"multi-object tie_mode={tie_mode}")

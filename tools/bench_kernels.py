@@ -59,8 +59,13 @@ def main():
     if "cos" in what:
         from foundpose_amd._lib import call, ptr, stream
         for T, W, Bq in ((10000, 2048, 32), (800, 2048, 32), (50000, 2048, 128)):
-            bank_n = ops.normalize_rows(torch.rand(T, W, device=dev))
-            desc_n = ops.normalize_rows(torch.rand(Bq, W, device=dev))
+            # tf-idf-like rows: ~half of the words present (a template's ~375 patches x 3 words of 2048), queries likewise.  (Dense iid
+            # uniform rows are the degenerate case of the prefiltered call -- all scores within the candidate window -- BENCH_DENSE=1.)
+            if os.environ.get("BENCH_DENSE") == "1":
+                bank_n, desc_n = ops.normalize_rows(torch.rand(T, W, device=dev)), ops.normalize_rows(torch.rand(Bq, W, device=dev))
+            else:
+                bank_n = ops.normalize_rows(torch.rand(T, W, device=dev) * (torch.rand(T, W, device=dev) < 0.5) + 1e-6)
+                desc_n = ops.normalize_rows(torch.rand(Bq, W, device=dev) * (torch.rand(Bq, W, device=dev) < 0.5) + 1e-6)
             seg = torch.tensor([0, Bq], dtype=torch.int32, device=dev)
             tpl = torch.tensor([0, T], dtype=torch.int32, device=dev)
             nt = torch.full((Bq,), T, dtype=torch.int32, device=dev)
@@ -72,6 +77,13 @@ def main():
                                          ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)
                 passes = (Bq + 31) // 32
                 print(f"cosine_topk T={T} W={W} B={Bq} tie_mode={mode}: {ms*1e3:8.1f} us  {passes*(T*W*4)/ms/1e6:7.1f} GB/s (bank bytes x {passes} pass(es))", flush=True)
+            from foundpose_amd._lib import cosine_prefilter_scratch_floats
+            bank_bf = bank_n.to(torch.float16).contiguous()
+            sims2 = torch.empty(cosine_prefilter_scratch_floats(Bq, T), device=dev)
+            for mode in (0, 1):
+                ms = timeit(lambda: call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank_n), ptr(bank_bf), ptr(tpl), 1, T, W, 5,
+                                         ptr(sims2), ptr(sc), ptr(ids), mode | 256, stream()), iters=50)
+                print(f"cosine_topk_prefiltered T={T} W={W} B={Bq} tie_mode={mode}: {ms*1e3:8.1f} us  {passes*(T*W*4)/ms/1e6:7.1f} GB/s of fp32 bank bytes", flush=True)
     if "match" in what:
         # the three exact-fp32 tile launches of one matching step at the bench shapes: PCA 1024 -> 256 of 32 x 517 patches,
         # visual-word 3-NN (2048 words), cyclic distance tiles of 32 x 5 (query crop, template) pairs
