@@ -88,6 +88,8 @@ def main():
                     help="the near-exact mode timed next to the headline as `parity_mode` (f16x3: split-fp16 operands, three fp16 MFMAs per product; "
                          "fp32: the exact-fp32 MFMA mode) with its index agreement against oracle A and the fp32 mode")
     ap.add_argument("--parity-steps", type=int, default=5)
+    ap.add_argument("--skip-probes", action="store_true", help="time the steps and stop: no roofline probe launches, no parity passes (tools/pmc_bench.sh: every "
+                                                                "launch the counters see then belongs to a step of the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
     ap.add_argument("--cpu-detections", type=int, default=3)
@@ -177,6 +179,14 @@ def main():
         cnt = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(cnt)
         assert int(cnt.item()) == world == ranks_seen, "every rank must contribute its records to the gather"
+    if args.skip_probes:
+        if rank == 0:
+            print(json.dumps({"metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank", "value": round(det_per_s, 2), "unit": "detections/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "probes": "skipped"}), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     # the other tie order, timed next to the headline (same inputs; not part of `value`)
     other = "canonical" if args.tie_order == "torch" else "torch"
     eng_o = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=other)
@@ -284,6 +294,21 @@ def main():
         knn5_bytes = T5 * 2048 * 4 + 32 * 2048 * 4 + 32 * T5 * 4
         del bank5, sims5
         key = (args.version, args.size, B, args.precision)
+        # ---- the whole matching stage of a step: PCA projection + word k-NN + tf-idf + retrieval + 5 x cyclic matching, timed
+        # with HIP events inside the engine on one extra step; algorithmic bytes by 8d's formula with the fp32 element size
+        eng.record_stage_times = True
+        step()
+        st_t = eng.stage_times()
+        eng.record_stage_times = False
+        sumQ = int(masks[:, 7::14, 7::14].sum())
+        P_bar = bank.feats.shape[0] / max(1, bank.descs_n.shape[0])
+        match_bytes = (args.objects * args.templates * W_words * 4 + B * 5 * P_bar * 256 * 4 + args.objects * W_words * 256 * 4 + sumQ * 256 * 4
+                       + B * 5 * 300 * 12)
+        match_flops = 2.0 * sumQ * W_words * 256 + 2.0 * B * args.templates * W_words + 5 * 2 * 2.0 * (sumQ / B) * P_bar * 256 * B
+        ms_match = 1e3 * (st_t.get("corresp", 0.0))
+        ms_projn = 1e3 * st_t.get("proj", 0.0)
+        # proj is the one block GEMM whose floor is HBM, not the matrix pipe: fp32 residual read + write, bf16 copy, operands
+        proj_bytes = mv * arch.dim * (2 + 4 + 4 + (2 if fold else 0)) + arch.dim * arch.dim * 2
         result = {
             "metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank",
             "value": round(det_per_s, 2), "unit": "detections/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -306,7 +331,11 @@ def main():
                          "flops_per_launch": ls_flops / 2},
             "roofline_other_gemms": {"fc1": {"launch_ms": round(ms_fc1, 4), "frac": round(fl(hid if arch.ffn == "mlp" else 2 * hid, arch.dim) / (ms_fc1 * 1e-3) / 1e12 / peak_mfma, 4)},
                                      "qkv": {"launch_ms": round(ms_qkv, 4), "frac": round(fl(3 * arch.dim, arch.dim) / (ms_qkv * 1e-3) / 1e12 / peak_mfma, 4)},
-                                     "proj": {"launch_ms": round(ms_proj, 4), "frac": round(fl(arch.dim, arch.dim) / (ms_proj * 1e-3) / 1e12 / peak_mfma, 4)},
+                                     "proj": {"launch_ms": round(ms_proj, 4), "frac": round(fl(arch.dim, arch.dim) / (ms_proj * 1e-3) / 1e12 / peak_mfma, 4),
+                                              "hbm_bound": {"bytes_per_launch": proj_bytes, "achieved_GBs": round(proj_bytes / (ms_proj * 1e-3) / 1e9, 1),
+                                                            "frac_of_hbm_peak": round(proj_bytes / (ms_proj * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                                            "note": "K = D: 92 GF of matrix work against 0.54 GB of operands + fp32 residual read-modify-write + bf16 copy: "
+                                                                    "this launch is bounded by HBM (floor 68 us at 8 TB/s), not by the MFMA roofline"}},
                                      "fc2": {"launch_ms": round(ms_fc2, 4), "frac": round(fl(arch.dim, hid) / (ms_fc2 * 1e-3) / 1e12 / peak_mfma, 4)}},
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
                                         "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": flops_exec,
@@ -319,6 +348,15 @@ def main():
                              "fp32_mfma_tflops": round(knn_flops / (ms_knn * 1e-3) / 1e12, 1), "fp32_mfma_peak": 157.3,
                              "note": "exact-fp32 scores: at 32 detections per bank pass the op sits at the fp32-MFMA / HBM ridge (16 FLOP/B vs 19.7), "
                                      "more detections per object add passes (32 at a time) and make it MFMA-bound"},
+            "roofline_matching_stage": {"what": "everything behind the sampled features in one step: word 3-NN, tf-idf, template retrieval, 5 x cyclic matching, record assembly "
+                                                "(engine stage `corresp`); the PCA projection (stage `proj`) is listed beside it",
+                                        "bound": "hbm", "ms_per_step": round(ms_match, 4), "ms_proj": round(ms_projn, 4), "bytes_per_step": int(match_bytes),
+                                        "achieved": round(match_bytes / (ms_match * 1e-3) / 1e9, 1) if ms_match > 0 else None, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                        "frac": round(match_bytes / (ms_match * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if ms_match > 0 else None,
+                                        "fp32_flops_per_step": match_flops, "fp32_mfma_floor_ms": round(match_flops / 157.3e12 * 1e3, 4),
+                                        "frac_of_fp32_mfma_floor": round(match_flops / 157.3e12 * 1e3 / ms_match, 4) if ms_match > 0 else None,
+                                        "note": "exact fp32 arithmetic (bit parity with the reference's searches): the stage's floor is the fp32-MFMA time of its three "
+                                                "distance / score products, not its 0.16 GB of algorithmic bytes"},
             "roofline_knn_50k_templates": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}', 50 000 templates x 32 detections (BASELINE config 5's bank, random descriptors)",
                                            "bound": "hbm", "achieved": round(knn5_bytes / (ms_knn5 * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                            "frac": round(knn5_bytes / (ms_knn5 * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn5, 4),

@@ -112,7 +112,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   // DMA issue is asymmetric on the 8-wave tile: only the waves of row wm == 0 fetch (every SIMD hosts one wave of each
   // row).  A global/buffer_load..lds blocks its wave for ~60-180 issue cycles; when all eight waves issue their pieces
   // in lock step the matrix pipes idle meanwhile, when one wave per SIMD does it the other keeps its SIMD's pipe fed.
+#ifdef FP_GEMM_ALT  // measurement build: every wave issues half as many pieces, the two wave rows in alternating halves of the K-tile
+  constexpr bool ASYM = false;
+  constexpr bool ALT = NW == 8;
+#else
   constexpr bool ASYM = NW == 8;
+  constexpr bool ALT = false;
+#endif
   constexpr int NISSUE = ASYM ? NW / 2 : NW;
   constexpr int A_INSTR = BM / 8 / NISSUE, B_INSTR = BN / 8 / NISSUE;  // DMA instructions per issuing wave per K-tile
   constexpr int PIECES = A_INSTR + B_INSTR;
@@ -268,6 +274,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+          if constexpr (ALT) {  // wave row 0 issues its pieces during k-steps 0, 1 -- row 1 during 2, 3
+            const int slot = ks - 2 * wm;
+            if (more && slot >= 0 && slot < 2) {
+#pragma unroll
+              for (int q = 0; q < PIECES / 2; ++q) stage_piece(slot * (PIECES / 2) + q, t + 1, nxt);
+            }
+          } else
           if (more) {
 #pragma unroll
             for (int q = 0; q < PER_KS; ++q) stage_piece(ks * PER_KS + q, t + 1, nxt);

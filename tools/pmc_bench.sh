@@ -7,13 +7,13 @@ tag=${1:-pmc}
 R=$GRAFT_REPO_ROOT
 out=$R/gpurun_out/${tag}_pmc_traffic.txt
 cd /tmp && export TMPDIR=/tmp
-echo "# rocprofv3 --pmc over: python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity (averages per launch, KiB as reported)" > $out
+echo "# rocprofv3 --pmc over: python bench.py --steps 3 --warmup 1 --skip-probes (averages per launch AND launch grid, KiB as reported)" > $out
 echo "# FETCH_SIZE on gfx950 counts 64 B per 128-B request of wide coalesced streams: double it (guide, HBM section); WRITE_SIZE as reported" >> $out
 for ctr in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pmcb_$ctr
   rm -rf $d
-  timeout 400 rocprofv3 --pmc $ctr -d $d -o r -- python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity > /dev/null 2>&1 || echo "pass $ctr failed/timeout" >> $out
+  timeout 400 rocprofv3 --pmc $ctr -d $d -o r -- python $R/bench.py --steps 3 --warmup 1 --skip-probes > /dev/null 2>&1 || echo "pass $ctr failed/timeout" >> $out
   db=$(find $d -name "*.db" 2>/dev/null | head -1)
-  [ -n "$db" ] && python $R/tools/pmc_summary.py $db "" | grep -i "gemm_bf16\|attn_bf16\|cosine_fused\|f32_tile\|layernorm\|topn_rows\|cyclic" >> $out
+  [ -n "$db" ] && python $R/tools/pmc_summary.py $db "" | grep -i "gemm_bf16\|attn_bf16\|cosine_\|cand_merge\|f32_tile\|layernorm\|ln_sample\|topn_rows\|cyclic" >> $out
 done
 cat $out
