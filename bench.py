@@ -297,7 +297,7 @@ def main():
         # ---- the whole matching stage of a step: PCA projection + word k-NN + tf-idf + retrieval + 5 x cyclic matching, timed
         # with HIP events inside the engine on one extra step; algorithmic bytes by 8d's formula with the fp32 element size
         eng.record_stage_times = True
-        step()
+        fe.pack_result(eng.infer_batch(images, masks, det_obj))   # (rank 0 alone here: no collective)
         st_t = eng.stage_times()
         eng.record_stage_times = False
         sumQ = int(masks[:, 7::14, 7::14].sum())

@@ -226,14 +226,17 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 
 // QB = 32-query blocks per wave: 2 (4 waves per block, 208 VGPRs, 2 waves/SIMD -- the default) or 1 (8 waves per block of the
 // same 256 queries, <= 128 VGPRs, 4 waves/SIMD: more waves to overlap, twice the LDS fragment traffic per flop).
-template <int QB>
-__global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) {
+// NW = waves per block (default 512 / (64 QB): a 256-query block); QB = 2 with NW = 8 is a 512-query block: a staged K/V tile then serves
+// twice the queries (variant 3, measured in DESIGN section 5).  Each wave stages GW = 8 / NW of the tile's eight 8-key row groups.
+template <int QB, int NW = 8 / QB>
+__global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
+  constexpr int QBLK = NW * 32 * QB, GW = 8 / NW;
   __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: DMA offsets
   const int l31 = lane & 31, kh = lane >> 5;
   int qt, head, img;
   {
-    const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + QBLK - 1) / QBLK, pairs = a.heads * a.batch, i = blockIdx.x;
     int pair;
     if ((pairs & 7) == 0) {  // all query tiles of an (image, head) pair on one XCD (one L2), see attn_bf16_kernel
       const int j = i >> 3;
@@ -251,15 +254,15 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   // queries: every token, or the image's selected tokens (the keys are always all N tokens)
   const int sel_base = a.sel_off ? a.sel_off[img] : 0;
   const int NQ = a.sel_off ? a.sel_off[img + 1] - sel_base : N;
-  if (qt * 256 >= NQ) return;  // selected mode: the grid is sized for the image with the most queries
+  if (qt * QBLK >= NQ) return;  // selected mode: the grid is sized for the image with the most queries
   // The last query tile of an (image, head) pair is usually short (1374 tokens = 5 x 256 + 94).  With two 32-query blocks
   // per wave only 2 of its 4 waves would have queries, each doing a full tile's work: the block would cost as much as a
   // full one for 37 % of the queries.  When <= 128 queries remain every wave takes ONE 32-query block instead (the QC = 1
   // instantiation of the tile loop): the same arithmetic per query, half the work per wave, the tail block ends in about
   // half the time.  Block-uniform.
-  const bool short_tail = QB == 2 && qt == (NQ + 255) / 256 - 1 && NQ - qt * 256 <= 128;
+  const bool short_tail = QB == 2 && qt == (NQ + QBLK - 1) / QBLK - 1 && NQ - qt * QBLK <= QBLK / 2;
   const int nqb = short_tail ? 1 : QB;
-  const int q0 = qt * 256 + wave * (32 * nqb);
+  const int q0 = qt * QBLK + wave * (32 * nqb);
   const bool active = q0 < NQ;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
 
   // ---- staging: wave w issues row groups 2w, 2w+1 (8 keys x 128 B each) of K and of V
@@ -270,13 +273,13 @@ __global__ __launch_bounds__(512 / QB, 2) void attn_bf16_w64_kernel(AttnArgs a) 
   const unsigned voff_k1 = rowoff + ((sp ^ ((sr >> 1) + 4)) << 4);  // odd row group: ... + 4
   const unsigned voff_v = rowoff + ((sp ^ (((sr >> 1) & 1) << 2)) << 4);
   const unsigned tile_stride = (unsigned)(64 * a.ld_qkv) * 2u, grp_stride = (unsigned)(8 * a.ld_qkv) * 2u;
-  const unsigned soff_k = (unsigned)(D + head * 64) * 2u + (unsigned)QB * wave * grp_stride, soff_v = soff_k + (unsigned)D * 2u;
-  const unsigned voff_kw = (wave & 1) ? voff_k1 : voff_k0;  // QB == 1: wave w stages row group w only
+  const unsigned soff_k = (unsigned)(D + head * 64) * 2u + (unsigned)GW * wave * grp_stride, soff_v = soff_k + (unsigned)D * 2u;
+  const unsigned voff_kw = (wave & 1) ? voff_k1 : voff_k0;  // GW == 1: wave w stages row group w only
   auto stage_tile = [&](int kt, int stage) {
     const unsigned t = kt * tile_stride;
-    char* kd = KV[stage][0] + wave * (1024 * QB);
-    char* vd = KV[stage][1] + wave * (1024 * QB);
-    if constexpr (QB == 2) {
+    char* kd = KV[stage][0] + wave * (1024 * GW);
+    char* vd = KV[stage][1] + wave * (1024 * GW);
+    if constexpr (GW == 2) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
@@ -731,15 +734,16 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
-    FP_REQUIRE(a.variant >= 0 && a.variant <= 2, "attention: unknown kernel variant %d", a.variant);
-    const int w64 = a.variant == 1 ? 0 : (a.variant == 2 ? 2 : 1);  // default: 64 queries per wave
+    FP_REQUIRE(a.variant >= 0 && a.variant <= 3, "attention: unknown kernel variant %d", a.variant);
+    const int w64 = a.variant == 1 ? 0 : (a.variant == 2 ? 2 : 1);  // default: 64 queries per wave; 3: the same with 8 waves = 512-query blocks
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     const bool sel = a.sel_off != nullptr;
     FP_REQUIRE(!sel || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");
     FP_REQUIRE(!sel || (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull), "attention: query selection exists in the 64-queries-per-wave kernel only");
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
-      const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, 256) * a.heads * a.batch);
-      if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
+      const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, a.variant == 3 ? 512 : 256) * a.heads * a.batch);
+      if (a.variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
+      else if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);

@@ -596,6 +596,9 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   //  hooked block's selected rows, proj 79 -> 67 us, fc2 207 -> 195 us; results do not depend on the tile)
   const int tiles_big = (a.M / 256) * (a.N / 256), cus = fp_num_cus();
   const bool use_big = big_ok && (force == 256 || (force == 0 && tiles_big >= cus && !(tiles_big > cus && tiles_big < cus + cus / 2)));
+  // (Measured and dropped, round 3: sending the m-tiles that hold the few tiles beyond a whole number of rounds -- qkv at the bench batch:
+  //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us.  The stragglers of a single launch start while other CUs
+  //  are still inside their eighth tile and cost far less than a round; a dependent second launch costs its own latency.)
   if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
 }

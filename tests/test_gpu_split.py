@@ -208,3 +208,4 @@ def test_extractor_f16x3_facets_vs_fp32_mode():
         a = feature_util.make_feature_extractor(name, state_dict=sd, arch=TINY, precision="fp32").to("cuda")(imgs)["feature_maps"]
         b = feature_util.make_feature_extractor(name, state_dict=sd, arch=TINY, precision="f16x3").to("cuda")(imgs)["feature_maps"]
         assert rel_err(b, a) < 2e-5
+

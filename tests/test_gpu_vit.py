@@ -116,6 +116,9 @@ def test_attention_bf16_work_splits_agree_bitwise(B, N, heads):
     o_a = ops.attention(q16, B, N, D, heads, variant=1).clone()   # 32 queries per wave, register staging
     o_b = ops.attention(q16, B, N, D, heads, variant=0).clone()   # the pipeline's kernel
     o_c = ops.attention(q16, B, N, D, heads, variant=2)           # the DMA kernel with one 32-query block per wave, 8 waves per block
+    o_d = ops.attention(q16, B, N, D, heads, variant=3)           # 8 waves x 64 queries: 512-query blocks
+    torch.cuda.synchronize()
+    assert torch.equal(o_a.view(torch.int16), o_d.view(torch.int16))
     torch.cuda.synchronize()
     assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_c.view(torch.int16))
 

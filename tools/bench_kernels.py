@@ -38,7 +38,7 @@ def main():
             bias = torch.randn(n, device=dev)
             gamma = torch.randn(n, device=dev)
             out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
-            for tile in (256, 128):
+            for tile in (0, 256, 128):   # 0 = the launcher's choice (incl. the tail split of near-whole round counts)
                 ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
                 print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "fp8" in what:
@@ -54,8 +54,10 @@ def main():
         print(f"quantize_fp8 bf16 [{M}, {4*D}]: {ms*1e3:8.1f} us  {M*4*D*3/ms/1e6:7.1f} GB/s", flush=True)
     if "attn" in what:
         qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
-        ms = timeit(lambda: ops.attention(qkv, B, N, D, H))
-        print(f"attn B={B} N={N} H={H}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
+        for rep in range(2):
+            for variant in (0, 3, 2):
+                ms = timeit(lambda: ops.attention(qkv, B, N, D, H, variant=variant))
+                print(f"attn B={B} N={N} H={H} variant={variant}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
     if "cos" in what:
         from foundpose_amd._lib import call, ptr, stream
         for T, W, Bq in ((10000, 2048, 32), (800, 2048, 32), (50000, 2048, 128)):
