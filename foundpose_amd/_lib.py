@@ -13,7 +13,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8, FP_F16X3 = 0, 1, 2, 3
-SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 128.0, 64.0, 64.0  # FP_SPLIT_SCALE_* of the header
+SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header
 ABI_VERSION = 12
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64

@@ -35,9 +35,12 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of 
  * a b = hi_a hi_b + hi_a lo_b + lo_a hi_b (the dropped lo lo term is <= 2^-22 relative).
  * Storage: a logical row of K values (K % 32 == 0) is 2K halves: group g = k / 32 holds hi(x[32g .. 32g + 31]) in halves
  * [64g, 64g + 32) and lo(...) in [64g + 32, 64g + 64).  Fixed scales of the activation rows inside fp_vit_forward: */
-#define FP_SPLIT_SCALE_ACT 128.f /* LayerNorm outputs, attention outputs, normalised pixels of the patch rows */
-#define FP_SPLIT_SCALE_QKV 64.f  /* q, k, v rows written by the qkv GEMM */
-#define FP_SPLIT_SCALE_HID 64.f  /* hidden activations written by the GELU / SwiGLU epilogue */
+#define FP_SPLIT_SCALE_ACT 16.f /* LayerNorm outputs, attention outputs, normalised pixels of the patch rows: saturation at +-4094 */
+#define FP_SPLIT_SCALE_QKV 16.f /* q, k, v rows written by the qkv GEMM: saturation at +-4094 */
+#define FP_SPLIT_SCALE_HID 4.f  /* hidden activations written by the GELU / SwiGLU epilogue: saturation at +-16376 */
+/* (A pair represents x to within max(2^-22 |x|, 2^-25 / s): the lo half of a small value is an fp16 subnormal, which the MFMA
+ *  multiplies like any other number, so a modest scale costs nothing on O(1) activations and leaves three decades of head room for
+ *  the outlier channels of real checkpoints.) */
 
 #define FP_ABI_VERSION 12
 int fp_abi_version(void);

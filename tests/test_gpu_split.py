@@ -209,3 +209,26 @@ def test_extractor_f16x3_facets_vs_fp32_mode():
         b = feature_util.make_feature_extractor(name, state_dict=sd, arch=TINY, precision="f16x3").to("cuda")(imgs)["feature_maps"]
         assert rel_err(b, a) < 2e-5
 
+
+def test_extractor_f16x3_with_massive_activation_channels():
+    """Real checkpoints carry a few residual channels hundreds of times larger than the rest (and tokens whose hidden activations are
+    in the hundreds).  Plant them -- one fc2 output channel x 400 in block 0, one fc1 unit x 60 in block 1 -- and check that the pairs'
+    fixed scales have the head room: f16x3 stays at the fp32 mode's noise level and nothing saturates."""
+    from foundpose_amd import feature_util
+    arch = ARCHS["vits14-reg"]
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1"
+    sd = {k: v.clone() for k, v in synthetic.make_vit_state_dict(arch, seed=5).items()}
+    sd["blocks.0.mlp.fc2.weight"][17] *= 400.0
+    sd["blocks.1.mlp.fc1.weight"][33] *= 60.0
+    sd["blocks.1.mlp.fc1.bias"][33] += 150.0
+    imgs = synthetic.make_crops(2, 224, seed=2)
+    ref = ov.extractor_forward(sd, arch, imgs, 9, True)["feature_maps"]
+    hs = ov.hidden_after_block(sd, arch, imgs, 0, None, False, None)
+    assert float(hs.abs().max()) > 100.0          # the planted channel really is massive
+    outs = {}
+    for prec in ("fp32", "f16x3"):
+        ex = feature_util.make_feature_extractor(name, state_dict=sd, precision=prec).to("cuda")
+        outs[prec] = ex(imgs.cuda())["feature_maps"].cpu()
+        assert bool(torch.isfinite(outs[prec]).all())
+    e32, e3 = rel_err(outs["fp32"], ref), rel_err(outs["f16x3"], ref)
+    assert e3 < 3 * e32 + 1e-5 and e3 < 1e-4, (e3, e32)
