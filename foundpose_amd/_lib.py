@@ -31,7 +31,7 @@ class VitModel(C.Structure):
         ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
         ("ffn_swiglu", i32), ("weight_dtype", i32),
         ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
-        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("patch_acc_scale", f32), ("ln_fold", i32),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("patch_stride", i32), ("patch_acc_scale", f32), ("ln_fold", i32),
     ]
 
 

@@ -427,8 +427,10 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
                      const VitSelection* sel, fp_stream_t stream) {
   FP_REQUIRE(m && ws && (images || mode == VIT_LAST_SELECTED) && m->blocks, "fp_vit_forward: null pointer");
   FP_REQUIRE(layer >= -1 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);  // -1: token embedding only
-  FP_REQUIRE(H % m->patch == 0 && W % m->patch == 0, "fp_vit_forward: image size must be a multiple of the patch size");
-  const int D = m->dim, np = (H / m->patch) * (W / m->patch), ntok = 1 + m->registers + np;
+  const int pstride = m->patch_stride > 0 ? m->patch_stride : m->patch;  // the conv stride of the patch embedding (dinov2_utils.py:364-389)
+  FP_REQUIRE(pstride != m->patch || (H % m->patch == 0 && W % m->patch == 0), "fp_vit_forward: image size must be a multiple of the patch size");
+  FP_REQUIRE(H >= m->patch && W >= m->patch && (pstride == m->patch || mode == VIT_FULL), "fp_vit_forward: image smaller than a patch, or token selection with stride != patch size");
+  const int D = m->dim, np = (1 + (H - m->patch) / pstride) * (1 + (W - m->patch) / pstride), ntok = 1 + m->registers + np;
   const int Mtok = B * ntok, Mp = B * np;
   FP_REQUIRE(ws->m_pad >= Mtok && ws->m_pad % 128 == 0, "fp_vit_forward: workspace m_pad (%d) too small for %d tokens or not a multiple of 128", ws->m_pad, Mtok);
   FP_REQUIRE(ws->m_patch_pad >= Mp && ws->m_patch_pad % 128 == 0, "fp_vit_forward: workspace m_patch_pad too small");
@@ -447,7 +449,8 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
   if (mode != VIT_LAST_SELECTED) {
-  TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
+  if (pstride == m->patch) TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
+  else TRY(patchify_strided_launch(images, B, H, W, m->patch, pstride, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
   TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
   if (sp) {
     GemmBf16Args g;

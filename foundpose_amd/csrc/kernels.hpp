@@ -176,6 +176,8 @@ int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb,
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
                     int out_dtype, hipStream_t st, float out_scale = 1.f);  // out_scale: FP_DTYPE_F16X3 rows only
+int patchify_strided_launch(const float* images, int batch, int height, int width, int patch, int stride, void* out, int ld_out, int out_dtype,
+                            hipStream_t st, float out_scale = 1.f);
 int prefix_tokens_launch(const float* prefix, int n_prefix, int dim, float* tokens, int batch, int n_tok, hipStream_t st);
 int convert_f32_to_bf16_launch(const float* in, void* out, long long n, hipStream_t st);
 int quantize_fp8_launch(const void* in, int in_dtype, long long n, float scale, void* out, hipStream_t st);

@@ -323,6 +323,36 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
       *reinterpret_cast<uint4*>(out_row + (size_t)gx * ld + ch * V) = *reinterpret_cast<const uint4*>(tile + (size_t)gx * lds_ld + ch * V);
 }
 
+// stride != patch size (the reference's patch_vit_resolution, dinov2_utils.py:364-389: the conv of the patch embedding runs with a
+// smaller stride, patches overlap): row = b * gh * gw + gy * gw + gx with gh = 1 + (H - P) / stride, same column order.  One thread per
+// output element -- a rarely used configuration, not a hot kernel.  OUT: 0 fp32, 1 bf16, 2 split-fp16 (ld in halves).
+template <int OUT>
+__global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __restrict__ img, int B, int H, int W, int P, int stride, int gh, int gw,
+                                                               void* __restrict__ out, int ld, int cols_pad, float scale) {
+  const long long id = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long total = (long long)B * gh * gw * cols_pad;
+  if (id >= total) return;
+  const int col = (int)(id % cols_pad);
+  const long long row = id / cols_pad;
+  const int gx = (int)(row % gw), gy = (int)((row / gw) % gh), b = (int)(row / ((long long)gw * gh));
+  float v = 0.f;
+  if (col < 3 * P * P) {
+    const int c = col / (P * P), py = (col - c * P * P) / P, px = col - c * P * P - py * P;
+    const float mean = c == 0 ? 0.485f : (c == 1 ? 0.456f : 0.406f);
+    const float stdv = c == 0 ? 0.229f : (c == 1 ? 0.224f : 0.225f);
+    v = (img[(((size_t)b * 3 + c) * H + gy * stride + py) * W + gx * stride + px] - mean) / stdv;
+  }
+  if constexpr (OUT == 0) reinterpret_cast<float*>(out)[(size_t)row * ld + col] = v;
+  else if constexpr (OUT == 1) reinterpret_cast<__bf16*>(out)[(size_t)row * ld + col] = (__bf16)v;
+  else {
+    const float sv = v * scale;
+    const _Float16 hi = (_Float16)sv;
+    _Float16* d = reinterpret_cast<_Float16*>(out) + (size_t)row * ld + split16_pos(col);
+    d[0] = hi;
+    d[32] = (_Float16)(sv - (float)hi);
+  }
+}
+
 // Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
 // LayerScale GEMM has produced yet.  One wave per row; slot 0 of the partial-sum table gets the whole row, the others zero.
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, int rows, int dim, __bf16* __restrict__ xb, int ld_xb,
@@ -544,6 +574,23 @@ int ln_sample_launch(const float* x, int ld_x, const float* weight, const float*
   else if (dim <= 512) hipLaunchKernelGGL((ln_sample_kernel<2, 4>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((ln_sample_kernel<2, 16>), grid, dim3(256), 0, st, a);
   FP_CHECK_LAUNCH("ln_sample");
+  return FP_OK;
+}
+
+int patchify_strided_launch(const float* images, int batch, int height, int width, int patch, int stride, void* out, int ld_out, int out_dtype,
+                            hipStream_t st, float out_scale) {
+  FP_REQUIRE(stride >= 1 && height >= patch && width >= patch, "patchify: stride %d / image %dx%d / patch %d", stride, height, width, patch);
+  const int gh = 1 + (height - patch) / stride, gw = 1 + (width - patch) / stride;
+  const bool split = out_dtype == FP_DTYPE_F16X3;
+  const int cols_pad = split ? ld_out / 2 : ld_out;   // logical columns of a row (zero beyond 3 P^2)
+  FP_REQUIRE(cols_pad >= 3 * patch * patch && (!split || ld_out % 64 == 0), "patchify: ld_out too small");
+  const long long total = (long long)batch * gh * gw * cols_pad;
+  if (total == 0) return FP_OK;
+  const unsigned grid = (unsigned)((total + 255) / 256);
+  if (split) hipLaunchKernelGGL(patchify_strided_kernel<2>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
+  else if (out_dtype == FP_DTYPE_BF16) hipLaunchKernelGGL(patchify_strided_kernel<1>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
+  else hipLaunchKernelGGL(patchify_strided_kernel<0>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
+  FP_CHECK_LAUNCH("patchify_strided");
   return FP_OK;
 }
 

@@ -6,7 +6,8 @@ Differences that do not change results:
     block's output, dinov2_utils.py:257) and no autograd graph is built;
   * weights: the reference downloads the pretrained hub checkpoint (`pretrained=True`, dinov2_utils.py:82);
     there is no network here, so pass `state_dict=` (upstream DINOv2 key names) or get seeded random weights.
-Not implemented: stride != 14 (the reference's own code for it cannot run) and the "attn" facet.
+Not implemented: the "attn" facet (the reference's extract_descriptors asserts it away, dinov2_utils.py:285-290).  stride != 14 follows
+what the reference's patch_vit_resolution / _fix_pos_enc state (its own branch cannot run: see __init__).
 """
 
 import ctypes as C
@@ -40,6 +41,22 @@ def _interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: 
     return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)
 
 
+def _interpolate_pos_embed_strided(pos_embed: torch.Tensor, patch: int, stride: int, H: int, W: int) -> torch.Tensor:
+    """Position encoding for stride != patch size, as the reference's _fix_pos_enc states it (dinov2_utils.py:325-360; upstream calls it with
+    (tokens, image height, image width)): bicubic, scale-factor mode, +0.1 fudge, no antialias.  Host-side weight preparation."""
+    n = pos_embed.shape[1] - 1
+    m = int(math.sqrt(n))
+    w0, h0 = 1 + (H - patch) // stride, 1 + (W - patch) // stride
+    if w0 * h0 == n and H == W:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    grid = F.interpolate(pos_embed[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2), scale_factor=((w0 + 0.1) / m, (h0 + 0.1) / m),
+                         mode="bicubic", align_corners=False, recompute_scale_factor=False)
+    if tuple(grid.shape[-2:]) != (w0, h0):
+        raise RuntimeError("pos-embed interpolation produced an unexpected grid")
+    return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)
+
+
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
                  precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
@@ -54,11 +71,13 @@ class DinoFeatureExtractor(torch.nn.Module):
         self.arch: VitArch = arch if arch is not None else spec.arch
         self.model_base_name = f"dinov2_{self.version}".replace("-", "_")
         self.patch_size = self.arch.patch
-        if self.stride != self.patch_size:
-            raise NotImplementedError(
-                "stride != patch size is not implemented on the MI355X path.  (The reference's own code for it cannot run "
-                "either: _fix_pos_enc returns a function without a `self` parameter and binds it with types.MethodType "
-                "(dinov2_utils.py:326,386-388), so its first forward raises TypeError; there is no behaviour to match.)")
+        # stride != patch size: the reference's patch_vit_resolution (dinov2_utils.py:364-389) -- the patch-embedding conv runs with
+        # the smaller stride (overlapping patches, 1 + (size - patch) // stride tokens per axis) and the position encoding comes from
+        # _fix_pos_enc (scale-factor bicubic with the +0.1 fudge).  The reference's own branch cannot run (the function is declared
+        # without `self`, closes over the wrapper's non-existent pos_embed and is bound with types.MethodType: its first forward raises);
+        # what is implemented is what that code states, pinned by calling the reference's function directly (tests/golden/extractor_tiny_stride7.npz).
+        if self.stride != self.patch_size and (self.stride < 1 or (self.patch_size // self.stride) * self.stride != self.patch_size):
+            raise AssertionError(f"stride {self.stride} should divide patch_size {self.patch_size}")   # dinov2_utils.py:378-380
         if self.facet not in ("token", "key", "query", "value"):
             raise NotImplementedError(f"facet '{self.facet}' is not implemented on the MI355X path ('token', 'key', 'query', 'value' are)")
         if self.facet != "token" and use_graph:
@@ -215,6 +234,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m = _lib.VitModel()
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")
+        m.patch_stride = 0 if self.stride == self.patch_size else self.stride
         m.weight_dtype = _lib.FP_F32 if self.precision == "fp32" else _lib.FP_BF16  # "fp8": bf16 until calibrated (_to_fp8)
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
@@ -287,6 +307,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m = _lib.VitModel()
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")
+        m.patch_stride = 0 if self.stride == self.patch_size else self.stride
         m.weight_dtype = _lib.FP_F16X3
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.patch_acc_scale = 1.0 / (S_ACT * spw)
@@ -299,11 +320,24 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._ws.clear()
         self._graphs.clear()
 
-    def _grid_tables(self, gh: int, gw: int):
-        key = (gh, gw)
+    def _grid(self, H: int, W: int) -> Tuple[int, int]:
+        """Patch tokens per axis (dinov2_utils.py:266-269): 1 + (size - patch) // stride; at stride == patch size the image must tile."""
+        if self.stride == self.patch_size:
+            if H % self.patch_size or W % self.patch_size:
+                raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {self.patch_size}")
+            return H // self.patch_size, W // self.patch_size
+        if H < self.patch_size or W < self.patch_size:
+            raise ValueError(f"image size {H}x{W} is smaller than a patch")
+        return 1 + (H - self.patch_size) // self.stride, 1 + (W - self.patch_size) // self.stride
+
+    def _grid_tables(self, gh: int, gw: int, H: int = 0, W: int = 0):
+        key = (gh, gw) if self.stride == self.patch_size else (gh, gw, H, W)
         if key not in self._grids:
             a, sd = self.arch, self._sd
-            pos = _interpolate_pos_embed(sd["pos_embed"].float(), a, gh, gw)[0]  # [1+Np, D]
+            if self.stride == self.patch_size:
+                pos = _interpolate_pos_embed(sd["pos_embed"].float(), a, gh, gw)[0]  # [1+Np, D]
+            else:
+                pos = _interpolate_pos_embed_strided(sd["pos_embed"].float(), a.patch, self.stride, H, W)[0]
             rows = [sd["cls_token"].float().reshape(1, -1) + pos[:1]]
             if a.registers:
                 rows.append(sd["register_tokens"].float().reshape(a.registers, -1))
@@ -356,10 +390,8 @@ class DinoFeatureExtractor(torch.nn.Module):
             raise ValueError("images must be [B, 3, H, W]")
         images = images.float().contiguous()
         B, _, H, W = images.shape
-        if H % self.patch_size or W % self.patch_size:
-            raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {self.patch_size}")
-        gh, gw = H // self.patch_size, W // self.patch_size
-        pos_patch, prefix = self._grid_tables(gh, gw)
+        gh, gw = self._grid(H, W)
+        pos_patch, prefix = self._grid_tables(gh, gw, H, W)
         self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
@@ -380,7 +412,8 @@ class DinoFeatureExtractor(torch.nn.Module):
     @property
     def supports_token_selection(self) -> bool:
         """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms."""
-        return self.facet == "token" and not self.use_graph and self.precision == "bf16" and self.fold_layernorm and self.layer >= 0
+        return (self.facet == "token" and not self.use_graph and self.precision == "bf16" and self.fold_layernorm and self.layer >= 0
+                and self.stride == self.patch_size)   # the selection maps query points to 14-px cells
 
     def forward_hidden(self, images: torch.Tensor, prefix_only: bool = False) -> Tuple[int, int, int]:
         """Runs the backbone up to the hooked block and leaves its output in the workspace (no final norm, no feature map):
@@ -396,10 +429,8 @@ class DinoFeatureExtractor(torch.nn.Module):
         _lib.require_cuda(images)
         images = images.float().contiguous()
         B, _, H, W = images.shape
-        if H % self.patch_size or W % self.patch_size:
-            raise ValueError(f"image size {H}x{W} is not a multiple of the patch size {self.patch_size}")
-        gh, gw = H // self.patch_size, W // self.patch_size
-        pos_patch, prefix = self._grid_tables(gh, gw)
+        gh, gw = self._grid(H, W)
+        pos_patch, prefix = self._grid_tables(gh, gw, H, W)
         self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
@@ -467,8 +498,8 @@ class DinoFeatureExtractor(torch.nn.Module):
                 raise ValueError("calibrate_fp8 needs a calibration batch or explicit act_scales")
             images = images.float().contiguous()
             B, _, H, W = images.shape
-            gh, gw = H // self.patch_size, W // self.patch_size
-            pos_patch, prefix = self._grid_tables(gh, gw)
+            gh, gw = self._grid(H, W)
+            pos_patch, prefix = self._grid_tables(gh, gw, H, W)
             self._model.pos_patch, self._model.prefix = ptr(pos_patch), ptr(prefix)
             self._model.weight_dtype = _lib.FP_BF16
             ws, bufs = self._workspace(B, gh, gw)
@@ -562,6 +593,6 @@ class DinoFeatureExtractor(torch.nn.Module):
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
         B, _, H, W = images.shape
         fmap, cls = self.forward_tokens(images)
-        gh, gw = H // self.patch_size, W // self.patch_size
+        gh, gw = self._grid(H, W)
         # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output
         return {"cls_tokens": cls, "feature_maps": fmap.reshape(B, gh, gw, self.arch.dim).permute(0, 3, 1, 2)}

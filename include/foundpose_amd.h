@@ -209,6 +209,9 @@ typedef struct {
   int ld_w_dim, ld_w_hidden;  /* row strides (elements) of the block matrices with K = dim (qkv, proj, fc1) and with
                                  K = hidden (fc2); 0 = dense (dim / hidden).  A stride that is not a multiple of 2 KiB
                                  keeps the 8 rows of a staging instruction off one L2 channel */
+  int patch_stride;        /* conv stride of the patch embedding; 0 = patch (the shipped configs).  Smaller strides (the reference's
+                              patch_vit_resolution, utils/dinov2_utils.py:364-389) give overlapping patches: 1 + (size - patch) / stride
+                              tokens per axis, pos_patch then holds the reference's strided position encoding; full forward only */
   float patch_acc_scale;   /* FP_F16X3 only: 1 / (FP_SPLIT_SCALE_ACT x scale of the split patch_w [D, 2 * patch_k_pad]) */
   int ln_fold;             /* FP_BF16 only.  1: the two LayerNorms of a block are folded into the GEMMs around them -- no
                               LayerNorm kernel runs inside the blocks.  qkv_w / fc1_w then hold W * diag(ln weight) (bf16),

@@ -229,6 +229,35 @@ def gen_extractor_420(ref):
     print("extractor_vits14reg_420", fm.shape, float(np.abs(fm).mean()))
 
 
+def gen_extractor_stride(ref):
+    """(d) stride != patch size.  The reference's own branch cannot run end to end: `_fix_pos_enc` returns a function declared
+    without `self` that closes over the WRAPPER's (non-existent) pos_embed and is bound with types.MethodType (dinov2_utils.py:325-326,386-388).
+    What its code states is still executable piece by piece, and that is what this fixture pins: the reference's position-encoding function
+    itself (called on an object that has the table), the reference wrapper's constructor (it sets the conv stride of the backbone) and forward
+    (hook, token slicing, 1 + (size - patch) // stride grid, final norm), over the stand-in backbone whose embedding calls that function."""
+    import types as _types
+    from foundpose_amd.vit_config import ARCHS
+    ARCHS[TINY.name] = TINY
+    sd = synthetic.make_vit_state_dict(TINY, seed=1234)
+    fn = ref.dinov2_utils.DinoFeatureExtractor._fix_pos_enc(_types.SimpleNamespace(pos_embed=sd["pos_embed"]), TINY.patch, (7, 7))
+    out = {"weights_seed": np.int64(1234), "image_seed": np.int64(0), "stride": np.int64(7)}
+    for (H, W) in ((56, 56), (70, 56), (28, 28)):
+        npatch = (1 + (H - 14) // 7) * (1 + (W - 14) // 7)
+        out[f"pos_{H}x{W}"] = t2n(fn(torch.zeros(1, 1 + npatch, TINY.dim), H, W)).astype(np.float32)   # upstream passes (x, image height, image width)
+    imgs = synthetic.make_crops(2, 56, seed=0)
+    for layer, norm in ((2, 1), (0, 0)):
+        ex = _make_ref_extractor(ref, TINY, sd, 56, f"dinov2_version=tiny-reg_stride=7_facet=token_layer={layer}_logbin=0_norm={norm}")
+        assert ex.stride == 7 and tuple(ex.model.patch_embed.proj.stride) == (7, 7)
+        ex.model.hf.embeddings.interpolate_pos_encoding = lambda emb, height, width: fn(emb, height, width)
+        with torch.no_grad():
+            o = ex(imgs)
+        out[f"fmap_l{layer}_n{norm}"] = t2n(o["feature_maps"]).astype(np.float32)
+        out[f"cls_l{layer}_n{norm}"] = t2n(o["cls_tokens"]).astype(np.float32)
+    assert out["fmap_l2_n1"].shape == (2, TINY.dim, 7, 7)
+    np.savez_compressed(os.path.join(OUT, "extractor_tiny_stride7.npz"), **out)
+    print("extractor_tiny_stride7", out["fmap_l2_n1"].shape, out["pos_70x56"].shape)
+
+
 # ------------------------------------------------------------------ composite hot section
 def gen_hot_section(ref):
     """infer.py:468-542 driven through the reference's functions on a tiny extractor."""
@@ -581,6 +610,7 @@ def main():
     gen_points(ref)
     gen_extractor(ref)
     gen_extractor_420(ref)
+    gen_extractor_stride(ref)
     gen_hot_section(ref)
     gen_crop(ref)
     gen_lift(ref)

@@ -73,14 +73,37 @@ def interpolate_pos_embed(pos_embed: torch.Tensor, arch: VitArch, gh: int, gw: i
     return torch.cat([cls_pos, patch_pos], dim=1)
 
 
-def embed_tokens(sd: Dict[str, torch.Tensor], arch: VitArch, x: torch.Tensor, quant=None) -> torch.Tensor:
-    """Normalised image -> [B, 1+R+Np, D] token sequence (cls, registers, patches)."""
+def interpolate_pos_embed_strided(pos_embed: torch.Tensor, patch: int, stride: int, H: int, W: int) -> torch.Tensor:
+    """The position-encoding function the reference installs when stride != patch size
+    (/root/reference/utils/dinov2_utils.py:325-360, `_fix_pos_enc`; upstream calls it as (x, w, h) = (tokens, image HEIGHT, image WIDTH)):
+    token counts 1 + (size - patch) // stride per axis, bicubic, scale-factor mode with the +0.1 fudge, no antialias."""
+    n = pos_embed.shape[1] - 1
+    m = int(math.sqrt(n))
+    w0, h0 = 1 + (H - patch) // stride, 1 + (W - patch) // stride     # the reference's names: w = first spatial size
+    if w0 * h0 == n and H == W:
+        return pos_embed
+    dim = pos_embed.shape[-1]
+    grid = F.interpolate(pos_embed[:, 1:].reshape(1, m, m, dim).permute(0, 3, 1, 2), scale_factor=((w0 + 0.1) / m, (h0 + 0.1) / m),
+                         mode="bicubic", align_corners=False, recompute_scale_factor=False)
+    assert grid.shape[-2] == w0 and grid.shape[-1] == h0
+    return torch.cat([pos_embed[:, :1], grid.permute(0, 2, 3, 1).reshape(1, -1, dim)], dim=1)
+
+
+def embed_tokens(sd: Dict[str, torch.Tensor], arch: VitArch, x: torch.Tensor, quant=None, stride: Optional[int] = None) -> torch.Tensor:
+    """Normalised image -> [B, 1+R+Np, D] token sequence (cls, registers, patches).  stride (default: the patch size): the conv stride
+    the reference's patch_vit_resolution sets (dinov2_utils.py:364-389) -- overlapping patches, its own position-encoding function."""
     B, _, H, W = x.shape
     gh, gw = H // arch.patch, W // arch.patch
     w = _q(sd["patch_embed.proj.weight"], quant)
-    t = F.conv2d(_q(x, quant), w, sd["patch_embed.proj.bias"], stride=arch.patch)
+    st = arch.patch if stride is None else stride
+    t = F.conv2d(_q(x, quant), w, sd["patch_embed.proj.bias"], stride=st)
     t = t.flatten(2).transpose(1, 2)  # [B, Np, D], row-major over (gy, gx)
     t = torch.cat([sd["cls_token"].expand(B, -1, -1), t], dim=1)
+    if st != arch.patch:
+        t = t + interpolate_pos_embed_strided(sd["pos_embed"], arch.patch, st, H, W)
+        if arch.registers:
+            t = torch.cat([t[:, :1], sd["register_tokens"].expand(B, -1, -1), t[:, 1:]], dim=1)
+        return t
     t = t + interpolate_pos_embed(sd["pos_embed"], arch, gh, gw)
     if arch.registers:
         t = torch.cat([t[:, :1], sd["register_tokens"].expand(B, -1, -1), t[:, 1:]], dim=1)
@@ -152,13 +175,13 @@ def _block_forward_fp8(sd, arch: VitArch, i: int, x: torch.Tensor, s) -> torch.T
 
 
 @torch.no_grad()
-def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quant=None, all_blocks=False, fp8_act=None) -> torch.Tensor:
+def hidden_after_block(sd, arch: VitArch, images: torch.Tensor, layer: int, quant=None, all_blocks=False, fp8_act=None, stride=None) -> torch.Tensor:
     """Output of blocks[layer] for [0,1] images (what the reference's forward hook captures).
 
     `all_blocks=True` keeps running to the last block like the reference does
     (dinov2_utils.py:257 runs the entire model) -- only used by the cpu_baseline timing.
     """
-    x = embed_tokens(sd, arch, normalize_images(images), "bf16" if fp8_act is not None else quant)
+    x = embed_tokens(sd, arch, normalize_images(images), "bf16" if fp8_act is not None else quant, stride)
     out = None
     last = arch.depth - 1 if all_blocks else layer
     for i in range(last + 1):
@@ -185,18 +208,19 @@ def facet_tokens(sd, arch: VitArch, images: torch.Tensor, layer: int, facet: str
 
 @torch.no_grad()
 def extractor_forward(sd, arch: VitArch, images: torch.Tensor, layer: int, apply_norm: bool = True, quant=None, all_blocks=False, fp8_act=None,
-                      facet: str = "token"):
+                      facet: str = "token", stride=None):
     """-> {"cls_tokens": [B,D], "feature_maps": [B,D,Hp,Wp]} exactly like the reference wrapper."""
     B, _, H, W = images.shape
     if facet == "token":
-        hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks, fp8_act)
+        hs = hidden_after_block(sd, arch, images, layer, quant, all_blocks, fp8_act, stride)
     else:
         hs = facet_tokens(sd, arch, images, layer, facet, quant)
     cls, patch = hs[:, :1], hs[:, 1 + arch.registers:]
     if apply_norm:
         tok = F.layer_norm(torch.cat([cls, patch], 1), (arch.dim,), sd["norm.weight"], sd["norm.bias"], eps=1e-6)
         cls, patch = tok[:, :1], tok[:, 1:]
-    gh, gw = H // arch.patch, W // arch.patch
+    st = arch.patch if stride is None else stride
+    gh, gw = 1 + (H - arch.patch) // st, 1 + (W - arch.patch) // st   # dinov2_utils.py:266-269 (= H // patch at stride == patch size)
     fmap = patch.reshape(B, gh, gw, arch.dim).permute(0, 3, 1, 2)
     return {"cls_tokens": cls[:, 0], "feature_maps": fmap}
 

@@ -198,6 +198,56 @@ def test_extractor_vits14reg_420_vs_reference_wrapper_fixture(precision, tol):
     np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
 
 
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("f16x3", 5e-5), ("bf16", 6e-2)])
+def test_extractor_stride7_vs_reference_fixture(precision, tol):
+    """stride != patch size (the reference's patch_vit_resolution / _fix_pos_enc, dinov2_utils.py:313-389): overlapping patches,
+    7 x 7 tokens for a 56-px image, the strided position encoding.  Fixture: the reference wrapper + the reference's own position-encoding
+    function over the stand-in backbone; plus a non-square image against the oracle (pinned to the same function on CPU)."""
+    g = load_golden("extractor_tiny_stride7")
+    imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"])).cuda()
+    for layer, norm in ((2, 1), (0, 0)):
+        ex = _extractor(TINY, f"dinov2_version=tiny-reg_stride=7_facet=token_layer={layer}_logbin=0_norm={norm}", int(g["weights_seed"]), precision)
+        assert ex.stride == 7 and not ex.supports_token_selection
+        o = ex(imgs)
+        assert o["feature_maps"].shape == (2, TINY.dim, 7, 7)
+        scale = np.abs(g[f"fmap_l{layer}_n{norm}"]).max()
+        np.testing.assert_allclose(o["feature_maps"].cpu().numpy(), g[f"fmap_l{layer}_n{norm}"], rtol=0, atol=tol * scale)
+        np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g[f"cls_l{layer}_n{norm}"], rtol=0, atol=tol * scale)
+    sd = synthetic.make_vit_state_dict(TINY, seed=int(g["weights_seed"]))
+    wide = synthetic.make_crops(1, 70, seed=3)[:, :, :, :56].contiguous()      # 70 x 56: 9 x 7 tokens
+    ex = _extractor(TINY, "dinov2_version=tiny-reg_stride=7_facet=token_layer=2_logbin=0_norm=1", int(g["weights_seed"]), precision)
+    got = ex(wide.cuda())["feature_maps"].cpu()
+    ref = ov.extractor_forward(sd, TINY, wide, 2, True, stride=7)["feature_maps"]
+    assert got.shape == (1, TINY.dim, 9, 7) and rel_err(got, ref) < tol
+
+
+def test_extractor_stride_through_the_engine():
+    """The batched engine on a strided extractor (token selection switches itself off, the fused norm + sampling reads the finer 15 x 15
+    grid) returns what the drop-in single-detection calls return: extractor -> filter_points_by_mask -> sample_feature_map_at_points ->
+    project_features -> establish_correspondences, index for index."""
+    from foundpose_amd import corresp_util, engine as fe, feature_util, projector_util, workload
+    from foundpose_amd.bank import DeviceBank
+    name = "dinov2_version=vits14-reg_stride=7_facet=token_layer=3_norm=1"
+    ex = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    wl = workload.build_planted_workload(ex, 3, 112, 1, 60, seed=2, crop_seed=1)
+    repre = wl.repres[0]
+    res = fe.FoundPoseEngine(ex, DeviceBank(wl.repres), 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
+    assert ex.num_patches == (15, 15) and not ex.supports_token_selection
+    grid = feature_util.generate_grid_points((112, 112), 14.0).cuda()
+    for b in range(3):
+        fmap = ex(wl.crops[b:b + 1])["feature_maps"][0]
+        assert fmap.shape == (384, 15, 15)
+        qp = feature_util.filter_points_by_mask(grid, wl.masks[b])
+        qf = feature_util.sample_feature_map_at_points(fmap, qp, (112, 112)).contiguous()
+        qfp = projector_util.project_features(qf, repre.feat_raw_projectors).contiguous()
+        single = corresp_util.establish_correspondences(qp, qfp, repre, "tfidf", "cyclic_buddies", 5, 300)
+        batch = res.corresp_list(b)
+        assert len(single) == len(batch) == 5
+        for s_, b_ in zip(single, batch):
+            assert int(s_["template_id"]) == int(b_["template_id"])
+            assert torch.equal(s_["coord_2d_ids"], b_["coord_2d_ids"]) and torch.equal(s_["nn_vertex_ids"], b_["nn_vertex_ids"])
+
+
 def test_extractor_batch_invariance_and_420():
     """Each image of a batch gets the same features as when run alone; 420x420 crops take the interpolated pos-embed."""
     ex = _extractor(None, "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1", 1234, "bf16")

@@ -53,6 +53,22 @@ def test_extractor_vits14reg_420_matches_reference_wrapper():
     assert abs(float(fm.mean()) - float(g["fmap_mean"])) < 1e-5
 
 
+def test_extractor_stride7_matches_reference_pieces():
+    """stride != patch size: the oracle's strided position encoding equals the reference's `_fix_pos_enc` function output
+    (square, non-square and the identity case), and the whole forward equals the reference wrapper run with that function
+    (tests/golden/extractor_tiny_stride7.npz; why pieces: oracle/make_golden.py::gen_extractor_stride)."""
+    g = load_golden("extractor_tiny_stride7")
+    sd = synthetic.make_vit_state_dict(TINY, seed=int(g["weights_seed"]))
+    for (H, W) in ((56, 56), (70, 56), (28, 28)):
+        np.testing.assert_allclose(ov.interpolate_pos_embed_strided(sd["pos_embed"], 14, 7, H, W).numpy(), g[f"pos_{H}x{W}"], rtol=0, atol=1e-6)
+    imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"]))
+    for layer, norm in ((2, 1), (0, 0)):
+        o = ov.extractor_forward(sd, TINY, imgs, layer, bool(norm), stride=7)
+        assert o["feature_maps"].shape == (2, TINY.dim, 7, 7)
+        np.testing.assert_allclose(o["feature_maps"].numpy(), g[f"fmap_l{layer}_n{norm}"], rtol=0, atol=2e-5)
+        np.testing.assert_allclose(o["cls_tokens"].numpy(), g[f"cls_l{layer}_n{norm}"], rtol=0, atol=2e-5)
+
+
 def test_name_grammar_defaults():
     s = parse_extractor_name("dinov2_vitl14")
     assert (s.version, s.layer, s.stride, s.facet, s.apply_norm) == ("vitl14", 9, 14, "token", True)
