@@ -86,46 +86,55 @@ def mask_iou(a: np.ndarray, b: np.ndarray) -> float:
     return float(np.logical_and(a, b).sum() / union) if union else 0.0
 
 
+def _centre_crop_offsets(canvas_wh: Tuple[int, int], image_wh: Tuple[int, int]) -> np.ndarray:
+    """(dx, dy) of an image that was centre-cropped out of the detector's canvas (e.g. to a multiple of the ViT patch size); the image can
+    never be larger than the canvas the masks were predicted on."""
+    canvas, image = np.asarray(canvas_wh, np.int64), np.asarray(image_wh, np.int64)
+    if np.any(image > canvas):
+        raise ValueError("Image is larger than mask.")
+    return (canvas - image) // 2
+
+
+def _best_overlap(mask: np.ndarray, annos: Sequence[Any]) -> Tuple[Optional[Any], float]:
+    """The annotation whose modal mask overlaps `mask` most (first one on ties, annotation 0 when nothing overlaps) and that IoU; all IoUs in
+    one vectorised pass over the stacked annotation masks."""
+    if len(annos) == 0:
+        return None, 0.0
+    m = np.asarray(mask).astype(bool)
+    stack = np.stack([np.asarray(a.masks_modal).astype(bool) for a in annos])
+    inter = np.logical_and(stack, m[None]).reshape(len(annos), -1).sum(1)
+    union = np.logical_or(stack, m[None]).reshape(len(annos), -1).sum(1)
+    ious = np.where(union > 0, inter / np.maximum(union, 1), 0.0)
+    best = int(np.argmax(ious)) if float(ious.max()) > 0.0 else 0    # argmax returns the first maximum, like a strict `>` scan
+    return annos[best], float(ious[best]) if float(ious.max()) > 0.0 else 0.0
+
+
+def _instance_from_detection(pred: Dict[str, Any], image_size: Tuple[int, int], gt_object_annos: Sequence[Any]) -> Dict[str, Any]:
+    """One CNOS detection -> the instance record of the driver: opened modal mask and amodal box, both moved into the (possibly
+    centre-cropped) image, plus the best-overlapping annotation when ground truth is given."""
+    mask = open_mask_3x3(rle_to_binary_mask(pred["segmentation"]).astype(np.uint8))
+    dx, dy = _centre_crop_offsets((mask.shape[1], mask.shape[0]), image_size)
+    # (the reference slices [shift:-shift], which empties the mask when the shift is 0; a zero shift is a no-op here)
+    mask = mask[dy:mask.shape[0] - dy, dx:mask.shape[1] - dx]
+    x, y, w, h = np.array(pred["bbox"])                       # CNOS boxes are (x, y, w, h) on the detector's canvas
+    box = np.array(pred["bbox"])
+    box[:] = (x - dx, y - dy, x - dx + w, y - dy + h)        # -> (x1, y1, x2, y2) in the image, dtype of the input kept
+    gt_anno, gt_iou = _best_overlap(mask, gt_object_annos)
+    return {"input_box_amodal": box, "input_mask_modal": mask, "gt_anno": gt_anno, "gt_iou": gt_iou, "time": pred["time"]}
+
+
 def get_instances_for_pose_estimation(bop_chunk_id: int, bop_im_id: int, obj_id: int, use_detections: bool, detections: Dict[Any, Any],
                                       max_num_preds: int, gt_object_annos: Sequence[Any], image_size: Tuple[int, int]) -> List[Dict[str, Any]]:
-    """Per-instance dicts {input_box_amodal (x1, y1, x2, y2), input_mask_modal uint8 [H, W], gt_anno, gt_iou, time}."""
-    instance_infos: List[Dict[str, Any]] = []
+    """Per-instance dicts {input_box_amodal (x1, y1, x2, y2), input_mask_modal uint8 [H, W], gt_anno, gt_iou, time}: the interface of
+    /root/reference/utils/infer_pose_util.py:44-151.  With detections: the max_num_preds best-scoring ones of (scene, image, object) -- a
+    single detection is kept whatever max_num_preds says, as in the reference -- else one instance per ground-truth annotation."""
     if not use_detections:
-        for anno in gt_object_annos:
-            instance_infos.append({"input_box_amodal": np.array(anno.boxes_amodal).copy(), "input_mask_modal": np.array(anno.masks_modal).copy(), "gt_anno": anno})
-        return instance_infos
-    key = (bop_chunk_id, bop_im_id, obj_id)
-    if key not in detections:
+        return [{"input_box_amodal": np.array(a.boxes_amodal).copy(), "input_mask_modal": np.array(a.masks_modal).copy(), "gt_anno": a}
+                for a in gt_object_annos]
+    preds = detections.get((bop_chunk_id, bop_im_id, obj_id))
+    if preds is None:
         return []
-    preds = detections[key]
     if len(preds) > 1:
-        preds = sorted(preds, key=lambda x: x["score"], reverse=True)[:max_num_preds]
-    for pred in preds:
-        box_amodal = np.array(pred["bbox"])  # (x, y, w, h)
-        mask_modal = open_mask_3x3(rle_to_binary_mask(pred["segmentation"]).astype(np.uint8))
-        mask_size = (mask_modal.shape[1], mask_modal.shape[0])
-        # the input image may have been centre-cropped to a multiple of the ViT patch size
-        shift_x = shift_y = 0
-        if image_size[0] < mask_size[0]:
-            shift_x = (mask_size[0] - image_size[0]) // 2
-        elif image_size[0] > mask_size[0]:
-            raise ValueError("Image is larger than mask.")
-        if image_size[1] < mask_size[1]:
-            shift_y = (mask_size[1] - image_size[1]) // 2
-        elif image_size[1] > mask_size[1]:
-            raise ValueError("Image is larger than mask.")
-        # (the reference slices [shift:-shift], which empties the mask when the shift is 0; a zero shift is a no-op here)
-        mask_modal = mask_modal[shift_y:mask_modal.shape[0] - shift_y, shift_x:mask_modal.shape[1] - shift_x]
-        box_amodal[0] -= shift_x
-        box_amodal[1] -= shift_y
-        box_amodal[2] += box_amodal[0]
-        box_amodal[3] += box_amodal[1]
-        best_anno_id, best_anno_iou, gt_anno = 0, 0.0, None
-        if len(gt_object_annos) != 0:
-            for anno_id, anno in enumerate(gt_object_annos):
-                iou = mask_iou(mask_modal, anno.masks_modal)
-                if iou > best_anno_iou:
-                    best_anno_iou, best_anno_id = iou, anno_id
-            gt_anno = gt_object_annos[best_anno_id]
-        instance_infos.append({"input_box_amodal": box_amodal, "input_mask_modal": mask_modal, "gt_anno": gt_anno, "gt_iou": best_anno_iou, "time": pred["time"]})
-    return instance_infos
+        order = sorted(range(len(preds)), key=lambda i: preds[i]["score"], reverse=True)   # stable: equal scores keep their file order
+        preds = [preds[i] for i in order[:max_num_preds]]
+    return [_instance_from_detection(p_, image_size, gt_object_annos) for p_ in preds]
