@@ -122,7 +122,15 @@ def match_batch(
     # ---- every small host table of the batch in ONE upload: q_off [B+1] | det_seg [num_obj+1] | det_nt [B] | tpl_base [B] | feat_base [B]
     tabs_h = q_off_h + det_seg_h + [bank.objects[o].num_templates for o in det_obj] + [bank.objects[o].tpl_base for o in det_obj] \
         + [bank.objects[o].feat_base for o in det_obj]
-    tabs = torch.tensor(tabs_h, dtype=torch.int32, device=dev)
+    # (pinned staging + asynchronous copy: a pageable upload blocks the host until the stream has drained -- the whole backbone of this batch --
+    #  and the launches behind it would then reach an idle GPU one launch latency at a time; the caching host allocator keeps the pinned
+    #  block alive until the copy has run)
+    if os.environ.get("FP_TABS_BLOCKING") == "1":   # A/B switch: the pageable, blocking upload
+        tabs = torch.tensor(tabs_h, dtype=torch.int32, device=dev)
+    else:
+        tabs_host = torch.empty(len(tabs_h), dtype=torch.int32, pin_memory=True)
+        tabs_host.copy_(torch.tensor(tabs_h, dtype=torch.int32))
+        tabs = tabs_host.to(dev, non_blocking=True)
     o1 = B + 1
     o2 = o1 + bank.num_objects + 1
     q_off, det_seg, det_nt, tpl_base, feat_base = tabs[:o1], tabs[o1:o2], tabs[o2:o2 + B], tabs[o2 + B:o2 + 2 * B], tabs[o2 + 2 * B:o2 + 3 * B]

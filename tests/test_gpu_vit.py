@@ -123,7 +123,7 @@ def test_attention_bf16_work_splits_agree_bitwise(B, N, heads):
     assert torch.equal(o_a.view(torch.int16), o_b.view(torch.int16)) and torch.equal(o_a.view(torch.int16), o_c.view(torch.int16))
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("bf16", 3e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("f16x3", 3e-5), ("bf16", 3e-2)])
 def test_extractor_key_query_value_facets_vs_reference_wrapper_fixture(precision, tol):
     g = load_golden("extractor_tiny_facets")
     imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"])).cuda()
@@ -143,7 +143,7 @@ def _extractor(arch, name, seed, precision):
     return ex.to("cuda")
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("bf16", 6e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("f16x3", 3e-5), ("bf16", 6e-2)])
 def test_extractor_tiny_vs_reference_wrapper_fixture(precision, tol):
     g = load_golden("extractor_tiny")
     imgs = synthetic.make_crops(2, 56, seed=int(g["image_seed"])).cuda()
@@ -169,7 +169,7 @@ def test_extractor_tiny_bf16_vs_quantisation_aware_oracle():
     assert eb < 1.5e-2, (eb, ea)
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 8e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("f16x3", 5e-5), ("bf16", 8e-2)])
 def test_extractor_vits14reg_518_vs_reference_wrapper_fixture(precision, tol):
     g = load_golden("extractor_vits14reg_518")
     imgs = synthetic.make_crops(1, 518, seed=int(g["image_seed"])).cuda()
@@ -298,7 +298,7 @@ def test_hot_section_composite_fp32():
         assert a == b
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16", 2e-2)])
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("f16x3", 5e-5), ("bf16", 2e-2)])
 def test_extractor_swiglu_ffn(precision, tol):
     """ViT-g style blocks (SwiGLU FFN, fused into the w12 GEMM epilogue) vs the oracle."""
     from foundpose_amd import feature_util
