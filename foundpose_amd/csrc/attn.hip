@@ -331,7 +331,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     const int key0 = kt * 64;
     const char* Ks = KV[kt & 1][0];
     const char* Vs = KV[kt & 1][1];
+#ifndef FP_ATTN_NO_DMA  // (measurement builds, tools/attn_ablate.sh: the tile loop without its K/V stream -- every tile re-reads tile 0's image)
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);  // the other stage was last read one iteration ago
+#endif
     if (active) {
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
       f32x16 sacc[QC][2];
@@ -343,7 +345,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           for (int r = 0; r < 16; ++r) sacc[qb][ks][r] = 0.f;
 #pragma unroll
         for (int ds = 0; ds < 4; ++ds) {
+#ifdef FP_ATTN_NO_LDS  // (measurement builds: fragments from registers instead of LDS)
+          bf16x8 kf = qf[0][ds];
+          kf[0] = (__bf16)(float)(kt & 3);
+#else
           const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
+#endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
             sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
@@ -409,18 +416,26 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* vp = Vs + (vrd0 ^ (dt << 6)) + kstep * 2048;  // + 512 B = 4 keys on
+#ifdef FP_ATTN_NO_LDS
+          bf16x8 vf = qf[0][kstep];
+          vf[0] = (__bf16)(float)((kt + dt) & 3);
+          (void)vp;
+#else
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 512));
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
             oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kstep], oacc[qb][dt], 0, 0, 0);
         }
     }
+#ifndef FP_ATTN_NO_BARRIER  // (measurement builds: no per-tile wait + barrier; only meaningful together with FP_ATTN_NO_DMA)
     if constexpr (!RAGGED) {
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
       __syncthreads();
     }
+#endif
   };
   const int nfull = N / 64;
   auto run = [&](auto qblocks) {
