@@ -141,16 +141,24 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
 #pragma unroll
     for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);  // v_max3_f32
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_run, mx);
-    // the running max stops moving after the first few tiles: skip the rescale of O and l unless some lane needs it
-    const bool grow = __any(m_new > m_run);
+    // lazy rescale, per query: the exponent's reference m_run moves only when the tile maximum exceeds it by more than 8 in the
+    // exponent (see attn_bf16_w64_kernel; the same rule, so the two kernels stay bit-identical)
+#ifdef FP_ATTN_EAGER_RESCALE
+    const bool moves = mx > m_run;
+#else
+    const bool moves = mx - m_run > 8.f / (0.125f * 1.44269504088896340736f);
+#endif
+    const bool grow = __any(moves);
     float alpha = 1.f;
-    if (grow) alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-    m_run = m_new;
+    if (grow) {
+      const float m_new = moves ? mx : m_run;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+    }
     // exp2(s*c - m*c): scalar fp32 VALU on purpose -- v_pk_fma/v_pk_add variants measured 25 % SLOWER here
     // (packed fp32 issues badly beside MFMAs, guide "price of one filler beside MFMAs")
     float psum = 0.f;
-    const float mc = m_new * c;
+    const float mc = m_run * c;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -293,6 +301,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   stage_tile(0, 0);
 
   const float c = 0.125f * 1.44269504088896340736f;  // head_dim^-0.5 * log2(e)
+  constexpr float LAZY_TH = 8.f / (0.125f * 1.44269504088896340736f);  // 8 in the exponent, in score units
   // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d]
   bf16x8 qf[QB][4];
 #pragma unroll
@@ -332,7 +341,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     const char* Ks = KV[kt & 1][0];
     const char* Vs = KV[kt & 1][1];
 #ifndef FP_ATTN_NO_DMA  // (measurement builds, tools/attn_ablate.sh: the tile loop without its K/V stream -- every tile re-reads tile 0's image)
-    if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);  // the other stage was last read one iteration ago
+    // the other stage was last read one iteration ago.  (Issued from inside the softmax instead -- between the two query blocks, a
+    // VALU-only stretch -- the kernel measured 1.5 % SLOWER: 362 vs 356 us.)
+    if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
 #endif
     if (active) {
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
@@ -356,6 +367,25 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
             sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
         }
       }
+#if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
+      // (-DFP_ATTN_TR_ASM, measured and NOT the default.)  The tile's eight V^T fragments issued HERE (they land under the softmax)
+      // and as inline asm: through the builtin the compiler cannot tell a transpose read from an access to the stage the LDS-DMA
+      // is filling and puts s_waitcnt vmcnt(0) in front of the first one -- the prefetch of tile t+1 has to land in the middle of
+      // tile t.  (LDS returns in order, so the compiler's own lgkmcnt waits for its K reads stay conservative with these in the
+      // queue.)  Same speed within the noise of one box (347.6 / 347.0 us vs 341.5 / 350.0), 235 instead of 208 VGPRs.
+      s16x4 vlo[4][2], vhi[4][2];
+      {
+        const unsigned vs0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(Vs + vrd0);
+        const unsigned vs1 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)(Vs + (vrd0 ^ 64));
+#pragma unroll
+        for (int kstep = 0; kstep < 4; ++kstep) {
+          asm volatile("ds_read_b64_tr_b16 %0, %4 offset:%6\n\tds_read_b64_tr_b16 %1, %4 offset:%7\n\t"
+                       "ds_read_b64_tr_b16 %2, %5 offset:%6\n\tds_read_b64_tr_b16 %3, %5 offset:%7"
+                       : "=&v"(vlo[kstep][0]), "=&v"(vhi[kstep][0]), "=&v"(vlo[kstep][1]), "=&v"(vhi[kstep][1])
+                       : "v"(vs0), "v"(vs1), "n"(kstep * 2048), "n"(kstep * 2048 + 512));
+        }
+      }
+#endif
       bf16x8 pf[QC][4];
 #pragma unroll
       for (int qb = 0; qb < QC; ++qb) {
@@ -371,15 +401,33 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
         float mx = fmaxf(sacc[qb][0][0], sacc[qb][1][0]);
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[qb][0][r]), sacc[qb][1][r]);  // v_max3_f32
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run[qb], mx);
-        // the running max stops moving after the first few tiles: skip the rescale of O and l unless some lane needs it
-        const bool grow = __any(m_new > m_run[qb]);
+        {  // the query's other 32 scores live in lane ^ 32: one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through LDS
+          const unsigned mu = __builtin_bit_cast(unsigned, mx);
+          const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);  // lanes < 32: {own, partner's}; >= 32: {partner's, own}
+          const unsigned m0 = sw[0], m1 = sw[1];  // (through temporaries: __builtin_bit_cast applied to sw[1] directly reads element 0 with this hipcc)
+          mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
+        }
+        // Lazy rescale: m_run is the REFERENCE of the exponent, not necessarily the running maximum.  It moves (and O, l are rescaled)
+        // only when some lane's tile maximum exceeds it by more than LAZY_TH, i.e. when a probability would exceed 2^8; softmax is
+        // shift-invariant, so the result is the same function of the scores, with p <= 256 instead of <= 1 (fp32 sums, bf16 P:
+        // the same relative precision).  With the exact maximum some lane of 64 sees a new one in most tiles (random scores:
+        // 1 - (1 - 1/t)^32) and the wave pays the rescale of its 64 accumulator registers nearly every tile.
+        // The decision is per QUERY (a lane whose query does not move multiplies by exactly 1): a query's result does not depend
+        // on which other queries share its wave -- selected-token runs stay bit-identical to the full forward.
+#ifdef FP_ATTN_EAGER_RESCALE
+        const bool moves = mx > m_run[qb];
+#else
+        const bool moves = mx - m_run[qb] > LAZY_TH;
+#endif
+        const bool grow = __any(moves);
         float alpha = 1.f;
-        if (grow) alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
-        m_run[qb] = m_new;
+        if (grow) {
+          const float m_new = moves ? mx : m_run[qb];
+          alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+          m_run[qb] = m_new;
+        }
         float psum = 0.f;
-        const float mc = m_new * c;
+        const float mc = m_run[qb] * c;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -411,6 +459,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           }
       }
       // ---- O^T += V^T P^T over 4 steps of 16 keys; one V^T fragment serves both query blocks
+#if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
+      asm volatile("s_waitcnt lgkmcnt(0)"  // the asm reads above (the compiler does not count them)
+                   : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
+                     "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]));
+#endif
 #pragma unroll
       for (int kstep = 0; kstep < 4; ++kstep)
 #pragma unroll
@@ -420,10 +473,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           bf16x8 vf = qf[0][kstep];
           vf[0] = (__bf16)(float)((kt + dt) & 3);
           (void)vp;
-#else
+#elif !defined(FP_ATTN_TR_ASM)
           const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
           const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 512));
           const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#else
+          (void)vp;
+          const bf16x8 vf = __builtin_bit_cast(bf16x8, __builtin_shufflevector(vlo[kstep][dt], vhi[kstep][dt], 0, 1, 2, 3, 4, 5, 6, 7));
 #endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
@@ -466,16 +522,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           for (int g = 0; g < 4; ++g)
             *reinterpret_cast<unsigned*>(o + dt * 32 + 8 * g + 4 * kh) =
                 pack_fp8x4(oacc[qb][dt][4 * g + 0] * sc, oacc[qb][dt][4 * g + 1] * sc, oacc[qb][dt][4 * g + 2] * sc, oacc[qb][dt][4 * g + 3] * sc);
-      } else if (q < NQ) {
+      } else if (a.out_fp8_scale <= 0.f) {
+        // A lane holds 4 consecutive d of its query per (dt, g) and lane ^ 32 the next 4: one v_permlane32_swap per register pairs
+        // them into 8 consecutive d = one 16-B store per lane (8 dwordx4 stores per query block instead of 16 dwordx2: the store
+        // tail of an attention block is issue-bound, guide "attention epilogue store tail").  The swap runs with all lanes on.
         __bf16* o = reinterpret_cast<__bf16*>(a.out) + orow * a.ld_out + head * 64;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int d = dt * 32 + 8 * g + 4 * kh;
-            uint2 pk = make_uint2(pack_bf16x2(oacc[qb][dt][4 * g + 0] * inv, oacc[qb][dt][4 * g + 1] * inv),
-                                  pack_bf16x2(oacc[qb][dt][4 * g + 2] * inv, oacc[qb][dt][4 * g + 3] * inv));
-            *reinterpret_cast<uint2*>(o + d) = pk;
+          for (int j = 0; j < 2; ++j) {
+            const int g0 = 2 * j, g1 = 2 * j + 1;
+            const unsigned x0 = pack_bf16x2(oacc[qb][dt][4 * g0 + 0] * inv, oacc[qb][dt][4 * g0 + 1] * inv);
+            const unsigned x1 = pack_bf16x2(oacc[qb][dt][4 * g0 + 2] * inv, oacc[qb][dt][4 * g0 + 3] * inv);
+            const unsigned y0 = pack_bf16x2(oacc[qb][dt][4 * g1 + 0] * inv, oacc[qb][dt][4 * g1 + 1] * inv);
+            const unsigned y1 = pack_bf16x2(oacc[qb][dt][4 * g1 + 2] * inv, oacc[qb][dt][4 * g1 + 3] * inv);
+            const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);  // lanes < 32: {own x, partner's x}; >= 32: {partner's y, own y}
+            const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
+            if (q < NQ) *reinterpret_cast<uint4*>(o + dt * 32 + 16 * j + 8 * kh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
           }
       }
     }
@@ -750,14 +813,17 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
     FP_REQUIRE(a.variant >= 0 && a.variant <= 3, "attention: unknown kernel variant %d", a.variant);
-    const int w64 = a.variant == 1 ? 0 : (a.variant == 2 ? 2 : 1);  // default: 64 queries per wave; 3: the same with 8 waves = 512-query blocks
+    // A/B switch for same-box measurements of the whole pipeline: FP_ATTN_DEFAULT_VARIANT=<2|3> runs that split where 0 was asked for
+    static const int dflt = [] { const char* e = getenv("FP_ATTN_DEFAULT_VARIANT"); const int v = e ? atoi(e) : 0; return v == 2 || v == 3 ? v : 0; }();
+    const int variant = a.variant == 0 ? dflt : a.variant;
+    const int w64 = variant == 1 ? 0 : (variant == 2 ? 2 : 1);  // default: 64 queries per wave; 3: the same with 8 waves = 512-query blocks
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     const bool sel = a.sel_off != nullptr;
     FP_REQUIRE(!sel || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");
     FP_REQUIRE(!sel || (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull), "attention: query selection exists in the 64-queries-per-wave kernel only");
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
-      const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, a.variant == 3 ? 512 : 256) * a.heads * a.batch);
-      if (a.variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
+      const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, variant == 3 ? 512 : 256) * a.heads * a.batch);
+      if (variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
       else if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {

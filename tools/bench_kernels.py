@@ -28,7 +28,7 @@ def timeit(fn, iters=20):
 
 def main():
     what = sys.argv[1:] or ["gemm", "attn", "ln"]
-    B, N, D, H = 32, int(os.environ.get("BENCH_TOKENS", 1374)), 1024, 16   # BENCH_TOKENS=611: the selected rows of the hooked block
+    B, N, D, H = int(os.environ.get("BENCH_BATCH", 32)), int(os.environ.get("BENCH_TOKENS", 1374)), 1024, 16   # BENCH_TOKENS=611: the selected rows of the hooked block
     M = (B * N + 255) // 256 * 256
     dev = "cuda"
     if "gemm" in what:
@@ -55,7 +55,7 @@ def main():
     if "attn" in what:
         qkv = (torch.randn(M, 3 * D, device=dev)).to(torch.bfloat16)
         for rep in range(2):
-            for variant in (0, 3, 2):
+            for variant in [int(v) for v in os.environ.get("BENCH_ATTN_VARIANTS", "0,3,2").split(",")]:
                 ms = timeit(lambda: ops.attention(qkv, B, N, D, H, variant=variant))
                 print(f"attn B={B} N={N} H={H} variant={variant}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
     if "cos" in what:
