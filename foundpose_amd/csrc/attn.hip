@@ -555,6 +555,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 //   V image [64 keys][256 B]: 64-B unit  u of row r holds unit  u ^ (r & 3)         (transpose reads: a half-wave's four keys x 64 B
 //                                                                                    fall into the four bank quarters)
 constexpr float SPLIT_P_SCALE = 16384.f;
+constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);  // 1 in the exponent, in score units
 
 __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][16384];  // [stage][K | V]
@@ -666,14 +667,24 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
       float mx = fmaxf(sacc[0][0], sacc[1][0]);
 #pragma unroll
       for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-      const float m_new = fmaxf(m_run, mx);
-      const bool grow = __any(m_new > m_run);
+      {  // the query's other 32 scores live in lane ^ 32 (one v_permlane32_swap; results through temporaries, see attn_bf16_w64_kernel)
+        const unsigned mu = __builtin_bit_cast(unsigned, mx);
+        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+        const unsigned m0 = sw[0], m1 = sw[1];
+        mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
+      }
+      // lazy rescale, per query (attn_bf16_w64_kernel): here the reference may trail the maximum by at most 1 in the exponent --
+      // p <= 2, and 2 * SPLIT_P_SCALE = 2^15 still splits into fp16 (max 65504)
+      const bool moves = mx - m_run > SPLIT_LAZY_TH;
+      const bool grow = __any(moves);
       float alpha = 1.f;
-      if (grow) alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
+      if (grow) {
+        const float m_new = moves ? mx : m_run;
+        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+        m_run = m_new;
+      }
       float psum = 0.f;
-      const float mc = m_new * c;
+      const float mc = m_run * c;
       f16x8 ph[4], pl[4];
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks) {
@@ -738,20 +749,27 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     const int q = q0 + l31;
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
-    if (q < N) {
-      _Float16* o = reinterpret_cast<_Float16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 128;
+    // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
+    _Float16* o = reinterpret_cast<_Float16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 128;
 #pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
+    for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          unsigned h01, l01, h23, l23;
-          split16_pack2(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, a.out_scale, h01, l01);
-          split16_pack2(oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv, a.out_scale, h23, l23);
-          _Float16* op = o + dt * 64 + 8 * g + 4 * kh;
-          *reinterpret_cast<uint2*>(op) = make_uint2(h01, h23);
-          *reinterpret_cast<uint2*>(op + 32) = make_uint2(l01, l23);
+      for (int j = 0; j < 2; ++j) {
+        unsigned xh0, xl0, xh1, xl1, yh0, yl0, yh1, yl1;
+        split16_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xl0);
+        split16_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xl1);
+        split16_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yl0);
+        split16_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yl1);
+        const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
+        const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
+        const auto l0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false);
+        const auto l1 = __builtin_amdgcn_permlane32_swap(xl1, yl1, false, false);
+        _Float16* op = o + dt * 64 + 16 * j + 8 * kh;
+        if (q < N) {
+          *reinterpret_cast<uint4*>(op) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+          *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
         }
-    }
+      }
   }
 }
 
@@ -811,7 +829,7 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.dim % 64 == 0 && a.heads * 64 == a.dim, "attention: head_dim must be 64 (dim %d heads %d)", a.dim, a.heads);
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
-    FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_out % 4 == 0, "attention(bf16): leading dims must keep 16-byte alignment");
+    FP_REQUIRE(a.ld_qkv % 8 == 0 && (a.out_fp8_scale > 0.f ? a.ld_out % 4 == 0 : a.ld_out % 8 == 0), "attention(bf16): leading dims must keep 16-byte alignment");
     FP_REQUIRE(a.variant >= 0 && a.variant <= 3, "attention: unknown kernel variant %d", a.variant);
     // A/B switch for same-box measurements of the whole pipeline: FP_ATTN_DEFAULT_VARIANT=<2|3> runs that split where 0 was asked for
     static const int dflt = [] { const char* e = getenv("FP_ATTN_DEFAULT_VARIANT"); const int v = e ? atoi(e) : 0; return v == 2 || v == 3 ? v : 0; }();
@@ -831,7 +849,7 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     }
   } else if (dtype == FP_DTYPE_F16X3) {
     FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
-    FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 4 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
+    FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 8 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
     FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
     FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
     hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);

@@ -1,5 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for v in 0 2 0 2; do
-echo "== default variant $v"
-FP_ATTN_DEFAULT_VARIANT=$v python bench.py --skip-probes --steps 10 --warmup 3 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.readlines()[-1]); print(d['value'], d['ms_per_step'])"
-done
+python -m pytest tests/test_gpu_split.py tests/test_gpu_vit.py -q -m gpu -x 2>&1 | tail -3
+python bench.py --steps 10 --warmup 3 2>/dev/null | tail -1 > gpurun_out/bench_now.json
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/bench_now.json'))
+print(d['value'], d['ms_per_step'])
+print(json.dumps(d.get('parity_mode'), indent=None)[:1500])
+PY
