@@ -348,17 +348,21 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     if (active) {
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
       f32x16 sacc[QC][2];
+      // four independent accumulation chains (2 key halves x 2 query blocks) interleaved over the four 16-d steps (two chains, key
+      // half outermost, measured 1 % slower: a dependent MFMA waits for its predecessor's last pass)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int qb = 0; qb < QC; ++qb)
 #pragma unroll
           for (int r = 0; r < 16; ++r) sacc[qb][ks][r] = 0.f;
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
+      for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
 #ifdef FP_ATTN_NO_LDS  // (measurement builds: fragments from registers instead of LDS)
           bf16x8 kf = qf[0][ds];
-          kf[0] = (__bf16)(float)(kt & 3);
+          kf[0] = (__bf16)(float)((kt + ks) & 3);
 #else
           const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
 #endif
@@ -366,7 +370,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           for (int qb = 0; qb < QC; ++qb)
             sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
         }
-      }
 #if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
       // (-DFP_ATTN_TR_ASM, measured and NOT the default.)  The tile's eight V^T fragments issued HERE (they land under the softmax)
       // and as inline asm: through the builtin the compiler cannot tell a transpose read from an access to the stage the LDS-DMA

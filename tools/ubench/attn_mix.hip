@@ -1,12 +1,17 @@
 // What bounds the bf16 attention kernel at head_dim 64?  The kernel's own per-tile instruction stream (csrc/attn.hip, attn_bf16_w64_kernel<2>:
 // per wave and 64-key tile, two 32-query blocks: 16 score MFMAs + 16 P.V MFMAs, the fp32 online softmax, the bf16 packing) with everything
-// that touches memory removed -- operands are register constants, no LDS, no DMA, no barrier -- at the kernel's occupancy (two waves per SIMD).
-//   mode 0  the 32 MFMAs alone                                  -> the matrix pipe's own pace
+// that touches memory removed -- operands are register values, no LDS, no DMA, no barrier -- at the kernel's occupancy (two waves per SIMD).
+//   mode 0  the 32 MFMAs alone                                  -> the matrix pipe's own pace under this dependency structure
 //   mode 1  the softmax VALU work alone                         -> the vector pipe's own pace
-//   mode 2  both, INDEPENDENT (softmax on dummy registers)      -> what perfect co-issue of this instruction mix could reach
-//   mode 3  both, with the real dataflow S -> softmax -> P.V    -> what the dependency chain allows at two waves per SIMD, memory-free
-// Output: cycles per (wave, tile) and the equivalent TFLOP/s of 4 N^2 D attention at 256 CUs; compare mode 3 with the real kernel
-// (tools/bench_kernels.py attn): the difference is LDS fragment reads, LDS-DMA and the per-tile barrier.
+//   mode 2  both, INDEPENDENT (softmax on dummy registers)
+//   mode 3  both, with the real dataflow S -> softmax -> P.V    -> the kernel's tile loop, memory-free
+// plus: the rescale branch taken every tile (what the exact running maximum costs on random scores), the kernel's launch shape (3072
+// workgroups x 22 tiles), and the leaner softmax streams that were candidates (reference folded into the score MFMA's C operand = no fma;
+// no running maximum; row sum by v_dot2c over the packed probabilities) -- none of which is faster than the plain stream by more than 6 %.
+// Measured (MI355X, us per tile-round = one tile of each of the two waves of a SIMD; fraction of the 2.5 PFLOP/s dense bf16 peak):
+//   MFMAs alone 1.30 (0.66) | softmax alone 1.30 | real dataflow 1.84 (0.47) | launch shape 241 us (0.42) -- the same 240 us the real
+//   kernel takes with its DMA, barrier and LDS reads compiled out (tools/attn_ablate.sh).  The real kernel: 324 us (0.31).
+// (The two 32-key halves of a tile must get different fragments: with one fragment the compiler merges them -- 24 MFMAs, half the softmax.)
 //   hipcc --offload-arch=gfx950 -O3 -mllvm -amdgpu-mfma-vgpr-form tools/ubench/attn_mix.hip -o tools/ubench/attn_mix && tools/ubench/attn_mix
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -176,7 +181,8 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void lean_kernel(float* out, i
 #pragma unroll
         for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
         auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
-        mx = fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
+        const unsigned m0 = sw[0], m1 = sw[1];
+        mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ++ks)
