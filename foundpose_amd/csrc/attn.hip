@@ -834,9 +834,11 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && (a.out_fp8_scale > 0.f ? a.ld_out % 4 == 0 : a.ld_out % 8 == 0), "attention(bf16): leading dims must keep 16-byte alignment");
     FP_REQUIRE(a.variant >= 0 && a.variant <= 3, "attention: unknown kernel variant %d", a.variant);
-    // A/B switch for same-box measurements of the whole pipeline: FP_ATTN_DEFAULT_VARIANT=<2|3> runs that split where 0 was asked for
-    static const int dflt = [] { const char* e = getenv("FP_ATTN_DEFAULT_VARIANT"); const int v = e ? atoi(e) : 0; return v == 2 || v == 3 ? v : 0; }();
-    const int variant = a.variant == 0 ? dflt : a.variant;
+#ifdef FP_ATTN_DEFAULT_VARIANT  // (measurement build for same-box A/B runs of the whole pipeline: that split where 0 was asked for)
+    const int variant = a.variant == 0 ? FP_ATTN_DEFAULT_VARIANT : a.variant;
+#else
+    const int variant = a.variant;
+#endif
     const int w64 = variant == 1 ? 0 : (variant == 2 ? 2 : 1);  // default: 64 queries per wave; 3: the same with 8 waves = 512-query blocks
     FP_REQUIRE(a.out_fp8_scale <= 0.f || (w64 && a.ld_out % 4 == 0), "attention: the fp8 output exists in the 64-queries-per-wave kernel only");
     const bool sel = a.sel_off != nullptr;
