@@ -37,6 +37,17 @@ PMC_TRAFFIC_SOURCE = ("profiles/r3_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv
                       "round-3 tree, the kernel's code is unchanged since round 2: 819.7 MB there)")
 
 
+# Matrix-pipe utilisation of the ViT forward as the counters report it: sum of SQ_VALU_MFMA_BUSY_CYCLES over the bf16 step's ViT launches /
+# (1024 SIMDs x their GRBM_GUI_ACTIVE / 8 cycles), from the rocprofv3 --pmc pass of THIS code over `python bench.py --skip-probes`.  It is
+# higher than the FLOP fraction of the nominal 2.5 PFLOP/s because the chip holds ~2.0 of its 2.4 GHz under this load (DVFS).
+PMC_MFMA_UTIL = {
+    # per kernel: RESID 0.397 (144 launches x 554.8 k cycles), fc1 0.449 (76 x 761.5 k), attention 0.371 (76 x 634.2 k), qkv 0.473 (76 x 558.1 k),
+    # hooked block's 128^2 launches 0.264 (8 x 378.1 k), patch embed 0.220 (4 x 250.4 k), ln_finalize 0 (152 x 31.2 k)
+    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.408, "resid_gemm": 0.397, "fc1": 0.449, "qkv": 0.473, "attention": 0.371},
+}
+PMC_MFMA_UTIL_SOURCE = "profiles/r3_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-3 checkout)"
+
+
 def synthetic_disc_patches(size):
     """Query patches of the default disc mask (radius 0.35 S)."""
     from foundpose_amd import synthetic
@@ -340,7 +351,8 @@ def main():
                                      "fc2": {"launch_ms": round(ms_fc2, 4), "frac": round(fl(arch.dim, hid) / (ms_fc2 * 1e-3) / 1e12 / peak_mfma, 4)}},
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
                                         "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": flops_exec,
-                                        "flops_per_detection_all_tokens": vit_flops_per_crop(arch, args.size, args.layer)},
+                                        "flops_per_detection_all_tokens": vit_flops_per_crop(arch, args.size, args.layer),
+                                        "mfma_busy_pmc": PMC_MFMA_UTIL.get(key), "mfma_busy_pmc_source": PMC_MFMA_UTIL_SOURCE if key in PMC_MFMA_UTIL else None},
             "token_selection": sel_info,
             "roofline_knn": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}' (template-descriptor streaming + top-5, whole call)", "bound": "hbm",
                              "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",

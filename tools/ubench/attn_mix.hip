@@ -28,7 +28,7 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));
 }
 
-template <int MODE, int WAVES_PER_SIMD, bool GROW = false>
+template <int MODE, int WAVES_PER_SIMD, bool GROW = false, bool ILP = false>
 __global__ __launch_bounds__(256, WAVES_PER_SIMD) void mix_kernel(float* out, int tiles, unsigned seed) {
   const int lane = threadIdx.x & 63;
   // register-constant "fragments" (values small enough that nothing overflows over the loop)
@@ -74,9 +74,19 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void mix_kernel(float* out, in
       if (MODE != 0) {
         f32x16* sc = (MODE == 3) ? sacc : dummy;   // compile-time choice
         // ---- the kernel's online softmax, verbatim
-        float mx = fmaxf(sc[0][0], sc[1][0]);
+        float mx;
+        if (ILP) {  // four independent max chains / row-sum chains instead of one serial chain each
+          float m4[4];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
+          for (int i = 0; i < 4; ++i) m4[i] = fmaxf(sc[0][i], sc[1][i]);
+#pragma unroll
+          for (int r = 4; r < 16; ++r) m4[r & 3] = fmaxf(fmaxf(m4[r & 3], sc[0][r]), sc[1][r]);
+          mx = fmaxf(fmaxf(m4[0], m4[1]), fmaxf(m4[2], m4[3]));
+        } else {
+          mx = fmaxf(sc[0][0], sc[1][0]);
+#pragma unroll
+          for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sc[0][r]), sc[1][r]);
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run[qb], mx);
         const bool grow = GROW ? __any(m_new >= m_run[qb]) : __any(m_new > m_run[qb]);  // GROW: the rescale branch taken every tile
@@ -85,14 +95,16 @@ __global__ __launch_bounds__(256, WAVES_PER_SIMD) void mix_kernel(float* out, in
         m_run[qb] = m_new;
         float psum = 0.f;
         const float mc = m_new * c;
-        float p[2][16];
+        float p[2][16], ps4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             p[ks][r] = __builtin_amdgcn_exp2f(fmaf(sc[ks][r], c, -mc));
-            psum += p[ks][r];
+            if (ILP) ps4[r & 3] += p[ks][r];
+            else psum += p[ks][r];
           }
+        if (ILP) psum = (ps4[0] + ps4[1]) + (ps4[2] + ps4[3]);
         if (grow) {
           l_run[qb] *= alpha;
 #pragma unroll
@@ -247,15 +259,15 @@ static double run_lean(int wgs, int tiles, float* d_out) {
   return ms / 5.0;
 }
 
-template <int MODE, int WPS, bool GROW = false>
+template <int MODE, int WPS, bool GROW = false, bool ILP = false>
 static double run(int wgs, int tiles, float* d_out) {
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  mix_kernel<MODE, WPS, GROW><<<wgs, 256>>>(d_out, tiles, 1);
+  mix_kernel<MODE, WPS, GROW, ILP><<<wgs, 256>>>(d_out, tiles, 1);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  for (int i = 0; i < 5; ++i) mix_kernel<MODE, WPS, GROW><<<wgs, 256>>>(d_out, tiles, 2 + i);
+  for (int i = 0; i < 5; ++i) mix_kernel<MODE, WPS, GROW, ILP><<<wgs, 256>>>(d_out, tiles, 2 + i);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
@@ -283,6 +295,11 @@ int main() {
       const double tf = m == 1 ? 0.0 : flop_tile * (double)wgs * 4 * tiles / (ms[m] * 1e-3) / 1e12;
       printf("%d wave(s)/SIMD  %-22s %8.3f us per tile-round  %8.1f TFLOP/s equivalent (%.3f of 2500)\n", occ, names[m], us_tile, tf, tf / 2500.0);
     }
+  }
+  {
+    const double a = run<1, 2, false, true>(cus * 2, tiles, d_out), b = run<3, 2, false, true>(cus * 2, tiles, d_out), c1 = run<3, 1, false, true>(cus, tiles, d_out);
+    printf("four max / row-sum chains instead of one:  softmax only %8.3f   real dataflow %8.3f (2 waves/SIMD)  %8.3f (1 wave/SIMD) us per tile-round\n",
+           a * 1e3 / tiles, b * 1e3 / tiles, c1 * 1e3 / tiles);
   }
   // the same stream with the rescale branch taken in every tile (random scores: some lane of 64 sees a new maximum in most tiles)
   {
