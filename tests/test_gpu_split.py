@@ -159,6 +159,25 @@ def test_attention_split_forced_rescale_and_constant_rows():
     assert rel_err(out, qkv[:, 2 * D:].double().mean(0, keepdim=True).expand(N, D)) < 5e-6
 
 
+@pytest.mark.parametrize("step", [0.4, 0.9, 3.0, 20.0])
+def test_attention_split_lazy_rescale_staircase(step):
+    """attn_split_kernel's reference may trail the maximum by at most 1 in the exponent (p <= 2 keeps P * 2^14 inside fp16): scores that
+    climb by `step` per 64-key tile, queries of four gains in one wave -- no rescale for several tiles, one every tile, jumps of 2^20."""
+    N, D, heads = 64 * 9 + 17, 64, 1
+    g = torch.Generator(device="cuda").manual_seed(int(step * 10))
+    qkv = torch.randn(N, 3 * D, generator=g, device="cuda") * 0.3
+    gain = torch.tensor([1.0, 2.0, 4.0, 0.5], device="cuda")[torch.arange(N, device="cuda") % 4]
+    qkv[:, 0] = gain * 4.0
+    tile = (torch.arange(N, device="cuda") // 64).float()
+    qkv[:, D] = tile * step / (4.0 * 4.0 * 0.125 * 1.4426950408889634)
+    packed = torch.cat([ops.split16_pack(qkv[:, i * D:(i + 1) * D].contiguous(), 64.0) for i in range(3)], dim=1)
+    out = ops.split16_unpack(ops.attention_split(packed, 1, N, D, heads, 64.0, 128.0), 128.0)
+    ref = _ref_attention(*(qkv[:, i * D:(i + 1) * D].double() for i in range(3)), 1, N, heads)
+    o32 = ops.attention(qkv, 1, N, D, heads)   # the exact mode's fp32 kernel: scores of magnitude 10^2..10^3 carry fp32 rounding of their own
+    e, e32 = rel_err(out, ref), rel_err(o32, ref)
+    assert e < 5e-6 or e < 2 * e32, (e, e32)
+
+
 TINY = VitArch("tiny-reg", dim=128, depth=3, heads=2, ffn="mlp", hidden=512, registers=4, pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
 TINY_G = VitArch("tinyg-reg", dim=128, depth=2, heads=2, ffn="swiglu", hidden=384, registers=4, pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
 

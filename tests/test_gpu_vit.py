@@ -105,6 +105,30 @@ def test_attention_bf16_and_f32(B, N, heads):
     assert float((o16.double() - ref).abs().max()) < 3 * 2 ** -8 * float(ref.abs().max())
 
 
+@pytest.mark.parametrize("step", [0.9, 2.5, 5.0, 12.0])
+def test_attention_bf16_lazy_rescale_staircase(step):
+    """The exponent's reference moves only when a tile's maximum exceeds it by more than 8 (csrc/attn.hip, lazy rescale).  Keys whose
+    scores climb by `step` (in the exponent, per 64-key tile) walk through every regime: never more than 8 above the reference for long
+    stretches (p up to 2^8, no rescale), a rescale every few tiles, a rescale every tile; queries of different gain see different regimes
+    in one wave, so lanes that move and lanes that do not share the rescale branch.  All four work splits stay bit-identical."""
+    from foundpose_amd import ops
+    N, D, heads = 64 * 9 + 17, 64, 1
+    g = torch.Generator().manual_seed(int(step * 10))
+    qkv = torch.randn(N, 3 * D, generator=g) * 0.3
+    gain = torch.tensor([1.0, 2.0, 4.0, 0.5])[torch.arange(N) % 4]
+    qkv[:, 0] = gain * 4.0                                             # q: dimension 0 carries the gain
+    tile = (torch.arange(N) // 64).float()
+    qkv[:, D] = tile * step / (4.0 * 4.0 * 0.125 * 1.4426950408889634)  # k: + `step` in the exponent per tile for the gain-4 queries
+    q16 = qkv.to(torch.bfloat16)
+    q, k, v = q16.double().reshape(1, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
+    ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(N, D)
+    outs = [ops.attention(q16.cuda(), 1, N, D, heads, variant=v_).clone() for v_ in (0, 1, 2, 3)]
+    torch.cuda.synchronize()
+    for o in outs[1:]:
+        assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
+    assert float((outs[0].cpu().double() - ref).abs().max()) < 3 * 2 ** -8 * float(ref.abs().max())
+
+
 @pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 8), (3, 905, 2), (1, 256, 1), (2, 257, 4), (1, 321, 16)])
 def test_attention_bf16_work_splits_agree_bitwise(B, N, heads):
     """The 64-queries-per-wave kernel (LDS-DMA staging) and the 32-queries-per-wave kernel issue the same MFMAs in the
