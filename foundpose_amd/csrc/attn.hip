@@ -826,6 +826,153 @@ __global__ __launch_bounds__(256) void attn_f32_kernel(AttnArgs a) {
   }
 }
 
+
+// ---------------------------------------------------------------- fp32 mode on the fp32 MFMA (v_mfma_f32_32x32x2_f32)
+// The exact-fp32 mode's attention as a flash kernel on the matrix pipe: every product and every accumulation is fp32 (the MFMA's fma
+// chain), the softmax is the fp32 online softmax of the kernels above.  4 waves x one 32-query block per workgroup; a 64-key K / V tile
+// lives in LDS as fp32 rows of 64 + 4 floats (272 B: eight consecutive rows start in the eight 16-B bank groups, so the b128 fragment
+// reads are conflict free), filled through registers -- the next tile's global loads are issued before the current tile's MFMAs.
+//   S^T = K Q^T : A = K (32 keys x 2 d), B = Q^T (2 d x 32 queries); the k-pair of step s is d = (s, 32 + s): lane (l31, kh) holds
+//                 Q[query l31][32 kh + s] (pre-multiplied by head_dim^-0.5, exact) and reads K[key][32 kh + 0..31] as eight b128.
+//   O^T += V^T P^T : the B operand of the step that multiplies keys (x, x + 4) is the score register itself -- a lane's register r of
+//                 key half ks is key 32 ks + (r & 3) + 8 (r >> 2) + 4 kh, i.e. exactly (query l31, k = kh) -- no conversion, no
+//                 exchange; A = V[that key][l31 + 32 dt], one b32 read per MFMA.
+// 128 MFMAs of 64 cycles per wave and key tile: matrix-pipe bound (256 flop/clk/CU).
+__global__ __launch_bounds__(256, 2) void attn_f32_mfma_kernel(AttnArgs a) {
+  constexpr int LDR = 68;  // floats per LDS row
+  __shared__ __attribute__((aligned(16))) float Ks[64 * LDR];
+  __shared__ __attribute__((aligned(16))) float Vs[64 * LDR];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+  const int qt = blockIdx.x, head = blockIdx.y, img = blockIdx.z;
+  const int N = a.n_tok, D = a.dim;
+  const float* qkv = reinterpret_cast<const float*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  const int q = qt * 128 + wave * 32 + l31;
+  const int qc = q < N ? q : N - 1;
+  float qv[32];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float4 t = *reinterpret_cast<const float4*>(qkv + (size_t)qc * a.ld_qkv + head * 64 + 32 * kh + 4 * j);
+    qv[4 * j + 0] = t.x * 0.125f; qv[4 * j + 1] = t.y * 0.125f; qv[4 * j + 2] = t.z * 0.125f; qv[4 * j + 3] = t.w * 0.125f;  // q * scale, like upstream
+  }
+  f32x16 oacc[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
+  float m_run = -INFINITY, l_run = 0.f;
+  // staging: thread t moves float4 chunk (row = c >> 4, col4 = c & 15), c = t + 256 i, of K and of V
+  float4 kst[4], vst[4];
+  auto load_tile = [&](int key0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c4 = c & 15;
+      int key = key0 + r;
+      key = key < N ? key : N - 1;
+      const float* src = qkv + (size_t)key * a.ld_qkv + D + head * 64 + 4 * c4;
+      kst[i] = *reinterpret_cast<const float4*>(src);
+      vst[i] = *reinterpret_cast<const float4*>(src + D);
+    }
+  };
+  auto store_tile = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = tid + 256 * i, r = c >> 4, c4 = c & 15;
+      *reinterpret_cast<float4*>(Ks + r * LDR + 4 * c4) = kst[i];
+      *reinterpret_cast<float4*>(Vs + r * LDR + 4 * c4) = vst[i];
+    }
+  };
+  const int nkt = (N + 63) / 64;
+  load_tile(0);
+  store_tile();
+  __syncthreads();
+  constexpr float LOG2E = 1.44269504088896340736f;
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int key0 = kt * 64;
+    if (kt + 1 < nkt) load_tile(key0 + 64);  // lands under this tile's MFMAs
+    // ---- S^T = K Q^T
+    f32x16 sacc[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
+      float4 kf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kf[j] = *reinterpret_cast<const float4*>(Ks + (ks * 32 + l31) * LDR + 32 * kh + 4 * j);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].x, qv[4 * j + 0], sacc[ks], 0, 0, 0);
+        sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].y, qv[4 * j + 1], sacc[ks], 0, 0, 0);
+        sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].z, qv[4 * j + 2], sacc[ks], 0, 0, 0);
+        sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[j].w, qv[4 * j + 3], sacc[ks], 0, 0, 0);
+      }
+    }
+    if (key0 + 64 > N) {  // ragged last tile: mask the padded keys
+      const int lim = N - key0 - 4 * kh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
+    }
+    // ---- online softmax (a query's 64 scores live in lanes l31 and l31 + 32); exact running maximum
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+    {
+      const unsigned mu = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      const unsigned m0 = sw[0], m1 = sw[1];
+      mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
+    }
+    const float m_new = fmaxf(m_run, mx);
+    const bool grow = __any(m_new > m_run);
+    float alpha = 1.f;
+    if (grow) alpha = __builtin_amdgcn_exp2f((m_run - m_new) * LOG2E);
+    m_run = m_new;
+    const float mc = m_new * LOG2E;
+    float psum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], LOG2E, -mc));
+        sacc[ks][r] = p;
+        psum += p;
+      }
+    if (grow) {
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    l_run += psum;
+    // ---- O^T += V^T P^T
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float* vrow = Vs + (ks * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh) * LDR + l31;
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[0], sacc[ks][r], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[32], sacc[ks][r], oacc[1], 0, 0, 0);
+      }
+    __syncthreads();  // every wave is done with the tile
+    if (kt + 1 < nkt) store_tile();
+    __syncthreads();
+  }
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / l_tot;
+  if (q < N) {
+    float* o = reinterpret_cast<float*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 64;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(o + dt * 32 + 8 * g + 4 * kh) =
+            make_float4(oacc[dt][4 * g + 0] * inv, oacc[dt][4 * g + 1] * inv, oacc[dt][4 * g + 2] * inv, oacc[dt][4 * g + 3] * inv);
+  }
+}
+
 }  // namespace
 
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
@@ -860,8 +1007,12 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
-    dim3 grid(cdiv(a.n_tok, 256), a.heads, a.batch);
-    hipLaunchKernelGGL(attn_f32_kernel, grid, dim3(256), 0, st, a);
+    if (a.variant == 1) {  // the thread-per-query VALU kernel (one fma chain per score, keys in order): the cross-check of the MFMA kernel
+      hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(a.n_tok, 256), a.heads, a.batch), dim3(256), 0, st, a);
+    } else {
+      FP_REQUIRE(a.ld_qkv % 4 == 0 && a.ld_out % 4 == 0, "attention(fp32): leading dims must keep 16-byte alignment");
+      hipLaunchKernelGGL(attn_f32_mfma_kernel, dim3(cdiv(a.n_tok, 128), a.heads, a.batch), dim3(256), 0, st, a);
+    }
   } else {
     fp_set_error("attention: unsupported dtype %d", dtype);
     return FP_ERR_UNSUPPORTED;

@@ -58,6 +58,11 @@ def main():
             for variant in [int(v) for v in os.environ.get("BENCH_ATTN_VARIANTS", "0,3,2").split(",")]:
                 ms = timeit(lambda: ops.attention(qkv, B, N, D, H, variant=variant))
                 print(f"attn B={B} N={N} H={H} variant={variant}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
+    if "attn32" in what:   # the exact-fp32 mode's attention: fp32 MFMA kernel (variant 0) vs the thread-per-query VALU kernel (variant 1)
+        qkv = torch.randn(M, 3 * D, device=dev)
+        for variant in (0, 1, 0):
+            ms = timeit(lambda: ops.attention(qkv, B, N, D, H, variant=variant), iters=5)
+            print(f"attn fp32 B={B} N={N} H={H} variant={variant}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s", flush=True)
     if "cos" in what:
         from foundpose_amd._lib import call, ptr, stream
         for T, W, Bq in ((10000, 2048, 32), (800, 2048, 32), (50000, 2048, 128)):
