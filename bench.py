@@ -230,7 +230,7 @@ def main():
         pm = {"precision": args.parity_precision, "value": round(world * B * args.parity_steps / el_pm, 2), "unit": "detections/s",
               "ms_per_step": round(1e3 * el_pm / args.parity_steps, 3), "steps": args.parity_steps, "n_gpus": world,
               "what": ("split-fp16 operands (hi + lo: 22 mantissa bits), every product = three fp16 MFMAs with fp32 accumulation, fp32 residual stream / "
-                       "LayerNorm / softmax / exact-erf GELU; all blocks on all tokens" if args.parity_precision == "f16x3"
+                       "LayerNorm / softmax / exact-erf GELU; the hooked block on the sampled tokens only, like the headline (bit-identical features)" if args.parity_precision == "f16x3"
                        else "exact-fp32 MFMA GEMMs (k-ascending fmaf chains) + fp32 attention")}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2

@@ -441,7 +441,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
   const int adt = sp ? FP_DTYPE_F16X3 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32);
   const int em = sp ? 2 : 1;                          // stored elements per logical element of an operand row
-  FP_REQUIRE(!sp || (mode == VIT_FULL && m->patch_acc_scale > 0.f), "fp_vit_forward: the f16x3 mode runs full blocks and needs patch_acc_scale");
+  FP_REQUIRE(!sp || m->patch_acc_scale > 0.f, "fp_vit_forward: the f16x3 mode needs patch_acc_scale");
   FP_REQUIRE(!f8 || (ws->a8 && ws->m_pad % 256 == 0), "fp_vit_forward: the fp8 mode needs workspace a8 and m_pad %% 256 == 0");
   FP_REQUIRE(!f8 || ((ws->ld_y == 0 || (ws->ld_y >= m->dim && ws->ld_y % 16 == 0)) && (ws->ld_h == 0 || (ws->ld_h >= m->hidden && ws->ld_h % 16 == 0)) &&
                      (m->ld_w_dim == 0 || (m->ld_w_dim >= m->dim && m->ld_w_dim % 16 == 0)) && (m->ld_w_hidden == 0 || (m->ld_w_hidden >= m->hidden && m->ld_w_hidden % 16 == 0))),
@@ -505,7 +505,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
     if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st));
   }
-  FP_REQUIRE(mode == VIT_FULL || fold, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold only");
+  FP_REQUIRE(mode == VIT_FULL || fold || sp, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold, or an f16x3 model");
   float2* ln_row = stats + (size_t)ln_parts * ws->m_pad;  // (rstd, mean * rstd) per row, behind the partial-sum slots
   int rows_valid = Mtok, rows_pad = ws->m_pad;  // the selected tail of the hooked block narrows these to the compact rows
   // (the residual GEMM files its partial sums with a stride of ITS row count: rows_pad)
@@ -571,12 +571,17 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       // f16x3 block: every GEMM / attention operand is a split-fp16 row written by the kernel in front of it (LayerNorm, the
       // qkv / GELU / SwiGLU epilogues, the attention kernel) with a fixed power-of-two scale; b.act_scale[j] = 1 / (scale of the
       // input x scale of the matrix) undoes both in the epilogue of GEMM j.  The residual stream, LayerNorm and softmax are fp32.
+      // mode VIT_LAST_SELECTED (the hooked block for the selected tokens only, as in the bf16 branch above): LayerNorm 1 and the qkv
+      // GEMM on all rows (keys / values need every token), attention takes its queries through the index list and writes compact
+      // rows, and from there on every operand has num_sel rows: the residual rows are gathered into the dead qkv buffer, proj /
+      // LayerNorm 2 / fc1 / fc2 run on them.  Per-row arithmetic does not depend on where a row sits: the same bits as the full block.
+      const bool selected = mode == VIT_LAST_SELECTED;
       auto sgemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
                        float acc_scale, float out_scale) -> int {
         GemmBf16Args g;
         memset(&g, 0, sizeof(g));
         g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
-        g.M = ws->m_pad; g.N = N; g.K = K; g.M_valid = Mtok; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+        g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
         g.acc_scale = acc_scale; g.out_scale = out_scale;
         return gemm_split_launch(epi, g, st);
       };
@@ -585,15 +590,26 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       TRY(sgemm(ws->y, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.act_scale[0], FP_SPLIT_SCALE_QKV));
       AttnArgs as = at;
       as.in_scale = FP_SPLIT_SCALE_QKV; as.out_scale = FP_SPLIT_SCALE_ACT;
-      TRY(attn_launch(as, FP_DTYPE_F16X3, st));
-      TRY(sgemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, b.ls1, ws->x, D, GEMM_EPI_LS_RESID_F32, b.act_scale[1], 0.f));
+      float* xr = ws->x;  // the residual rows the rest of the block updates
+      if (selected) {
+        as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;
+        TRY(attn_launch(as, FP_DTYPE_F16X3, st));
+        xr = reinterpret_cast<float*>(ws->qkv);  // qkv is dead after the attention: [num_sel, D] fp32 rows of the stream
+        TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xr, st));
+        rows_valid = sel->num;
+        rows_pad = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
+        ln.x = xr; ln.out_rows = rows_valid; ln.out_rows_per_img = rows_valid; ln.in_rows_per_img = rows_valid;
+      } else {
+        TRY(attn_launch(as, FP_DTYPE_F16X3, st));
+      }
+      TRY(sgemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, b.ls1, xr, D, GEMM_EPI_LS_RESID_F32, b.act_scale[1], 0.f));
       ln.weight = b.ln2_w; ln.bias = b.ln2_b;
       TRY(layernorm_launch(ln, st));
       if (m->ffn_swiglu)
         TRY(sgemm(ws->y, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.act_scale[2], FP_SPLIT_SCALE_HID));
       else
         TRY(sgemm(ws->y, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.act_scale[2], FP_SPLIT_SCALE_HID));
-      TRY(sgemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, b.ls2, ws->x, D, GEMM_EPI_LS_RESID_F32, b.act_scale[3], 0.f));
+      TRY(sgemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, b.ls2, xr, D, GEMM_EPI_LS_RESID_F32, b.act_scale[3], 0.f));
       continue;
     }
     if (f8) {

@@ -566,7 +566,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   const int l31 = lane & 31, kh = lane >> 5;
   int qt, head, img;
   {
-    const int nqt = (a.n_tok + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
     int pair;
     if ((pairs & 7) == 0) {  // all query tiles of an (image, head) pair on one XCD (one L2), see attn_bf16_kernel
       const int j = i >> 3;
@@ -581,8 +581,12 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   }
   const int N = a.n_tok, D = a.dim;
   const _Float16* qkv = reinterpret_cast<const _Float16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  // queries: every token, or the image's selected tokens (keys / values: always all N tokens), as in attn_bf16_w64_kernel
+  const int sel_base = a.sel_off ? a.sel_off[img] : 0;
+  const int NQ = a.sel_off ? a.sel_off[img + 1] - sel_base : N;
+  if (qt * 256 >= NQ) return;  // selected mode: the grid is sized for the image with the most queries (block-uniform, before any barrier)
   const int q0 = qt * 256 + wave * 32;
-  const bool active = q0 < N;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
+  const bool active = q0 < NQ;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
 
   // ---- staging: a DMA instruction moves 4 rows x 256 B; wave w issues row groups 2w, 2w + 1 of K and of V
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (unsigned)((size_t)N * a.ld_qkv * 2), 0x00020000);
@@ -612,7 +616,8 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   f16x8 qh[4], ql[4];
   {
     const int q = q0 + l31;
-    const int qc = q < N ? q : N - 1;
+    int qc = q < NQ ? q : NQ - 1;
+    if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;  // the selected query's token
     const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
@@ -753,7 +758,8 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
     // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
-    _Float16* o = reinterpret_cast<_Float16*>(a.out) + ((size_t)img * N + q) * a.ld_out + head * 128;
+    const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
+    _Float16* o = reinterpret_cast<_Float16*>(a.out) + orow * a.ld_out + head * 128;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -768,7 +774,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
         const auto l0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false);
         const auto l1 = __builtin_amdgcn_permlane32_swap(xl1, yl1, false, false);
         _Float16* op = o + dt * 64 + 16 * j + 8 * kh;
-        if (q < N) {
+        if (q < NQ) {
           *reinterpret_cast<uint4*>(op) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
           *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
         }
@@ -1000,13 +1006,13 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
     }
   } else if (dtype == FP_DTYPE_F16X3) {
-    FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
+    FP_REQUIRE(!a.sel_off || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 8 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
     FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
     FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
-    hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
+    hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
   } else if (dtype == FP_DTYPE_F32) {
-    FP_REQUIRE(!a.sel_off, "attention: query selection is a bf16 feature");
+    FP_REQUIRE(!a.sel_off, "attention: query selection exists in the bf16 and f16x3 kernels");
     if (a.variant == 1) {  // the thread-per-query VALU kernel (one fma chain per score, keys in order): the cross-check of the MFMA kernel
       hipLaunchKernelGGL(attn_f32_kernel, dim3(cdiv(a.n_tok, 256), a.heads, a.batch), dim3(256), 0, st, a);
     } else {

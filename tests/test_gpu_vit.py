@@ -626,15 +626,16 @@ def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
     assert torch.equal(got, want)
 
 
-@pytest.mark.parametrize("version,size,layer", [("vits14-reg", 224, 3), ("vits14-reg", 224, 0), ("vitl14-reg", 518, 2)])
-def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer):
+@pytest.mark.parametrize("version,size,layer,precision", [("vits14-reg", 224, 3, "bf16"), ("vits14-reg", 224, 0, "bf16"), ("vitl14-reg", 518, 2, "bf16"),
+                                                         ("vits14-reg", 224, 3, "f16x3"), ("vits14-reg", 224, 0, "f16x3"), ("vitl14-reg", 518, 1, "f16x3")])
+def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer, precision):
     """fp_vit_forward_prefix + fp_vit_block_selected + fp_vit_sample_features_selected: the hooked block computed only for
     the patch tokens the sampling reads (attention queries, proj, fc1, fc2 on the selected rows; keys / values all tokens)
     gives the SAME sampled features, bit for bit, as the full forward -- per-image selections of different sizes (a disc, a
     thin bar, a single cell, everything), points on and off the cell centres."""
     from foundpose_amd import feature_util
     from foundpose_amd.engine import FoundPoseEngine
-    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision="bf16").to("cuda")
+    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision=precision).to("cuda")
     assert ex.supports_token_selection
     B = 4
     imgs = synthetic.make_crops(B, size, seed=5).cuda()
