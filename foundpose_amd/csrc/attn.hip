@@ -648,20 +648,27 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
       // ---- S^T = K Q^T: sacc[ks][r] = score(query l31, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
       f32x16 sacc[2];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
-        const int row = ks * 32 + l31;
-        const char* kr = Ks + row * 256;
 #pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-          const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
-          const f16x8 kfh = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
-          const f16x8 kfl = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
-          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl, qh[ds], sacc[ks], 0, 0, 0);
-          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, ql[ds], sacc[ks], 0, 0, 0);
-          sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[ds], sacc[ks], 0, 0, 0);
+      for (int ds = 0; ds < 4; ++ds) {
+        const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
+        f16x8 kfh[2], kfl[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const int row = ks * 32 + l31;
+          const char* kr = Ks + row * 256;
+          kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
+          kfl[ks] = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
         }
+        // the two key halves' chains interleaved (per accumulator the order stays lo.hi, hi.lo, hi.hi over ds ascending)
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
+        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
+        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
       }
       if constexpr (RAGGED) {  // mask the padded keys
         const int lim = N - key0 - 4 * kh;
@@ -726,9 +733,10 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
           for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
       }
       l_run += psum;
-      // ---- O^T += V^T P^T over 4 steps of 16 keys
+      // ---- O^T += V^T P^T over 4 steps of 16 keys; the two d-halves' chains interleaved (per accumulator: lo.hi, hi.lo, hi.hi, k-steps ascending)
 #pragma unroll
-      for (int kstep = 0; kstep < 4; ++kstep)
+      for (int kstep = 0; kstep < 4; ++kstep) {
+        f16x8 vfh[2], vfl[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;       // hi unit of d-group dt (+ 1024 B = 4 keys on)
@@ -737,12 +745,16 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
           const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
           const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
           const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
-          const f16x8 vfh = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          const f16x8 vfl = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl, ph[kstep], oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, pl[kstep], oacc[dt], 0, 0, 0);
-          oacc[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh, ph[kstep], oacc[dt], 0, 0, 0);
+          vfh[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+          vfl[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
         }
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[0], ph[kstep], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[1], ph[kstep], oacc[1], 0, 0, 0);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], pl[kstep], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], pl[kstep], oacc[1], 0, 0, 0);
+        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], ph[kstep], oacc[0], 0, 0, 0);
+        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], ph[kstep], oacc[1], 0, 0, 0);
+      }
     }
     if constexpr (!RAGGED) {
       __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
