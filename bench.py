@@ -41,9 +41,9 @@ PMC_TRAFFIC_SOURCE = ("profiles/r3_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv
 # (1024 SIMDs x their GRBM_GUI_ACTIVE / 8 cycles), from the rocprofv3 --pmc pass of THIS code over `python bench.py --skip-probes`.  It is
 # higher than the FLOP fraction of the nominal 2.5 PFLOP/s because the chip holds ~2.0 of its 2.4 GHz under this load (DVFS).
 PMC_MFMA_UTIL = {
-    # per kernel: RESID 0.397 (144 launches x 554.8 k cycles), fc1 0.449 (76 x 761.5 k), attention 0.371 (76 x 634.2 k), qkv 0.473 (76 x 558.1 k),
-    # hooked block's 128^2 launches 0.264 (8 x 378.1 k), patch embed 0.220 (4 x 250.4 k), ln_finalize 0 (152 x 31.2 k)
-    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.408, "resid_gemm": 0.397, "fc1": 0.449, "qkv": 0.473, "attention": 0.371},
+    # per kernel: RESID 0.389 (144 launches x 566.3 k cycles), fc1 0.439 (76 x 778.6 k), attention 0.369 (76 x 637.2 k), qkv 0.465 (76 x 568.2 k),
+    # hooked block's 128^2 launches 0.255 (8 x 392.3 k), patch embed 0.219 (4 x 251.3 k), ln_finalize 0 (152 x 31.6 k)
+    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.401, "resid_gemm": 0.389, "fc1": 0.439, "qkv": 0.465, "attention": 0.369},
 }
 PMC_MFMA_UTIL_SOURCE = "profiles/r3_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-3 checkout)"
 

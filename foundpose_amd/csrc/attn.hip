@@ -15,7 +15,11 @@
 //     gfx950's hardware transpose read ds_read_b64_tr_b16 (two per fragment: lane (d = l&31, kh) receives keys
 //     kh*8 + 4r + j of column d) from an LDS image cut into 16-column blocks.  No pre-transposed V^T copy in HBM
 //     (92 MB per layer at the bench batch) and no transposing epilogue in the qkv GEMM.
-// fp32 kernel (parity mode): one thread per query, K/V rows broadcast from LDS, exact expf.
+//   * lazy rescale, decided per query: the exponent's reference moves only when a tile's maximum exceeds it by more than 8 (softmax is
+//     shift-invariant; p <= 2^8), so the accumulators are rescaled in a handful of tiles instead of nearly all of them
+// f16x3 kernel (attn_split_kernel): the same structure on split-fp16 operands, three fp16 MFMAs per product (its header).
+// fp32 kernels (exact mode): attn_f32_mfma_kernel, flash attention on v_mfma_f32_32x32x2_f32 (its header), and attn_f32_kernel
+// (one thread per query, one fma chain per score, exact expf; AttnArgs.variant = 1) as its cross-check.
 #include <type_traits>
 #include "common.hpp"
 #include "kernels.hpp"
