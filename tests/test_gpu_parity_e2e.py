@@ -121,10 +121,12 @@ def test_config1_lmo_geometry_vs_oracle_a():
     assert stats["bf16"]["templates_equal"] == 1 and stats["bf16"]["corresp_overlap"] >= 0.9
 
 
-def test_token_selection_changes_nothing_end_to_end(monkeypatch):
+@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
     """The engine's default path computes the hooked block for the sampled tokens only; with FP_TOKEN_SELECT=0 it runs the
     block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark
-    geometry (ViT-L/14-reg layer 18, 518 px) with masks of different sizes in one batch."""
+    geometry (ViT-L/14-reg layer 18, 518 px) with masks of different sizes in one batch (one of them empty: an image
+    without a selected token), in the bf16 mode and in the f16x3 mode."""
     ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, 8, 518, 1, 200, seed=5, crop_seed=1)
     del ex32
@@ -135,7 +137,7 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch):
     masks[2, 200:260, 100:400] = 1  # a bar
     masks[3] = 1                    # everything
     masks[5] = 0                    # no query point at all: the detection selects no token
-    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision=precision).to("cuda")
     eng = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
     assert exbf.supports_token_selection
     monkeypatch.setenv("FP_TOKEN_SELECT", "1")

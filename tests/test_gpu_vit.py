@@ -105,7 +105,7 @@ def test_attention_bf16_and_f32(B, N, heads):
     assert float((o16.double() - ref).abs().max()) < 3 * 2 ** -8 * float(ref.abs().max())
 
 
-@pytest.mark.parametrize("B,N,heads", [(1, 1374, 3), (2, 905, 2), (3, 77, 1), (1, 64, 2), (2, 129, 4), (1, 700, 16)])
+@pytest.mark.parametrize("B,N,heads", [(1, 1374, 3), (2, 905, 2), (3, 77, 1), (1, 64, 2), (2, 129, 4), (1, 700, 16), (2, 1, 1), (1, 5, 2), (1, 128, 1)])
 def test_attention_f32_mfma_kernel_vs_fp64_and_valu_kernel(B, N, heads):
     """The exact-fp32 mode's attention runs on the fp32 MFMA (variant 0); the thread-per-query VALU kernel (variant 1: one fma chain per
     score, keys in order) is its cross-check.  Both at fp32 rounding level of the fp64 result, ragged tails and idle waves included;
@@ -114,7 +114,8 @@ def test_attention_f32_mfma_kernel_vs_fp64_and_valu_kernel(B, N, heads):
     D = heads * 64
     g = torch.Generator().manual_seed(N * 7 + heads)
     qkv = torch.randn(B * N, 3 * D, generator=g) * 1.5
-    qkv[N - 3, D:D + 64] = qkv[5, 0:64] * 3.0   # key N-3 of image 0 / head 0 aligned with query 5
+    if N > 8:
+        qkv[N - 3, D:D + 64] = qkv[5, 0:64] * 3.0   # key N-3 of image 0 / head 0 aligned with query 5
     q, k, v = qkv.double().reshape(B, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(B * N, D)
     o_m = ops.attention(qkv.cuda(), B, N, D, heads).cpu()
