@@ -257,7 +257,7 @@ int fp_vit_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B
 int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,
                            int img_h, const float* points, const int32_t* point_img, int num_points, float* out, fp_stream_t stream);
 
-/* Query-token selection in the hooked block (bf16 model with ln_fold).  The reference runs the backbone on every token and
+/* Query-token selection in the hooked block (bf16 model with ln_fold, or f16x3 model).  The reference runs the backbone on every token and
  * then reads the feature map at the query points only (utils/dinov2_utils.py:257,304 -> utils/feature_util.py:100-131 at the
  * points of scripts/infer.py:452-466): the hooked block's OUTPUT is needed for the patch tokens under the sampling taps and
  * for no other token, while its keys and values still come from all tokens.  Three calls replace fp_vit_forward +
@@ -346,7 +346,9 @@ int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, 
 /* qkv [B*N, 3D] (q | k | v column blocks, head-major inside) -> out [B*N, D].
  * dtype: FP_F32 / FP_BF16 (+ FP_F16X3, see fp_vit_forward), optionally OR-ed with FP_ATTN_VARIANT(v) to pick a bf16 work split
  * (all bit-identical): 0 = 64 queries per wave, K/V by LDS-DMA (default), 1 = 32 queries per wave with register staging,
- * 2 = the DMA kernel with 8 waves per 256-query block. */
+ * 2 = the DMA kernel with 8 waves per 256-query block, 3 = 8 waves x 64 queries (512-query blocks).
+ * FP_F32: 0 = flash attention on the fp32 MFMA (default), 1 = one thread per query with one fma chain per score (its cross-check;
+ * the two agree to fp32 rounding, not bit for bit). */
 #define FP_ATTN_VARIANT(v) ((v) << 8)
 int fp_attention(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok,
                  int dim, int heads, int dtype, fp_stream_t stream);
