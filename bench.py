@@ -30,11 +30,11 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 # HBM-side bytes of one launch of the dominant kernel template from the rocprofv3 --pmc passes of THIS code (per the
 # guide's gfx950 corrections); keyed by (version, size, batch, precision).  Source file + commit are reported next to it.
 PMC_TRAFFIC = {
-    # gemm_bf16_kernel<RESID> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 424.0 KiB + WRITE_SIZE 266 572.6 KiB) x 1024
-    ("vitl14-reg", 518, 32, "bf16"): 820654694,
+    # gemm_bf16_kernel<RESID> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 429.9 KiB + WRITE_SIZE 266 572.1 KiB) x 1024
+    ("vitl14-reg", 518, 32, "bf16"): 820666266,
 }
 PMC_TRAFFIC_SOURCE = ("profiles/r3_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
-                      "round-3 tree, the kernel's code is unchanged since round 2: 819.7 MB there)")
+                      "final round-3 checkout; the kernel's code is unchanged since round 2: 819.7 MB there)")
 
 
 # Matrix-pipe utilisation of the ViT forward as the counters report it: sum of SQ_VALU_MFMA_BUSY_CYCLES over the bf16 step's ViT launches /
