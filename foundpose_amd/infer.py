@@ -81,6 +81,12 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         raise ValueError(f"Unknown final pose type {opts.final_pose_type}")
     if not opts.crop:
         raise NotImplementedError("crop=False (whole-image extraction) is not on the batched path")
+    # scripts/infer.py:482-485 subsamples the query points with torch.randperm when a mask yields more than max_num_queries of them
+    # (default 1 000 000: never for a crop).  The batched path keeps every point; an option value that could trigger the subsampling
+    # is refused instead of being ignored.
+    max_points = int(opts.crop_size[0] // opts.grid_cell_size) * int(opts.crop_size[1] // opts.grid_cell_size)
+    if opts.max_num_queries < max_points:
+        raise NotImplementedError(f"max_num_queries={opts.max_num_queries} could subsample the {max_points} grid points of a crop: not on the batched path")
     if extractor is None:
         extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
     bank = DeviceBank([repre])

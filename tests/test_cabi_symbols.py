@@ -55,6 +55,19 @@ def test_bank_builder_entry_points_refuse_cpu_tensors_and_bad_names():
         knn_util.KNN(k=1, metric="manhattan").fit(torch.zeros(4, 4))         # knn_util.py:61-63 in the reference
 
 
+def test_infer_driver_refuses_options_it_would_otherwise_ignore():
+    """scripts/infer.py options the batched path does not implement are refused before any GPU work: whole-image extraction, a
+    max_num_queries that could trigger the reference's random subsampling (infer.py:482-485), unknown matching / pose types."""
+    from foundpose_amd import infer
+    base = dict(version="v", repre_version="r", object_dataset="lmo")
+    for bad, exc in ((dict(crop=False), NotImplementedError), (dict(max_num_queries=500), NotImplementedError),
+                     (dict(match_template_type="sift"), ValueError), (dict(match_feat_matching_type="1nn"), ValueError),
+                     (dict(final_pose_type="refined"), ValueError)):
+        with pytest.raises(exc):
+            infer.infer_object(infer.InferOpts(**base, **bad), 1, None, [], {})
+    assert infer.load_opts({"infer_opts": dict(base, crop_size=[420, 420])}).max_num_queries == 1000000
+
+
 def test_oracle_topn_is_clamped_to_the_template_count():
     """torch.topk raises when there are fewer templates than top_n; the oracle (like the device path) returns what exists."""
     import numpy as np
