@@ -271,7 +271,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   // per wave only 2 of its 4 waves would have queries, each doing a full tile's work: the block would cost as much as a
   // full one for 37 % of the queries.  When <= 128 queries remain every wave takes ONE 32-query block instead (the QC = 1
   // instantiation of the tile loop): the same arithmetic per query, half the work per wave, the tail block ends in about
-  // half the time.  Block-uniform.
+  // half the time.  Block-uniform.  (Running the launch's LAST blocks as such half blocks, to fill the drain of the final round with
+  // twice as many blocks of half the lifetime, measured slower -- 345 / 353 / 363 us for the last 32 / 64 / 128 workgroup slots per
+  // XCD against 344 without: the half blocks stage every K / V tile for half the queries.)
   const bool short_tail = QB == 2 && qt == (NQ + QBLK - 1) / QBLK - 1 && NQ - qt * QBLK <= QBLK / 2;
   const int nqb = short_tail ? 1 : QB;
   const int q0 = qt * QBLK + wave * (32 * nqb);
