@@ -269,6 +269,22 @@ def main():
         ms_fc1 = gemm_ms(hid if arch.ffn == "mlp" else 2 * hid, arch.dim, 1 if arch.ffn == "mlp" else 6)
         ms_qkv = gemm_ms(3 * arch.dim, arch.dim, 0)
         fl = lambda n, k: 2.0 * mv * n * k     # algorithmic: valid rows only
+        # attention of one block at the step's shape (all tokens as queries; the precision's own kernel), 4 N^2 d per (image, head)
+        attn_info = None
+        if args.precision in ("bf16", "fp8", "f16x3"):
+            xq = torch.randn(M, 3 * arch.dim, device=dev)
+            if args.precision == "f16x3":
+                pk = torch.cat([ops.split16_pack(xq[:, i * arch.dim:(i + 1) * arch.dim].contiguous(), 16.0) for i in range(3)], dim=1)
+                ms_attn = time_kernel(lambda: ops.attention_split(pk, B, n_tok, arch.dim, arch.heads, 16.0, 16.0))
+            else:
+                xq16 = xq.to(torch.bfloat16)
+                ms_attn = time_kernel(lambda: ops.attention(xq16, B, n_tok, arch.dim, arch.heads))
+            attn_flops = 4.0 * B * n_tok * n_tok * arch.dim
+            attn_info = {"kernel": "attn_split_kernel (three fp16 MFMAs per product; FLOPs of the fp32 product)" if args.precision == "f16x3" else "attn_bf16_w64_kernel",
+                         "bound": "mfma", "launch_ms": round(ms_attn, 4), "achieved": round(attn_flops / (ms_attn * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(attn_flops / (ms_attn * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "flops_per_launch": attn_flops,
+                         "note": "back-to-back launches on random scores (inside the pipeline, behind the qkv GEMM, the same kernel measures 5-10 % faster: profiles/*_per_step_kernels.csv)"}
+            del xq
         ls_flops, ls_ms = fl(arch.dim, arch.dim) + fl(arch.dim, hid), ms_proj + ms_fc2
         ach = ls_flops / (ls_ms * 1e-3) / 1e12
         # executed FLOPs: the hooked block runs qkv on all tokens and everything else on the selected ones
@@ -349,6 +365,7 @@ def main():
                                                             "note": "K = D: 92 GF of matrix work against 0.54 GB of operands + fp32 residual read-modify-write + bf16 copy: "
                                                                     "this launch is bounded by HBM (floor 68 us at 8 TB/s), not by the MFMA roofline"}},
                                      "fc2": {"launch_ms": round(ms_fc2, 4), "frac": round(fl(arch.dim, hid) / (ms_fc2 * 1e-3) / 1e12 / peak_mfma, 4)}},
+            "roofline_attention": attn_info,
             "roofline_vit_end_to_end": {"bound": "mfma", "achieved": round(vit_tf, 1), "peak": peak_mfma, "unit": "TFLOP/s",
                                         "frac": round(vit_tf / peak_mfma, 4), "flops_per_detection": flops_exec,
                                         "flops_per_detection_all_tokens": vit_flops_per_crop(arch, args.size, args.layer),
