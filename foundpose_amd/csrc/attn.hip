@@ -352,6 +352,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
 #endif
     if (active) {
+      __builtin_amdgcn_iglp_opt(1);  // the compiler's MFMA / LDS interleaving strategy 1 for the tile body: +0.5 % same-box (0, 2, 3: -1...-2 %)
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
       f32x16 sacc[QC][2];
       // four independent accumulation chains (2 key halves x 2 query blocks) interleaved over the four 16-d steps (two chains, key
@@ -651,6 +652,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     const char* Vs = KV[kt & 1][1];
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
     if (active) {
+      __builtin_amdgcn_iglp_opt(1);  // as in attn_bf16_w64_kernel (+0.5...1 %)
       // ---- S^T = K Q^T: sacc[ks][r] = score(query l31, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
       f32x16 sacc[2];
 #pragma unroll

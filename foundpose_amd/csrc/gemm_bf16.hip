@@ -220,6 +220,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s * 2 * PER_KS + q, t + 1, nxt);
             }
             const int chunk = s * 4 + kh * 2;
+            __builtin_amdgcn_iglp_opt(1);  // as in the bf16 loop below (+0.5 % on the fp8 pipeline)
             i32x8 af[TM], wf[TN];
             auto frag8 = [&](const char* base, int row) {
               const i32x4 lo = __builtin_bit_cast(i32x4, read_frag(base, row, chunk));
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s2 * 2 * PER_KS + q, t + 1, nxt);
             }
             const int ch = s2 * 2 + kh;  // hi chunk of this lane's 8 k-values; the lo chunk sits 4 chunks (64 B) further
+            __builtin_amdgcn_iglp_opt(1);  // as in the bf16 loop below: +1 % on the f16x3 pipeline (strategy 0: -0.7 %)
             f16x8 ah[TM], al[TM], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
@@ -286,6 +288,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             for (int q = 0; q < PER_KS; ++q) stage_piece(ks * PER_KS + q, t + 1, nxt);
           }
           const int chunk = ks * 2 + kh;
+          // the compiler's MFMA / LDS-read interleaving strategy 1 for this scheduling region: +0.75 % on the pipeline in same-box A/B
+          // runs on two boxes (strategy 0: -0.4 %, 2 and 3: -1.3 %; its other list-scheduling strategies: 0...-1 %)
+          __builtin_amdgcn_iglp_opt(1);
           bf16x8 af[TM], wf[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
