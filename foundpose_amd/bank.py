@@ -32,6 +32,15 @@ class ObjectEntry:
     idf: torch.Tensor
     opts: TemplateDescOpts
     projectors: list
+    _unit: Optional[tuple] = None
+
+    def unit_words(self):
+        """Words scaled to unit length + their squared norms (tfidf_knn_metric="cosine": KNN.fit normalises the database,
+        knn_util.py:52-57); built on first use -- the shipped options search with "l2"."""
+        if self._unit is None:
+            wn = ops.normalize_rows(self.words, 0.0)
+            self._unit = (wn, ops.sqnorm_rows(wn))
+        return self._unit
 
 
 class DeviceBank:
@@ -80,12 +89,26 @@ class DeviceBank:
             raise ValueError("all objects of one bank must use the same number of visual words")
         d_all = torch.cat(descs, 0) if len(descs) > 1 else descs[0]
         self.descs_n = ops.normalize_rows(d_all, 1e-8)  # cosine_similarity's per-operand normalisation, once
-        # fp16 copy for the first pass of the prefiltered retrieval (fp_cosine_topk_prefiltered): candidates come from it, scores never do
-        self.descs_bf = self.descs_n.to(torch.float16).contiguous() if (self.num_words % 1024 == 0 and self.num_words <= 4096) else None
+        self._descs_f16: Optional[torch.Tensor] = None   # built on the first retrieval that takes the two-stage path (descs_f16())
         self.tpl_off = torch.tensor(offs, dtype=torch.int32, device=dev)
         self.obj_tpl_off = torch.tensor([o.tpl_base for o in self.objects] + [tpl_base], dtype=torch.int32, device=dev)
         self.num_templates_total = tpl_base
         self.max_templates = max(o.num_templates for o in self.objects)
+
+    def descs_f16(self) -> torch.Tensor:
+        """fp16 image (round to nearest even) of `descs_n` for the candidate pass of the two-stage retrieval
+        (fp_cosine_topk_prefiltered): candidates come from it, scores never do.  +50 % descriptor memory, so it is built lazily --
+        `prefilter_applies` is false for typical banks (e.g. 800 templates per object)."""
+        if self._descs_f16 is None:
+            self._descs_f16 = self.descs_n.to(torch.float16).contiguous()
+        return self._descs_f16
+
+    def prefilter_applies(self, max_det_per_obj: int, tie_mode: int) -> bool:
+        """Mirrors launch_cosine_topk_prefiltered's own gate (csrc/match.hip): the two-stage form pays off once the single-pass kernel
+        would stream more than ~250 MB of fp32 bank; word counts the fp16 pass (and, in the torch order, the exact fallback) handles."""
+        w = self.num_words
+        w_ok = w % 1024 == 0 and (w <= 2048 if tie_mode == 1 else w <= 4096)
+        return w_ok and self.max_templates * ((max_det_per_obj + 31) // 32) >= 30000
 
     @property
     def num_objects(self) -> int:

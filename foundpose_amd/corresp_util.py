@@ -7,7 +7,9 @@ device (csrc/stl_order.hpp). The batched engine defaults to the cheaper canonica
 
 `visual_words_knn_index` / `template_knn_indices` (faiss indices the reference builds per object and per
 template, scripts/infer.py:216-239) are accepted for call compatibility and not needed: the HBM bank is
-CSR-indexed by template, so no per-template index or mask scan exists.
+CSR-indexed by template, so no per-template index or mask scan exists.  What IS read from a passed
+`visual_words_knn_index` is its `.metric` ("l2" | "cosine"): the reference searches the words with whatever index the
+caller built (infer.py:218-222 builds it from template_desc_opts.tfidf_knn_metric, the default here).
 """
 
 from typing import Any, Dict, List, Optional, Tuple
@@ -60,5 +62,6 @@ def establish_correspondences(
     assert object_repre.vertices is not None
     bank = template_util.get_device_bank(object_repre)
     res = match_batch(bank, query_features.to("cuda"), query_points.to("cuda"), [query_points.shape[0]], None,
-                      top_n_templates, top_k_buddies, keep_debug=debug, tie_order=tie_order)
+                      top_n_templates, top_k_buddies, keep_debug=debug, tie_order=tie_order,
+                      word_metric=getattr(visual_words_knn_index, "metric", None))
     return res.corresp_list(0, debug=debug)

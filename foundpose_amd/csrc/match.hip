@@ -1252,7 +1252,11 @@ int launch_cosine_topk_prefiltered(const CosineArgs& a_in, int num_det, int num_
   // ~250 MB of fp32 bank to stream -- many templates, or several 32-detection passes over them (measured: 10 000 templates x 32
   // detections 39 vs 40 us, 50 000 x 128 147 vs 319 us); below that the single-pass kernel stays the faster exact answer.
   const bool worth = a.force_prefilter || (size_t)max_templates * (size_t)cdiv(max_det_per_obj, 32) >= 30000;
-  const bool ok = worth && a.bank_bf16 && a.W % 1024 == 0 && a.W <= 4096 && max_templates <= COS_PARTS * COS_LIST_CAP && n_top + 1 <= COS_NMAX && max_det_per_obj >= 1;
+  // The strict (torch) order replays tied rows from a whole row of EXACT scores, produced by cosine_fused_kernel<NQ, false> -- whose fp32
+  // path holds at most 4 chunks per k-slice (W <= 2048; launch_cosine_topk sends wider banks to the generic kernel).  So with tie_mode 1
+  // the two-stage form is taken for W <= 2048 only; W = 3072 / 4096 in the strict order run the single-pass exact path.
+  const bool w_ok = a.W % 1024 == 0 && (tie_mode == 1 ? a.W <= 2048 : a.W <= 4096);
+  const bool ok = worth && a.bank_bf16 && w_ok && max_templates <= COS_PARTS * COS_LIST_CAP && n_top + 1 <= COS_NMAX && max_det_per_obj >= 1;
   if (!ok) return launch_cosine_topk(a_in, num_det, num_obj, max_det_per_obj, max_templates, n_top, det_num_templates, out_scores, out_ids, tie_mode, st);
   const int tp = cdiv(max_templates, COS_PARTS);
   float* approx = extra_scratch;

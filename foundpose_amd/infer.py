@@ -98,16 +98,25 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         scene_id, im_id, cam = frame["scene_id"], frame["im_id"], frame["camera"]
         # number of target instances (infer.py:308-321): from the test targets when given -- frames that are not a target of
         # this object, or whose count is 0, are skipped -- otherwise the number of ground-truth annotations of the frame
+        # ground-truth annotations of this object that are sufficiently visible (infer.py:286-305): a frame that HAS annotations but
+        # none of them qualifies is skipped; a frame without annotations (sample.objects_anno is None) goes on with an empty list
+        object_annos = []
+        if frame.get("gt_annos") is not None:
+            object_annos = [a for a in frame["gt_annos"]
+                            if getattr(a, "lid", object_lid) == object_lid and not np.isnan(getattr(a, "visibilities", 1.0))
+                            and getattr(a, "visibilities", 1.0) > opts.min_visibility]
+            if len(object_annos) == 0:
+                continue
         if num_target_insts is not None:
             if (scene_id, im_id) not in num_target_insts:
                 continue
             n_target = int(num_target_insts[(scene_id, im_id)])
         else:
-            n_target = len(frame["gt_annos"]) if frame.get("gt_annos") else 1
+            n_target = len(object_annos)     # infer.py:317: no targets and no annotations -> 0 -> the frame is skipped
         if n_target == 0:
             continue
         instances = infer_pose_util.get_instances_for_pose_estimation(
-            scene_id, im_id, object_lid, opts.use_detections, detections, int(opts.num_preds_factor * n_target), frame.get("gt_annos", []),
+            scene_id, im_id, object_lid, opts.use_detections, detections, int(opts.num_preds_factor * n_target), object_annos,
             (cam.width, cam.height))
         kept = []
         for inst_j, inst in enumerate(instances):

@@ -84,6 +84,7 @@ def match_batch(
     top_k_buddies: int = 300,
     keep_debug: bool = False,
     tie_order: str = "canonical",  # "canonical": (value, lowest index);  "torch": the reference's torch.topk CPU tie order
+    word_metric: Optional[str] = None,  # metric of the visual-word search; default: each object's template_desc_opts.tfidf_knn_metric
 ) -> MatchResult:
     require_cuda(query_features, query_points)
     if tie_order not in ("canonical", "torch"):
@@ -145,9 +146,20 @@ def match_batch(
     for obj, d0, d1 in groups:
         o = bank.objects[obj]
         r0, r1 = q_off_h[d0], q_off_h[d1]
-        if o.opts.tfidf_knn_metric != "l2":
-            raise ValueError(f"Metric {o.opts.tfidf_knn_metric} is not supported on this path.")
-        w_d2, w_ids = ops.knn_l2(qf[r0:r1], o.words, o.opts.tfidf_knn_k, q_sqn[r0:r1], o.words_sqn)
+        metric = o.opts.tfidf_knn_metric if word_metric is None else word_metric
+        if metric == "l2":
+            w_d2, w_ids = ops.knn_l2(qf[r0:r1], o.words, o.opts.tfidf_knn_k, q_sqn[r0:r1], o.words_sqn)
+        elif metric == "cosine":
+            # KNN(metric="cosine") (knn_util.py:52-57, 91-100): words and queries scaled to unit length (no eps: a zero row is NaN there
+            # too), inner-product search, distance 1 - similarity.  On unit vectors |a - b|^2 = 2 - 2 a.b, so the exact-fp32 L2 tile
+            # kernel ranks identically (d^2 ascending = similarity descending) and d^2 / 2 is the cosine distance; the tf-idf kernel
+            # takes its square root like find_nearest_object_features does (template_util.py:26-27; it only matters with soft assignment).
+            words_n, words_n_sqn = o.unit_words()
+            qn = ops.normalize_rows(qf[r0:r1], 0.0)
+            w_d2, w_ids = ops.knn_l2(qn, words_n, o.opts.tfidf_knn_k, None, words_n_sqn)
+            w_d2.mul_(0.5)
+        else:
+            raise ValueError(f"Metric {metric} is not supported.")   # knn_util.py:62-63
         seg = q_off[d0:d1 + 1] if r0 == 0 else (q_off[d0:d1 + 1] - r0)
         ops.tfidf_build(w_ids, w_d2, seg, o.idf, o.opts.tfidf_soft_assign, o.opts.tfidf_soft_sigma_squared, sqrt_dists=True,
                         out=(desc[d0:d1], desc_n[d0:d1]))
@@ -159,9 +171,9 @@ def match_batch(
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
-    if getattr(bank, "descs_bf", None) is not None and os.environ.get("FP_COSINE_PREFILTER", "1") != "0":  # env: A/B switch (same outputs bit for bit)
+    if bank.prefilter_applies(max_det, tie_mode) and os.environ.get("FP_COSINE_PREFILTER", "1") != "0":  # env: A/B switch (same outputs bit for bit)
         sims = torch.empty(cosine_prefilter_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)
-        call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n), ptr(bank.descs_bf),
+        call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n), ptr(bank.descs_f16()),
              ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
     else:
         sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys

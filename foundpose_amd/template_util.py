@@ -64,7 +64,8 @@ def tfidf_matching(query_features: torch.Tensor, object_repre: repre_util.Featur
     bank = get_device_bank(object_repre)
     qf = query_features.to("cuda", torch.float32)
     pts = torch.zeros(qf.shape[0], 2, dtype=torch.float32, device="cuda")
-    res = match_batch(bank, qf, pts, [qf.shape[0]], None, top_n_templates, 1, tie_order="torch")
+    res = match_batch(bank, qf, pts, [qf.shape[0]], None, top_n_templates, 1, tie_order="torch",
+                      word_metric=getattr(visual_words_knn_index, "metric", None))
     return res.template_ids[0].to(torch.int64).to(query_features.device), res.template_scores[0].to(query_features.device)
 
 

@@ -102,8 +102,13 @@ int fp_cosine_topk(const float* desc_n, const int32_t* det_seg_off, const int32_
  * row for the replay of torch.topk's order; such rows release fp_cosine_topk's single-pass kernel and the replay behind a device-side
  * flag (both exit at once otherwise).  The three dependent launches cost ~10 us of latency each, so the two-stage form is taken only
  * when the single pass would stream more than ~250 MB (max_templates x ceil(max_det_per_obj / 32) >= 30 000; tie_mode |
- * FP_COSINE_FORCE_PREFILTER forces it); otherwise, and when num_words is not a multiple of 1024 (<= 4096), for more than 65536
- * templates per object or n_top > 7, the call IS fp_cosine_topk.  scratch: FP_COSINE_PREFILTER_SCRATCH_FLOATS(num_det, max_templates) floats. */
+ * FP_COSINE_FORCE_PREFILTER forces it); otherwise, and when num_words is not a multiple of 1024 (<= 4096 with tie_mode 0, <= 2048 with
+ * tie_mode 1: the strict order's exact fallback is the <= 2048-word single-pass kernel), for more than 65536
+ * templates per object or n_top > 7, the call IS fp_cosine_topk.  scratch: FP_COSINE_PREFILTER_SCRATCH_FLOATS(num_det, max_templates) floats.
+ * HARD PRECONDITIONS of the candidate bound (not checked; fp_cosine_topk has none of them and stays exact for any input): every row of
+ * desc_n and bank_n has L2 norm <= 1 (what fp_normalize_rows writes), and bank_n_f16 is the round-to-nearest-even fp16 image of bank_n
+ * element for element.  Unnormalised rows or any other fp16 copy void the superset guarantee -- true top-n templates can then be dropped
+ * silently.  The Python side (foundpose_amd/bank.py) builds both from the same tensor. */
 #define FP_COSINE_FORCE_PREFILTER 256
 #define FP_COSINE_PREFILTER_SCRATCH_FLOATS(num_det, max_templates) (FP_COSINE_SCRATCH_FLOATS(num_det, max_templates) + 3 * (size_t)(num_det) * (size_t)(max_templates) + 32 * (size_t)(num_det) + 16)
 int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, const int32_t* det_num_templates, int num_det, int max_det_per_obj,

@@ -258,6 +258,71 @@ def gen_extractor_stride(ref):
     print("extractor_tiny_stride7", out["fmap_l2_n1"].shape, out["pos_70x56"].shape)
 
 
+TINY0 = VitArch("tiny", dim=128, depth=3, heads=2, ffn="mlp", hidden=512, registers=0,
+                pretrain_grid=4, interp_antialias=False, interp_offset=0.1)
+
+
+def gen_extractor_noreg(ref):
+    """(e) the NON-register hub entries -- `InferOpts.extractor_name` defaults to "dinov2_vitl14" (scripts/infer.py:75; short form: layer
+    stays 9, dinov2_utils.py:62-64; hub name dinov2_utils.py:81-84).  0 register tokens (the wrapper drops 1 + 0 prefix rows,
+    dinov2_utils.py:304) and, off 518 x 518, upstream's scale-factor pos-embed interpolation with the +0.1 offset and no antialias.
+    The stand-in backbone is transformers' Dinov2Model carrying the same weights; its size-mode interpolation is replaced by the
+    REFERENCE's own `_fix_pos_enc(patch, (patch, patch))` function (dinov2_utils.py:325-360), which at stride = patch is upstream's
+    offset branch argument for argument: F.interpolate(scale_factor=((w0 + .1)/M, (h0 + .1)/M), bicubic, no antialias)."""
+    import types as _types
+    from foundpose_amd.vit_config import ARCHS
+
+    ARCHS[TINY0.name] = TINY0
+
+    def make(arch, sd, name):
+        fn = ref.dinov2_utils.DinoFeatureExtractor._fix_pos_enc(_types.SimpleNamespace(pos_embed=sd["pos_embed"]), arch.patch, (arch.patch, arch.patch))
+        base = f"dinov2_{arch.name}".replace("-", "_")
+        ref_shim.set_backbone(base, lambda pretrained=True: ref_shim.HFBackboneAdapter(sd, arch, arch.pretrain_grid * arch.patch, pos_fn=fn))
+        ex = ref.dinov2_utils.DinoFeatureExtractor(name)
+        assert ex.model.num_register_tokens == 0
+        return ex, fn
+
+    # tiny: full outputs; the native grid (no interpolation), a larger square grid, a non-square one
+    sd = synthetic.make_vit_state_dict(TINY0, seed=1234)
+    out = {"weights_seed": np.int64(1234), "image_seed": np.int64(0)}
+    for (H, W) in ((56, 56), (84, 84), (70, 42)):
+        g = torch.Generator().manual_seed(H * 1000 + W)
+        imgs = torch.rand(2, 3, H, W, generator=g)
+        for layer, norm in ((2, 1), (0, 0)):
+            ex, fn = make(TINY0, sd, f"dinov2_version=tiny_stride=14_facet=token_layer={layer}_logbin=0_norm={norm}")
+            with torch.no_grad():
+                o = ex(imgs)
+            out[f"fmap_{H}x{W}_l{layer}_n{norm}"] = t2n(o["feature_maps"]).astype(np.float32)
+            out[f"cls_{H}x{W}_l{layer}_n{norm}"] = t2n(o["cls_tokens"]).astype(np.float32)
+        out[f"pos_{H}x{W}"] = t2n(fn(torch.zeros(1, 1 + (H // 14) * (W // 14), TINY0.dim), H, W)).astype(np.float32)
+    assert out["fmap_70x42_l2_n1"].shape == (2, TINY0.dim, 5, 3)
+    np.savez_compressed(os.path.join(OUT, "extractor_tiny_noreg.npz"), **out)
+    print("extractor_tiny_noreg", out["fmap_84x84_l2_n1"].shape, out["pos_70x42"].shape)
+
+    # the hub architectures through their SHORT names (layer 9) and one long name; 518 (table as is) and 420 (LM-O crop size)
+    cases = (("vitl14", "dinov2_vitl14", 518, 8, 3), ("vitl14", "dinov2_vitl14", 420, 8, 2),
+             ("vits14", "dinov2_vits14", 420, 4, 2), ("vitb14", "dinov2_vitb14", 518, 8, 3),
+             ("vitb14", "dinov2_version=vitb14_stride=14_facet=token_layer=11_norm=1", 420, 8, 2))
+    for version, name, S, cs, ss in cases:
+        arch = ARCHS[version]
+        sd = synthetic.make_vit_state_dict(arch, seed=1234)
+        imgs = synthetic.make_crops(1, S, seed=5)
+        ex, _ = make(arch, sd, name)
+        assert ex.layer == (11 if "layer=11" in name else 9)
+        with torch.no_grad():
+            o = ex(imgs)
+        fm = t2n(o["feature_maps"]).astype(np.float32)
+        assert fm.shape == (1, arch.dim, S // 14, S // 14)
+        np.savez_compressed(
+            os.path.join(OUT, f"extractor_{version}_{S}.npz"),
+            weights_seed=np.int64(1234), image_seed=np.int64(5), layer=np.int64(ex.layer), name=np.array(name),
+            input_checksum=checksum(imgs, sd[f"blocks.{ex.layer}.attn.qkv.weight"], sd["pos_embed"]),
+            fmap_sub=fm[:, ::cs, ::ss, ::ss], cls=t2n(o["cls_tokens"]).astype(np.float32), sub=np.array([cs, ss]),
+            fmap_mean=np.float64(fm.mean()), fmap_abs_mean=np.float64(np.abs(fm).mean()),
+        )
+        print(f"extractor_{version}_{S}", fm.shape, float(np.abs(fm).mean()))
+
+
 # ------------------------------------------------------------------ composite hot section
 def gen_hot_section(ref):
     """infer.py:468-542 driven through the reference's functions on a tiny extractor."""
@@ -513,6 +578,42 @@ def gen_wrappers(ref):
 
 
 # ------------------------------------------------------------------ result formats
+def gen_wrappers_cosine(ref):
+    """`tfidf_knn_metric = "cosine"` for the visual-word search (scripts/infer.py:218-222 -> knn_util.py:52-57, 91-100): the reference's
+    find_nearest_object_features / calc_tfidf / tfidf_matching / establish_correspondences over a cosine word index, on the representation
+    of gen_wrappers (read back from tests/golden/repre_ref by the reference's loader).  The bank side of the descriptors is always built
+    with "l2" (template_util.py:105), so the same repre.pth serves."""
+    c = WRAP
+    _, _, pts, feats, _, _ = build_wrapper_inputs()
+    loaded = ref.repre_util.load_object_repre(os.path.join(OUT, "repre_ref"), tensor_device="cpu")
+    vw = ref.knn_util.KNN(k=3, metric="cosine")
+    vw.fit(loaded.feat_cluster_centroids)
+    word_ids, word_dists = ref.template_util.find_nearest_object_features(query_features=feats, knn_index=vw)
+    tfidf_hard = ref.template_util.calc_tfidf(word_ids, word_dists, loaded.feat_cluster_idfs, soft_assignment=False, soft_sigma_squared=10.0)
+    tfidf_soft = ref.template_util.calc_tfidf(word_ids, word_dists, loaded.feat_cluster_idfs, soft_assignment=True, soft_sigma_squared=10.0)
+    tm_ids, tm_scores = ref.template_util.tfidf_matching(feats, loaded, 5, vw)
+    tpl_idx = []
+    for t in range(c["T"]):
+        idx = ref.knn_util.KNN(k=1, metric="l2")
+        idx.fit(loaded.feat_vectors[torch.nonzero(loaded.feat_to_template_ids == t).flatten()])
+        tpl_idx.append(idx)
+    corresp = ref.corresp_util.establish_correspondences(
+        query_points=pts, query_features=feats, object_repre=loaded, template_matching_type="tfidf", feat_matching_type="cyclic_buddies",
+        top_n_templates=5, top_k_buddies=300, visual_words_knn_index=vw, template_knn_indices=tpl_idx, debug=True)
+    l2 = ref.knn_util.KNN(k=3, metric="l2")
+    l2.fit(loaded.feat_cluster_centroids)
+    l2_ids = ref.template_util.find_nearest_object_features(query_features=feats, knn_index=l2)[0]
+    out = {"word_ids": t2n(word_ids).astype(np.int64), "word_dists": t2n(word_dists), "tfidf_hard": t2n(tfidf_hard), "tfidf_soft": t2n(tfidf_soft),
+           "tm_ids": t2n(tm_ids).astype(np.int64), "tm_scores": t2n(tm_scores), "l2_word_ids": t2n(l2_ids).astype(np.int64),
+           "template_ids": np.array([int(x["template_id"]) for x in corresp], np.int64),
+           "template_scores": np.array([float(x["template_score"]) for x in corresp], np.float32)}
+    for i, x in enumerate(corresp):
+        out[f"coord_2d_ids_{i}"] = t2n(x["coord_2d_ids"]).astype(np.int64)
+        out[f"nn_vertex_ids_{i}"] = t2n(x["nn_vertex_ids"]).astype(np.int64)
+    np.savez_compressed(os.path.join(OUT, "wrappers_cosine.npz"), **out)
+    print("wrappers_cosine.npz templates", out["tm_ids"], "word rows differing from l2:", int((out["word_ids"] != out["l2_word_ids"]).any(1).sum()), "of", len(out["word_ids"]))
+
+
 def results_inputs():
     """Seeded stand-ins for what the driver hands the evaluator: per object a few instances, each with a pose in the crop camera's
     world, the original and the crop camera, the per-stage times and a correspondence set (with repeated query ids: the score is
@@ -611,10 +712,12 @@ def main():
     gen_extractor(ref)
     gen_extractor_420(ref)
     gen_extractor_stride(ref)
+    gen_extractor_noreg(ref)
     gen_hot_section(ref)
     gen_crop(ref)
     gen_lift(ref)
     gen_wrappers(ref)
+    gen_wrappers_cosine(ref)
     gen_results(ref)
 
 

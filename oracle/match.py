@@ -38,7 +38,21 @@ def knn_l2(queries: np.ndarray, db: np.ndarray, k: int) -> Tuple[np.ndarray, np.
     return clib.l2_knn(queries, db, k)
 
 
-def nearest_words(query_features: np.ndarray, centroids: np.ndarray, k: int):
+def unit_rows(x: np.ndarray) -> np.ndarray:
+    """x / ||x|| without an eps (KNN's cosine metric, knn_util.py:55, 94), ||x||^2 as the k-ascending fmaf chain."""
+    with np.errstate(invalid="ignore", divide="ignore"):
+        return (x / np.sqrt(clib.sqnorm(x)).astype(np.float32)[:, None]).astype(np.float32)
+
+
+def nearest_words(query_features: np.ndarray, centroids: np.ndarray, k: int, metric: str = "l2"):
+    """find_nearest_object_features over KNN(metric).  "cosine" (knn_util.py:52-57, 91-100): unit rows on both sides, inner-product
+    search, distance 1 - similarity -- restated as the L2 search on the unit rows (same ranking; 1 - a.b = |a - b|^2 / 2),
+    the form the device computes."""
+    if metric == "cosine":
+        d2, ids = knn_l2(unit_rows(query_features), unit_rows(centroids), k)
+        return ids, np.sqrt(d2 * np.float32(0.5))
+    if metric != "l2":
+        raise ValueError(f"Metric {metric} is not supported.")
     d2, ids = knn_l2(query_features, centroids, k)
     return ids, np.sqrt(d2)
 
@@ -103,7 +117,7 @@ def cosine_scores(template_descs: np.ndarray, query_tfidf: np.ndarray) -> np.nda
 
 def tfidf_matching(query_features, repre: Dict, top_n: int, topk_mode: str = "torch"):
     opts = repre["template_desc_opts"]
-    ids, dists = nearest_words(query_features, repre["feat_cluster_centroids"], opts["tfidf_knn_k"])
+    ids, dists = nearest_words(query_features, repre["feat_cluster_centroids"], opts["tfidf_knn_k"], opts.get("tfidf_knn_metric", "l2"))
     q_tfidf = calc_tfidf(ids, dists, repre["feat_cluster_idfs"], opts["tfidf_soft_assign"], opts["tfidf_soft_sigma_squared"])
     sims = cosine_scores(repre["template_descs"], q_tfidf)
     # (torch.topk raises when there are fewer templates than top_n, template_util.py:172; the device path returns the

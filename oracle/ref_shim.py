@@ -127,29 +127,33 @@ class HFBackboneAdapter(torch.nn.Module):
     """Exposes the attribute surface the reference wrapper touches (dinov2_utils.py:97-98,
     140, 206-211, 257, 304) on top of transformers' Dinov2WithRegistersModel."""
 
-    def __init__(self, sd, arch, image_size: int):
+    def __init__(self, sd, arch, image_size: int, pos_fn=None):
+        """pos_fn(tokens, height, width): replaces the stand-in's position-encoding interpolation.  The non-register hub entries
+        (`dinov2_vit{s,b,l,g}14`) interpolate in scale-factor mode with the +0.1 offset and no antialias -- transformers' Dinov2Model
+        interpolates by size -- so for those the fixtures install the REFERENCE's own `_fix_pos_enc(patch, (patch, patch))`
+        (dinov2_utils.py:325-360), which is that call argument for argument."""
         super().__init__()
-        from transformers import Dinov2WithRegistersConfig, Dinov2WithRegistersModel
+        from transformers import Dinov2Config, Dinov2Model, Dinov2WithRegistersConfig, Dinov2WithRegistersModel
 
-        assert arch.registers > 0, "HF cross-check model is the with-registers variant"
-        cfg = Dinov2WithRegistersConfig(
-            hidden_size=arch.dim, num_hidden_layers=arch.depth, num_attention_heads=arch.heads,
-            mlp_ratio=4, image_size=image_size, patch_size=arch.patch,
-            num_register_tokens=arch.registers, layer_norm_eps=1e-6,
-            use_swiglu_ffn=(arch.ffn == "swiglu"), hidden_act="gelu",
-        )
-        hf = Dinov2WithRegistersModel(cfg).eval()
+        common = dict(hidden_size=arch.dim, num_hidden_layers=arch.depth, num_attention_heads=arch.heads,
+                      mlp_ratio=4, image_size=image_size, patch_size=arch.patch, layer_norm_eps=1e-6,
+                      use_swiglu_ffn=(arch.ffn == "swiglu"), hidden_act="gelu")
+        if arch.registers > 0:
+            hf = Dinov2WithRegistersModel(Dinov2WithRegistersConfig(num_register_tokens=arch.registers, **common)).eval()
+        else:
+            hf = Dinov2Model(Dinov2Config(**common)).eval()
         D = arch.dim
         m = {
             "embeddings.cls_token": sd["cls_token"],
             "embeddings.mask_token": sd["mask_token"],
-            "embeddings.register_tokens": sd["register_tokens"],
             "embeddings.position_embeddings": sd["pos_embed"],
             "embeddings.patch_embeddings.projection.weight": sd["patch_embed.proj.weight"],
             "embeddings.patch_embeddings.projection.bias": sd["patch_embed.proj.bias"],
             "layernorm.weight": sd["norm.weight"],
             "layernorm.bias": sd["norm.bias"],
         }
+        if arch.registers > 0:
+            m["embeddings.register_tokens"] = sd["register_tokens"]
         for i in range(arch.depth):
             s, t = f"blocks.{i}.", f"encoder.layer.{i}."
             qw, qb = sd[s + "attn.qkv.weight"], sd[s + "attn.qkv.bias"]
@@ -181,6 +185,8 @@ class HFBackboneAdapter(torch.nn.Module):
             att.qkv = (lambda x, a=inner: torch.cat([a.query(x), a.key(x), a.value(x)], dim=-1))
             att.num_heads = arch.heads
             layer.attn = att
+        if pos_fn is not None:
+            hf.embeddings.interpolate_pos_encoding = lambda emb, height, width: pos_fn(emb, height, width)
         self.hf = hf
         self.blocks = hf.encoder.layer
         self.norm = hf.layernorm

@@ -5,7 +5,7 @@ import os
 import numpy as np
 import torch
 
-from oracle.make_golden import MATCH_CASES, TINY, build_match_inputs, checksum  # noqa: F401
+from oracle.make_golden import MATCH_CASES, TINY, TINY0, build_match_inputs, checksum  # noqa: F401
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
@@ -34,3 +34,20 @@ def match_case_inputs(name):
                                "tfidf_soft_assign": bool(c["soft"]), "tfidf_soft_sigma_squared": 10.0},
     }
     return c, g, repre, pts.numpy(), feats.numpy()
+
+
+NOREG_CASES = (("vitl14", 518), ("vitl14", 420), ("vits14", 420), ("vitb14", 518), ("vitb14", 420))
+
+
+def noreg_case(version, S):
+    """Inputs of tests/golden/extractor_<version>_<S>.npz (the non-register hub entries, scripts/infer.py:75) -> (g, name, spec, sd, imgs)."""
+    from foundpose_amd import synthetic
+    from foundpose_amd.vit_config import parse_extractor_name
+    g = load_golden(f"extractor_{version}_{S}")
+    name = str(g["name"])
+    spec = parse_extractor_name(name)
+    assert spec.version == version and spec.layer == int(g["layer"]) and spec.arch.registers == 0
+    sd = synthetic.make_vit_state_dict(spec.arch, seed=int(g["weights_seed"]))
+    imgs = synthetic.make_crops(1, S, seed=int(g["image_seed"]))
+    assert np.isclose(checksum(imgs, sd[f"blocks.{spec.layer}.attn.qkv.weight"], sd["pos_embed"]), g["input_checksum"], atol=1e-6)
+    return g, name, spec, sd, imgs

@@ -742,6 +742,32 @@ def test_prefiltered_retrieval_adversarial_rows(tie_mode):
     assert torch.equal(a[1], b[1]) and torch.equal(a[0].isnan(), b[0].isnan()) and torch.equal(a[0].nan_to_num(7.0), b[0].nan_to_num(7.0))
 
 
+@pytest.mark.parametrize("W", [3072, 4096])
+def test_prefiltered_retrieval_wide_banks_with_ties_strict_order(W):
+    """with 3072 / 4096 words the strict order's exact fallback used to be the <= 2048-word single-pass kernel (garbage
+    scores for any row with a tie among its best n + 1).  Rows WITH ties -- duplicated templates at the top, a tie across the cut, all
+    templates identical -- in the torch order and in the canonical one, forced two-stage call vs fp_cosine_topk, and vs torch.topk."""
+    from foundpose_amd import ops
+    rng = np.random.default_rng(W)
+    T = 1500
+    base = (rng.random((T, W)) * (rng.random((T, W)) < 0.03)).astype(np.float32)
+    base[:, 0] += 1e-3
+    q = (rng.random(W) * (rng.random(W) < 0.1)).astype(np.float32) + 1e-4
+    order = np.argsort(-(base / np.linalg.norm(base, axis=1, keepdims=True)) @ (q / np.linalg.norm(q)))
+    bank_a = base.copy(); bank_a[order[1]] = bank_a[order[0]]; bank_a[order[3]] = bank_a[order[2]]
+    bank_b = base.copy(); bank_b[order[5]] = bank_b[order[4]]
+    bank_c = np.repeat(base[:1], T, 0)
+    seg, off, nt = cu(np.array([0, 1], np.int32)), cu(np.array([0, T], np.int32)), cu(np.full(1, T, np.int32))
+    for name, bk in (("a", bank_a), ("b", bank_b), ("c", bank_c)):
+        bank_n, q_n = ops.normalize_rows(cu(bk)), ops.normalize_rows(cu(q[None]))
+        for tie_mode in (0, 1):
+            a, b = _both_retrievals(q_n, bank_n, seg, off, nt, 5, tie_mode, 1)
+            _assert_same(a, b, f"W={W} case {name} tie_mode={tie_mode}")
+        sc, ids, sims = _cosine_topk(q_n, bank_n, 5, tie_mode=1)
+        tv, ti = torch.topk(sims[:T].cpu(), 5, sorted=True)
+        assert b[1][0].cpu().tolist() == ti.tolist() and torch.equal(b[0][0].cpu(), tv), (W, name)
+
+
 def test_prefiltered_retrieval_multi_object_groups():
     """Three objects with different template counts, detections grouped by object (one of them with no detection): the prefiltered call
     serves every (object, chunk) pair like the single-pass call."""

@@ -12,7 +12,7 @@ import torch
 from foundpose_amd import _lib, synthetic
 from foundpose_amd.vit_config import ARCHS
 from oracle import vit as ov
-from tests.helpers import TINY, load_golden
+from tests.helpers import NOREG_CASES, TINY, TINY0, load_golden, noreg_case
 
 pytestmark = pytest.mark.gpu
 
@@ -182,7 +182,7 @@ def test_extractor_key_query_value_facets_vs_reference_wrapper_fixture(precision
 
 def _extractor(arch, name, seed, precision):
     from foundpose_amd import feature_util
-    ex = feature_util.make_feature_extractor(name, seed=seed, precision=precision, arch=arch if arch is TINY else None)
+    ex = feature_util.make_feature_extractor(name, seed=seed, precision=precision, arch=arch if arch in (TINY, TINY0) else None)
     return ex.to("cuda")
 
 
@@ -238,6 +238,42 @@ def test_extractor_vits14reg_420_vs_reference_wrapper_fixture(precision, tol):
     assert fm.shape == (1, 384, 30, 30)
     scale = np.abs(g["fmap_sub"]).max()
     np.testing.assert_allclose(fm[:, ::4, ::2, ::2], g["fmap_sub"], rtol=0, atol=tol * scale)
+    np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 3e-5), ("f16x3", 3e-5), ("bf16", 6e-2)])
+def test_extractor_tiny_noreg_vs_reference_wrapper_fixture(precision, tol):
+    """The NON-register layout (prefix of one row, N = 1 + Np) and the non-register hub entries' pos-embed interpolation (scale-factor
+    mode, +0.1 offset, no antialias) on the native, a larger square and a non-square grid: vs the reference wrapper over the
+    non-register stand-in backbone (oracle/make_golden.py::gen_extractor_noreg)."""
+    g = load_golden("extractor_tiny_noreg")
+    for (H, W) in ((56, 56), (84, 84), (70, 42)):
+        imgs = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H * 1000 + W)).cuda()
+        for layer, norm in ((2, 1), (0, 0)):
+            ex = _extractor(TINY0, f"dinov2_version=tiny_stride=14_facet=token_layer={layer}_logbin=0_norm={norm}", int(g["weights_seed"]), precision)
+            assert ex.arch.registers == 0
+            o = ex(imgs)
+            ref = g[f"fmap_{H}x{W}_l{layer}_n{norm}"]
+            assert o["feature_maps"].shape == ref.shape
+            np.testing.assert_allclose(o["feature_maps"].cpu().numpy(), ref, rtol=0, atol=tol * np.abs(ref).max())
+            np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g[f"cls_{H}x{W}_l{layer}_n{norm}"], rtol=0, atol=tol * np.abs(ref).max())
+
+
+@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("f16x3", 5e-5), ("bf16", 8e-2)])
+@pytest.mark.parametrize("version,S", NOREG_CASES)
+def test_extractor_noreg_hub_archs_vs_reference_wrapper_fixture(version, S, precision, tol):
+    """The reference's DEFAULT backbone family (InferOpts.extractor_name = "dinov2_vitl14", scripts/infer.py:75: no register tokens,
+    short form -> layer 9, dinov2_utils.py:62-64) and its ViT-S / ViT-B siblings (D = 768 / 12 heads) at 518 (N = 1370) and at the
+    LM-O crop size 420 (N = 901, interpolated table), against the reference wrapper's own output."""
+    g, name, spec, sd, imgs = noreg_case(version, S)
+    ex = _extractor(None, name, int(g["weights_seed"]), precision)
+    assert ex.arch.registers == 0 and ex.layer == int(g["layer"]) and ex.model_base_name == f"dinov2_{version}"
+    o = ex(imgs.cuda())
+    fm = o["feature_maps"].cpu().numpy()
+    cs, ss = (int(v) for v in g["sub"])
+    assert fm.shape == (1, spec.arch.dim, S // 14, S // 14)
+    scale = np.abs(g["fmap_sub"]).max()
+    np.testing.assert_allclose(fm[:, ::cs, ::ss, ::ss], g["fmap_sub"], rtol=0, atol=tol * scale)
     np.testing.assert_allclose(o["cls_tokens"].cpu().numpy(), g["cls"], rtol=0, atol=tol * scale)
 
 

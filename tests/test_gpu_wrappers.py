@@ -68,6 +68,42 @@ def test_knn_cosine_metric(case):
     np.testing.assert_allclose(d.numpy(), g["cos_dists"], rtol=0, atol=3e-6)
 
 
+def test_cosine_word_metric_through_the_drop_in_functions(case):
+    """tfidf_knn_metric = "cosine" (scripts/infer.py:218-222 -> knn_util.py:52-57, 91-100) through find_nearest_object_features,
+    tfidf_matching and establish_correspondences (metric taken from the passed word index, as the reference does, and from
+    template_desc_opts, as infer.py builds that index), and through the batched match_batch: vs the reference's own run over a cosine
+    word index (tests/golden/wrappers_cosine.npz).  26 of the 30 query rows pick different words than with "l2"."""
+    from foundpose_amd.matching import match_batch
+    gw, repre, pts, feats, _ = case
+    g = load_golden("wrappers_cosine")
+    vw = knn_util.KNN(k=3, metric="cosine")
+    vw.fit(repre.feat_cluster_centroids)
+    ids, dists = template_util.find_nearest_object_features(query_features=feats, knn_index=vw)
+    assert np.array_equal(ids.numpy(), g["word_ids"]) and (g["word_ids"] != g["l2_word_ids"]).any()
+    np.testing.assert_allclose(dists.numpy(), g["word_dists"], rtol=0, atol=2e-4)
+    ids_t, scores_t = template_util.tfidf_matching(feats, repre, 5, vw)
+    assert ids_t.tolist() == g["tm_ids"].tolist() != gw["tm_ids"].tolist()
+    np.testing.assert_allclose(scores_t.numpy(), g["tm_scores"], rtol=0, atol=2e-6)
+    cos_repre = repre_util.load_object_repre(os.path.join(GOLDEN, "repre_ref"))
+    cos_repre.template_desc_opts = cos_repre.template_desc_opts._replace(tfidf_knn_metric="cosine")
+    for got in (corresp_util.establish_correspondences(pts, feats, repre, "tfidf", "cyclic_buddies", 5, 300, visual_words_knn_index=vw),
+                corresp_util.establish_correspondences(pts, feats, cos_repre, "tfidf", "cyclic_buddies", 5, 300)):
+        assert [int(c["template_id"]) for c in got] == g["template_ids"].tolist()
+        np.testing.assert_allclose([float(c["template_score"]) for c in got], g["template_scores"], rtol=0, atol=2e-6)
+        for i, c in enumerate(got):
+            assert np.array_equal(c["coord_2d_ids"].cpu().numpy(), g[f"coord_2d_ids_{i}"])
+            assert np.array_equal(c["nn_vertex_ids"].cpu().numpy(), g[f"nn_vertex_ids_{i}"])
+    # batched: three detections of the same object in one call, soft assignment included (debug tensors carry the tf-idf rows)
+    bank = template_util.get_device_bank(cos_repre)
+    qf, qp = torch.cat([feats, feats[:11], feats]).cuda(), torch.cat([pts, pts[:11], pts]).cuda()
+    res = match_batch(bank, qf, qp, [len(feats), 11, len(feats)], None, 5, 300, keep_debug=True, tie_order="torch")
+    assert res.template_ids[0].tolist() == res.template_ids[2].tolist() == g["template_ids"].tolist()
+    np.testing.assert_allclose(res.query_tfidf[0].cpu().numpy(), g["tfidf_hard"], rtol=0, atol=1e-7)
+    assert np.array_equal(res.word_ids[:len(feats)].cpu().numpy(), g["word_ids"])
+    with pytest.raises(ValueError, match="not supported"):
+        match_batch(bank, qf, qp, [len(feats), 11, len(feats)], None, 5, 300, word_metric="dot")
+
+
 def test_projector_from_reference_tensordict(case):
     g, repre, pts, feats, raw_query = case
     got = projector_util.project_features(raw_query.cuda(), repre.feat_raw_projectors)

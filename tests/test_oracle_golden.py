@@ -58,3 +58,31 @@ def test_topk_torch_emulation_on_ties():
         tv, ti = torch.topk(torch.from_numpy(-v), k, sorted=True)
         ov, oi = clib.topk_torch(-v, k, True)
         assert np.array_equal(ti.numpy(), oi)
+
+
+def test_cosine_word_metric_matches_reference():
+    """tfidf_knn_metric = "cosine" (scripts/infer.py:218-222 -> knn_util.py:52-57, 91-100): the oracle's cosine word search, tf-idf and
+    the whole establish_correspondences vs the reference run over a cosine word index (tests/golden/wrappers_cosine.npz)."""
+    import os
+    from foundpose_amd import repre_util
+    from oracle.make_golden import build_wrapper_inputs
+    from tests.helpers import GOLDEN
+    g = load_golden("wrappers_cosine")
+    r = repre_util.load_object_repre(os.path.join(GOLDEN, "repre_ref"), tensor_device="cpu")
+    _, _, pts, feats, _, _ = build_wrapper_inputs()
+    ids, dists = om.nearest_words(feats.numpy(), r.feat_cluster_centroids.numpy(), 3, "cosine")
+    assert np.array_equal(ids, g["word_ids"]) and (g["word_ids"] != g["l2_word_ids"]).any()
+    np.testing.assert_allclose(dists, g["word_dists"], rtol=0, atol=2e-4)   # sqrt(1 - a.b) near 0.3: the 1-ulp difference of 1 - sim is amplified by the root
+    np.testing.assert_allclose(om.calc_tfidf(ids, dists, r.feat_cluster_idfs.numpy(), False, 10.0), g["tfidf_hard"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(om.calc_tfidf(ids, dists, r.feat_cluster_idfs.numpy(), True, 10.0), g["tfidf_soft"], rtol=0, atol=1e-6)
+    repre = {"vertices": r.vertices.numpy(), "feat_vectors": r.feat_vectors.numpy(), "feat_to_template_ids": r.feat_to_template_ids.numpy(),
+             "feat_cluster_centroids": r.feat_cluster_centroids.numpy(), "feat_cluster_idfs": r.feat_cluster_idfs.numpy(),
+             "template_descs": r.template_descs.numpy(),
+             "template_desc_opts": {"tfidf_knn_metric": "cosine", "tfidf_knn_k": 3, "tfidf_soft_assign": False, "tfidf_soft_sigma_squared": 10.0}}
+    out = om.establish_correspondences(pts.numpy(), feats.numpy(), repre, 5, 300, "torch")
+    assert [o["template_id"] for o in out] == g["template_ids"].tolist() == g["tm_ids"].tolist()
+    np.testing.assert_allclose([o["template_score"] for o in out], g["template_scores"], rtol=0, atol=2e-6)
+    for i, o in enumerate(out):
+        assert np.array_equal(o["coord_2d_ids"], g[f"coord_2d_ids_{i}"]) and np.array_equal(o["nn_vertex_ids"], g[f"nn_vertex_ids_{i}"])
+    with pytest.raises(ValueError, match="not supported"):
+        om.nearest_words(feats.numpy(), r.feat_cluster_centroids.numpy(), 3, "dot")

@@ -9,7 +9,7 @@ from foundpose_amd import synthetic
 from foundpose_amd.vit_config import ARCHS, parse_extractor_name
 from oracle import match as om
 from oracle import vit as ov
-from tests.helpers import TINY, checksum, load_golden
+from tests.helpers import NOREG_CASES, TINY, TINY0, checksum, load_golden, noreg_case
 
 
 def test_extractor_tiny_matches_reference_wrapper():
@@ -67,6 +67,35 @@ def test_extractor_stride7_matches_reference_pieces():
         assert o["feature_maps"].shape == (2, TINY.dim, 7, 7)
         np.testing.assert_allclose(o["feature_maps"].numpy(), g[f"fmap_l{layer}_n{norm}"], rtol=0, atol=2e-5)
         np.testing.assert_allclose(o["cls_tokens"].numpy(), g[f"cls_l{layer}_n{norm}"], rtol=0, atol=2e-5)
+
+
+def test_extractor_tiny_noreg_matches_reference_wrapper():
+    """0 register tokens + the scale-factor / offset-0.1 / no-antialias pos-embed interpolation of the non-register hub entries:
+    the oracle vs the reference wrapper over the non-register stand-in (oracle/make_golden.py::gen_extractor_noreg)."""
+    g = load_golden("extractor_tiny_noreg")
+    sd = synthetic.make_vit_state_dict(TINY0, seed=int(g["weights_seed"]))
+    assert "register_tokens" not in sd
+    for (H, W) in ((56, 56), (84, 84), (70, 42)):
+        np.testing.assert_allclose(ov.interpolate_pos_embed(sd["pos_embed"], TINY0, H // 14, W // 14).numpy(), g[f"pos_{H}x{W}"], rtol=0, atol=1e-6)
+        imgs = torch.rand(2, 3, H, W, generator=torch.Generator().manual_seed(H * 1000 + W))
+        for layer, norm in ((2, 1), (0, 0)):
+            o = ov.extractor_forward(sd, TINY0, imgs, layer, bool(norm))
+            np.testing.assert_allclose(o["feature_maps"].numpy(), g[f"fmap_{H}x{W}_l{layer}_n{norm}"], rtol=0, atol=2e-5)
+            np.testing.assert_allclose(o["cls_tokens"].numpy(), g[f"cls_{H}x{W}_l{layer}_n{norm}"], rtol=0, atol=2e-5)
+
+
+@pytest.mark.parametrize("version,S", NOREG_CASES)
+def test_extractor_noreg_hub_archs_match_reference_wrapper(version, S):
+    """`dinov2_vitl14` (InferOpts' default, scripts/infer.py:75; short form -> layer 9), `dinov2_vits14`, `dinov2_vitb14` (short and long
+    form) at 518 and 420: the oracle vs the reference wrapper's fixture."""
+    g, name, spec, sd, imgs = noreg_case(version, S)
+    o = ov.extractor_forward(sd, spec.arch, imgs, spec.layer, spec.apply_norm)
+    fm = o["feature_maps"].numpy()
+    cs, ss = (int(v) for v in g["sub"])
+    assert fm.shape == (1, spec.arch.dim, S // 14, S // 14)
+    np.testing.assert_allclose(fm[:, ::cs, ::ss, ::ss], g["fmap_sub"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(o["cls_tokens"].numpy(), g["cls"], rtol=0, atol=5e-5)
+    assert abs(float(fm.mean()) - float(g["fmap_mean"])) < 1e-5
 
 
 def test_name_grammar_defaults():
