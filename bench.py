@@ -104,7 +104,7 @@ def main():
                                                                 "launch the counters see then belongs to a step of the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the fp32-mode agreement pass (the oracle comparison rides on the cpu baseline)")
-    ap.add_argument("--cpu-detections", type=int, default=3)
+    ap.add_argument("--cpu-detections", type=int, default=5, help="detections of the CPU baseline sample (BASELINE.md section 2: median of >= 5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -177,16 +177,48 @@ def main():
         el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            el = float(t.item())
+            every = torch.empty(world, dtype=torch.float64, device=t.device)
+            dist.all_gather_into_tensor(every, t)          # every rank's own clock over the same K steps (between the same two barriers)
+            per_rank_s[:] = every.cpu().tolist()
+            el = float(every.max().item())                  # the contract's MAX over ranks
+        else:
+            per_rank_s[:] = [el]
         return el, out
+
+    per_rank_s = []
+
+    def gather_ms(steps=5):
+        """The exchange step alone: HIP events around gather_records (RCCL all-gather over xGMI) on `steps` extra, untimed steps;
+        -> mean ms on this rank.  Diagnoses a scaling curve: value(N) / (N value(1)) falls short either because a rank is slow
+        (per_rank_ms_per_step spreads) or because the gather is (gather_ms grows with N)."""
+        tot = 0.0
+        for _ in range(steps):
+            res = eng.infer_batch(images, masks, det_obj)
+            rec = fe.pack_result(res)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fe.gather_records(rec, world)
+            e1.record()
+            e1.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / steps
 
     for _ in range(args.warmup):
         step()
     elapsed, (gathered, last) = timed(eng, args.steps)
     det_per_s = world * B * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+    rank_ms = [1e3 * v / args.steps for v in per_rank_s]
+    multi = None
+    if world > 1:   # diagnosability of the scaling run (the driver computes the efficiency itself from the per-N values)
+        g_ms = torch.tensor([gather_ms()], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+        g_all = torch.empty(world, dtype=torch.float64, device=g_ms.device)
+        dist.all_gather_into_tensor(g_all, g_ms)
+        multi = {"per_rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3), "all": [round(v, 3) for v in rank_ms]},
+                 "gather_ms": {"mean_over_ranks": round(float(g_all.mean()), 4), "max_over_ranks": round(float(g_all.max()), 4),
+                               "what": "HIP events around the one all-gather of result records, 5 extra untimed steps", "record_bytes_per_rank": None}}
     if world > 1:
+        multi["gather_ms"]["record_bytes_per_rank"] = int(gathered.shape[0] // world * gathered.shape[1] * 4)
         ranks_seen = int(gathered.shape[0] // B)
         cnt = torch.ones(1, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(cnt)
@@ -194,7 +226,8 @@ def main():
     if args.skip_probes:
         if rank == 0:
             print(json.dumps({"metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank", "value": round(det_per_s, 2), "unit": "detections/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "probes": "skipped"}), flush=True)
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "probes": "skipped",
+                              **({"multi_gpu": multi} if multi is not None else {})}), flush=True)
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
@@ -350,6 +383,7 @@ def main():
                        "parallelism": f"detections sharded over {world} GPU(s), one RCCL all-gather of result records per step",
                        "tie_order": args.tie_order},
             "ranks_seen": ranks_seen,
+            **({"multi_gpu": multi} if multi is not None else {}),
             "tie_order_cost": {args.tie_order + "_ms_per_step": round(ms_per_step, 3), other + "_ms_per_step": round(ms_other, 3)},
             "roofline": {"kernel": ("gemm_bf16_kernel<RESID> (attn.proj + mlp.fc2 of one ViT block, residual update + bf16 copy + LayerNorm row sums: the largest time bucket of a step)"
                                     if fold else "gemm_bf16_kernel<LS_RESID> (attn.proj + mlp.fc2 of one ViT block: the largest time bucket of a step)"), "bound": "mfma",
@@ -416,7 +450,14 @@ def main():
             if pm is not None and args.parity_precision != "fp32":
                 pm["vs_fp32_mode"] = workload.parity_stats(lists_pm, lists32)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
-            result["cpu_baseline"], parity["vs_oracle_a"], ora = cpu_baseline(arch, args, bank, wl, lists)
+            dbg = eng.infer_batch(images, masks, det_obj, keep_debug=True)   # one untimed step that keeps the visual-word ids (stage attribution)
+            q_cnt = [int(masks[b, 7::14, 7::14].sum()) for b in range(B)]
+            q_off = [0]
+            for c_ in q_cnt:
+                q_off.append(q_off[-1] + c_)
+            dev_words = [dbg.word_ids[q_off[b]:q_off[b + 1]].cpu().numpy() for b in range(B)] if (args.size % 14 == 0 and dbg.word_ids is not None) else None
+            result["cpu_baseline"], parity["vs_oracle_a"], ora, extra = cpu_baseline(arch, args, bank, wl, lists, dev_words, want_oracle_b=args.precision in ("bf16", "fp8"))
+            parity.update(extra)
             if pm is not None:
                 pm["vs_oracle_a"] = workload.parity_stats(lists_pm[:len(ora)], ora)
         if pm is not None:  # north_star's index bar, stated as booleans next to the mode's throughput
@@ -431,7 +472,7 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(arch, args, bank, wl, gpu_lists):
+def cpu_baseline(arch, args, bank, wl, gpu_lists, dev_words=None, want_oracle_b=False):
     """The oracle's reference-equivalent CPU path on the host cores, bounded sample of the same workload; its fp32
     features then go through the oracle's pinned matching arithmetic (reference tie order) and are compared index for
     index with what the GPU produced for the same detections."""
@@ -455,26 +496,49 @@ def cpu_baseline(arch, args, bank, wl, gpu_lists):
     baseline.run_detection(sd, arch, args.layer, imgs[0], msk[0], cpu_bank)  # warm-up (thread pools, page-in)
     if time.perf_counter() - tw > 15.0:
         n = 1  # keep the default bench run within a few minutes on slow hosts
-    t0 = time.perf_counter()
-    stages, feats = {}, []
+    stages, feats, per_det = {}, [], []
     for i in range(n):
+        t0 = time.perf_counter()
         t, _, qpf = baseline.run_detection(sd, arch, args.layer, imgs[i], msk[i], cpu_bank, return_features=True)
+        per_det.append(time.perf_counter() - t0)
         feats.append(qpf)
         for k, v in t.items():
             stages[k] = stages.get(k, 0.0) + v / n
-    dt = time.perf_counter() - t0
-    base = {"value": round(n / dt, 4), "unit": "detections/s", "cores": cores, "kind": "port",
-            "sample": f"{n} detection(s) after 1 warm-up, batch of one, fp32 torch-CPU on {cores} threads, all {arch.depth} blocks run like the reference",
+    med = sorted(per_det)[len(per_det) // 2] if len(per_det) % 2 else 0.5 * (sorted(per_det)[len(per_det) // 2 - 1] + sorted(per_det)[len(per_det) // 2])
+    base = {"value": round(1.0 / med, 4), "unit": "detections/s", "cores": cores, "kind": "port",
+            "sample": f"median of {n} detection(s) after 1 warm-up (BASELINE.md section 2), batch of one, fp32 torch-CPU on {cores} threads, all {arch.depth} blocks run like the reference",
+            "s_per_detection": [round(v, 3) for v in per_det], "mean_value": round(n / sum(per_det), 4),
             "s_per_stage": {k: round(v, 4) for k, v in stages.items()}}
     # ---- oracle A on those detections: same fp32 features -> pinned matching arithmetic, the reference's tie order
     off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.bincount(cpu_bank["feat_to_template_ids"].long(), minlength=repre.template_descs.shape[0]), 0)])
     small = {"feat_cluster_centroids": cpu_bank["feat_cluster_centroids"].numpy(), "feat_cluster_idfs": cpu_bank["feat_cluster_idfs"].numpy(),
              "template_descs": cpu_bank["template_descs"].numpy(), "template_desc_opts": repre.template_desc_opts._asdict()}
     fetch = lambda tid: (cpu_bank["feat_vectors"][int(off[tid]):int(off[tid + 1])].numpy(), int(off[tid]))
-    ora = [baseline.exact_matching(qp.numpy(), qf.numpy(), small, fetch, 5, 300, "torch" if args.tie_order == "torch" else "canonical") for qp, qf in feats]
+    mode = "torch" if args.tie_order == "torch" else "canonical"
+    ora, words_a = zip(*[baseline.exact_matching(qp.numpy(), qf.numpy(), small, fetch, 5, 300, mode, return_words=True) for qp, qf in feats])
+    ora = list(ora)
     par = workload.parity_stats(gpu_lists[:n], ora)
     par["oracle"] = f"oracle A: fp32 CPU features of {n} detection(s) through oracle/match.py (pinned to the reference fixtures), tie order '{args.tie_order}'"
-    return base, par, ora
+    import numpy as np
+    srt = lambda ws: [np.sort(np.asarray(w), axis=1) for w in ws]   # hard assignment: a patch's words count as a set
+    par["by_stage"] = workload.stage_flips(gpu_lists[:n], ora, srt(dev_words[:n]) if dev_words is not None else None, srt(words_a) if dev_words is not None else None)
+    extra = {}
+    if want_oracle_b:
+        # oracle B (hard part 2): the same detections with every GEMM / attention operand rounded to bf16 at the device's cast
+        # points (oracle/vit.py quant="bf16"), fp32 accumulation, then the fp32 matching arithmetic -- what the bf16 mode is a
+        # realisation of.  The device differs from it by summation order, the folded LayerNorm's rounding points and the GELU polynomial
+        # (features within 1.5e-2, tests/test_gpu_vit.py), so on a workload WITHOUT engineered margins agreement is a rate, attributed per stage;
+        # on the margin-verified fixture it is exact (tests/test_gpu_parity_e2e.py::test_bf16_mode_index_exact_vs_oracle_b_on_fixture_with_verified_margins)
+        nb = min(n, 3)
+        pc, pm_ = (cpu_bank["pca_components"], cpu_bank["pca_mean"])
+        fb = [baseline.oracle_a_features(sd, arch, args.layer, imgs[i], msk[i], pc, pm_, quant="bf16") for i in range(nb)]
+        orb, words_b = zip(*[baseline.exact_matching(qp.numpy(), qf.numpy(), small, fetch, 5, 300, mode, return_words=True) for qp, qf in fb])
+        vb = workload.parity_stats(gpu_lists[:nb], list(orb))
+        vb["by_stage"] = workload.stage_flips(gpu_lists[:nb], list(orb), srt(dev_words[:nb]) if dev_words is not None else None, srt(words_b) if dev_words is not None else None)
+        vb["oracle"] = f"oracle B: bf16-operand CPU features (oracle/vit.py quant='bf16') of {nb} detection(s) through oracle/match.py, tie order '{args.tie_order}'"
+        vb["oracle_b_vs_oracle_a"] = workload.parity_stats(list(orb), ora[:nb])   # how far bf16 operands alone move the reference's answer
+        extra["vs_oracle_b"] = vb
+    return base, par, ora, extra
 
 
 if __name__ == "__main__":

@@ -241,6 +241,7 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
                  fp_stream_t stream) {
   FP_REQUIRE(x && weight && bias && out, "fp_layernorm: null pointer");
   LayerNormArgs a;
+  memset(&a, 0, sizeof(a));
   a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
   a.out_dtype = out_dtype; a.out_scale = 0.f; a.dim = dim; a.out_rows = out_rows;
   a.out_rows_per_img = out_rows_per_img > 0 ? out_rows_per_img : (out_rows > 0 ? out_rows : 1);
@@ -314,16 +315,21 @@ int fp_gemm_bf16_timeline(const void* A, int lda, const void* W, int ldw, int M,
 }
 #endif
 
-int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
-                const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream) {
+static int gemm_fp8_impl(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                         const float* col_scale, void* out, int ldo, int epilogue, float out_scale, int* sat, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_fp8: null pointer");
   FP_REQUIRE(out_scale >= 0.f, "fp_gemm_fp8: out_scale must be >= 0");
   GemmBf16Args a;
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = col_scale; a.out = out; a.ldo = ldo;
-  a.out_scale = out_scale;
+  a.out_scale = out_scale; a.sat = sat;
   return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
+}
+
+int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
+                const float* col_scale, void* out, int ldo, int epilogue, float out_scale, fp_stream_t stream) {
+  return gemm_fp8_impl(A, lda, W, ldw, M, N, K, M_valid, bias, col_scale, out, ldo, epilogue, out_scale, nullptr, stream);
 }
 
 int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
@@ -358,6 +364,7 @@ int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const flo
   FP_REQUIRE(x && weight && bias && out, "fp_layernorm_scaled: null pointer");
   FP_REQUIRE(out_dtype == FP_DTYPE_FP8 || out_dtype == FP_DTYPE_F16X3, "fp_layernorm_scaled: the scaled outputs are fp8 bytes and split-fp16 rows");
   LayerNormArgs a;
+  memset(&a, 0, sizeof(a));
   a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
   a.out_dtype = out_dtype; a.out_scale = out_scale; a.dim = dim; a.out_rows = out_rows;
   a.out_rows_per_img = out_rows > 0 ? out_rows : 1; a.in_rows_per_img = a.out_rows_per_img; a.in_skip = 0;
@@ -487,13 +494,15 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
                  ldq >= em * 3 * D && ldq % 8 == 0,
              "fp_vit_forward: operand row strides must cover the row and keep 16-byte alignment");
   LayerNormArgs ln;
-  ln.out_scale = 0.f;
+  memset(&ln, 0, sizeof(ln));
+  ln.sat = ws->sat;
   ln.x = ws->x; ln.ld_x = D; ln.eps = 1e-6f; ln.out = ws->y; ln.ld_out = ldy; ln.out_dtype = adt;
   ln.dim = D; ln.out_rows = Mtok; ln.out_rows_per_img = Mtok; ln.in_rows_per_img = Mtok; ln.in_skip = 0;
   AttnArgs at;
   memset(&at, 0, sizeof(at));
   at.qkv = ws->qkv; at.ld_qkv = ldq; at.out = ws->y; at.ld_out = ldy;
   at.batch = B; at.n_tok = ntok; at.dim = D; at.heads = m->heads;
+  at.sat = ws->sat;
 
   // LayerNorm folded into the GEMMs (bf16 blocks): see fp_vit_model.ln_fold.  The chain starts from the token embedding.
   const bool fold = m->ln_fold && bf && !f8;
@@ -582,7 +591,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
         memset(&g, 0, sizeof(g));
         g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
         g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
-        g.acc_scale = acc_scale; g.out_scale = out_scale;
+        g.acc_scale = acc_scale; g.out_scale = out_scale; g.sat = ws->sat;
         return gemm_split_launch(epi, g, st);
       };
       ln.out_scale = FP_SPLIT_SCALE_ACT;
@@ -622,18 +631,18 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       LayerNormArgs l8 = ln;
       l8.out = ws->a8; l8.ld_out = ld8y; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
       TRY(layernorm_launch(l8, st));
-      TRY(fp_gemm_fp8(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, stream));
+      TRY(gemm_fp8_impl(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, ws->sat, stream));
       AttnArgs a8 = at;
       a8.out = ws->a8; a8.ld_out = ld8y; a8.out_fp8_scale = b.act_scale[1];
       TRY(attn_launch(a8, FP_DTYPE_BF16, st));
-      TRY(fp_gemm_fp8(ws->a8, ld8y, b.proj_w, ld8wd, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
+      TRY(gemm_fp8_impl(ws->a8, ld8y, b.proj_w, ld8wd, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
       l8.weight = b.ln2_w; l8.bias = b.ln2_b; l8.out_scale = b.act_scale[2];
       TRY(layernorm_launch(l8, st));
       if (m->ffn_swiglu)
-        TRY(fp_gemm_fp8(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], ws->sat, stream));
       else
-        TRY(fp_gemm_fp8(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], stream));
-      TRY(fp_gemm_fp8(ws->h, ld8h, b.fc2_w, ld8wh, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], ws->sat, stream));
+      TRY(gemm_fp8_impl(ws->h, ld8h, b.fc2_w, ld8wh, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
       continue;
     }
     TRY(layernorm_launch(ln, st));
@@ -697,7 +706,7 @@ int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, in
   hipStream_t st = ST(stream);
   if (apply_norm) {
     LayerNormArgs ln;
-    ln.out_scale = 0.f;
+    memset(&ln, 0, sizeof(ln));
     ln.x = ws->x; ln.ld_x = D; ln.weight = m->norm_w; ln.bias = m->norm_b; ln.eps = 1e-6f;
     ln.out_dtype = FP_DTYPE_F32; ln.dim = D; ln.in_rows_per_img = ntok; ln.ld_out = D;
     ln.out = fmap; ln.out_rows = B * n_patches; ln.out_rows_per_img = n_patches; ln.in_skip = 1 + m->registers;

@@ -516,6 +516,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   }
 
   if (active) {
+    float sat_amax = 0.f;  // fp8 output: largest |scale * o| quantised (saturation report)
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
       if (qb >= nqb) break;
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             *reinterpret_cast<unsigned*>(o + dt * 32 + 8 * g + 4 * kh) =
-                pack_fp8x4(oacc[qb][dt][4 * g + 0] * sc, oacc[qb][dt][4 * g + 1] * sc, oacc[qb][dt][4 * g + 2] * sc, oacc[qb][dt][4 * g + 3] * sc);
+                pack_fp8x4(oacc[qb][dt][4 * g + 0] * sc, oacc[qb][dt][4 * g + 1] * sc, oacc[qb][dt][4 * g + 2] * sc, oacc[qb][dt][4 * g + 3] * sc, sat_amax);
       } else if (a.out_fp8_scale <= 0.f) {
         // A lane holds 4 consecutive d of its query per (dt, g) and lane ^ 32 the next 4: one v_permlane32_swap per register pairs
         // them into 8 consecutive d = one 16-B store per lane (8 dwordx4 stores per query block instead of 16 dwordx2: the store
@@ -552,6 +553,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           }
       }
     }
+    if (a.out_fp8_scale > 0.f) report_saturation(a.sat, 1, sat_amax, FP_E4M3_MAX);
   }
 }
 

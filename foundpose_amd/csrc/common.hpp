@@ -50,6 +50,18 @@ FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3) {
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0), clamp448(v1), 0, false);
   return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v2), clamp448(v3), w, true);
 }
+// ... and the largest magnitude that went in (saturation report: a value beyond +-448 was clamped)
+FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3, float& amax) {
+  amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));  // v_max3_f32 with |.| modifiers
+  return pack_fp8x4(v0, v1, v2, v3);
+}
+// Sticky saturation counters (fp_vit_workspace.sat, include/foundpose_amd.h): slot 0 counts split-fp16 clamps (|s x| > 65504),
+// slot 1 e4m3 clamps (|s x| > 448).  A thread keeps the running maximum of what it packed (one VALU op per pair) and reports
+// once at the end of the kernel; an atomic is issued only when something actually clamped.
+constexpr float FP_F16_MAX = 65504.f, FP_E4M3_MAX = 448.f;
+FP_DEVICE void report_saturation(int* sat, int slot, float amax, float limit) {
+  if (sat != nullptr && amax > limit) atomicAdd(sat + slot, 1);
+}
 
 FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
   f32x2 p = {lo, hi};
@@ -72,6 +84,11 @@ FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsign
   const f16x2 l = __builtin_convertvector(f32x2{a - hf[0], b - hf[1]}, f16x2);  // the residual is exact in fp32
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
+}
+// ... and the running maximum of |s x| the caller reports at the end of the kernel (report_saturation)
+FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsigned& lo, float& amax) {
+  amax = fmaxf(amax, fmaxf(fabsf(a * scale), fabsf(b * scale)));  // v_max3_f32 with |.| modifiers
+  split16_pack2(a, b, scale, hi, lo);
 }
 // position (in halves) of logical column c inside a split row; its lo half sits 32 halves further
 FP_DEVICE int split16_pos(int c) { return ((c >> 5) << 6) + (c & 31); }

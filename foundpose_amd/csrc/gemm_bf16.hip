@@ -349,9 +349,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
         }
       }
     __syncthreads();  // every wave is done with the operand tiles in LDS
+    float sat_amax = 0.f;  // largest |scale * value| of a LIVE row packed into a split-fp16 / e4m3 output (saturation report)
   #pragma unroll
     for (int tm = 0; tm < TM; ++tm) {
       const int m = m0 + wm * (BM / WM) + tm * 32 + l31;
+      float band_amax = 0.f;
       // Global reads of this band (residual / pos-embed rows, whole rows, all passes) are issued FIRST, ahead of the
       // register -> slab pass and its barrier, so their latency hides under that pass (proj -4 %, fc2 -1.5 %).
       // Issuing them one band ahead, interleaved with the previous band's stores, measured 5 % SLOWER.
@@ -432,23 +434,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             }
             if constexpr (SPOUT) {
               unsigned hi, lo;
-              split16_pack2(h0, h1, a.out_scale, hi, lo);
+              split16_pack2(h0, h1, a.out_scale, hi, lo, band_amax);
               char* sp = srow + split16_pos(col >> 1) * 2;
               *reinterpret_cast<unsigned*>(sp) = hi;
               *reinterpret_cast<unsigned*>(sp + 64) = lo;
-            } else if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f);
+            } else if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f, band_amax);
             else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
           } else if constexpr (SPOUT) {
             unsigned h01, l01, h23, l23;
-            split16_pack2(v0, v1, a.out_scale, h01, l01);
-            split16_pack2(v2, v3, a.out_scale, h23, l23);
+            split16_pack2(v0, v1, a.out_scale, h01, l01, band_amax);
+            split16_pack2(v2, v3, a.out_scale, h23, l23, band_amax);
             char* sp = srow + split16_pos(col) * 2;
             *reinterpret_cast<uint2*>(sp) = make_uint2(h01, h23);
             *reinterpret_cast<uint2*>(sp + 64) = make_uint2(l01, l23);
           } else if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
-          else if constexpr (F8OUT) *reinterpret_cast<unsigned*>(srow + col) = pack_fp8x4(v0 * a.out_scale, v1 * a.out_scale, v2 * a.out_scale, v3 * a.out_scale);
+          else if constexpr (F8OUT) *reinterpret_cast<unsigned*>(srow + col) = pack_fp8x4(v0 * a.out_scale, v1 * a.out_scale, v2 * a.out_scale, v3 * a.out_scale, band_amax);
           else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
+      if constexpr (SPOUT || F8OUT) {
+        if (m < a.M_valid) sat_amax = fmaxf(sat_amax, band_amax);  // padding rows (computed, never stored) do not report
+      }
       __syncthreads();
       // (b) slab -> global, whole rows
   #pragma unroll
@@ -486,6 +491,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       }
       if (!TWO_SLABS && tm + 1 < TM) __syncthreads();
     }
+    if constexpr (SPOUT) report_saturation(a.sat, 0, sat_amax, FP_F16_MAX);
+    if constexpr (F8OUT) report_saturation(a.sat, 1, sat_amax, FP_E4M3_MAX);
     } else {
     float4 bias[TN][4], gam[TN][4];
   #pragma unroll

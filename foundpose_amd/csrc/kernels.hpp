@@ -122,6 +122,7 @@ struct GemmBf16Args {
   //   out = epi(rstd_r * (acc - mean_r * colsum_n) + bias_n);  ln_stats [M] = (rstd_r, mean_r * rstd_r) from ln_finalize_launch
   const float2* ln_stats; int ln_parts; float ln_eps;
   const float* colsum;        // [N] fp32 sums of the rows of W
+  int* sat;                   // may be null; else [2] sticky saturation counters (common.hpp report_saturation): the split-fp16 / e4m3 epilogues report clamped outputs
 };
 
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
@@ -148,6 +149,8 @@ struct AttnArgs {
   // staging (the cross-check); 2 = the DMA kernel with one 32-query block per wave, 8 waves per 256-query block
   int variant;
   float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
+  int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps (the split-fp16
+                                 // output is a convex combination of v rows that already fit their scale: it cannot clamp)
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 
@@ -160,6 +163,7 @@ struct LayerNormArgs {
   int dim;
   int out_rows;                  // rows to produce
   int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi
+  int* sat;                      // may be null; else [2] sticky saturation counters: split-fp16 / e4m3 outputs report clamps
 };
 int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
 int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,

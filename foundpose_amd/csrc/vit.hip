@@ -27,6 +27,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
     return a.x + ((size_t)img * a.in_rows_per_img + a.in_skip + p) * a.ld_x;
   };
   vec_t v[MAXI], nx[MAXI];
+  float amax = 0.f;  // largest |scale * y| packed into a split-fp16 / e4m3 row (saturation report)
   {
     const float* x = row_ptr(row);
 #pragma unroll
@@ -73,14 +74,14 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
         if (a.out_dtype == FP_DTYPE_FP8) {
           if constexpr (VEC == 4)
             *reinterpret_cast<unsigned*>(reinterpret_cast<unsigned char*>(a.out) + (size_t)row * a.ld_out + c) =
-                pack_fp8x4(y[0] * a.out_scale, y[1] * a.out_scale, y[2] * a.out_scale, y[3] * a.out_scale);
+                pack_fp8x4(y[0] * a.out_scale, y[1] * a.out_scale, y[2] * a.out_scale, y[3] * a.out_scale, amax);
         } else if (a.out_dtype == FP_DTYPE_F16X3) {  // split-fp16 row (common.hpp): the next GEMM's A operand in the f16x3 mode
           _Float16* o = reinterpret_cast<_Float16*>(a.out) + (size_t)row * a.ld_out + split16_pos(c);
           unsigned h01, l01;
-          split16_pack2(y[0], y[1], a.out_scale, h01, l01);
+          split16_pack2(y[0], y[1], a.out_scale, h01, l01, amax);
           if constexpr (VEC == 4) {
             unsigned h23, l23;
-            split16_pack2(y[2], y[3], a.out_scale, h23, l23);
+            split16_pack2(y[2], y[3], a.out_scale, h23, l23, amax);
             *reinterpret_cast<uint2*>(o) = make_uint2(h01, h23);
             *reinterpret_cast<uint2*>(o + 32) = make_uint2(l01, l23);
           } else {
@@ -96,6 +97,8 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
         }
       }
   }
+  if (a.out_dtype == FP_DTYPE_F16X3) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  else if (a.out_dtype == FP_DTYPE_FP8) report_saturation(a.sat, 1, amax, FP_E4M3_MAX);
 }
 
 // Final LayerNorm + bilinear sampling in one pass (SURVEY 8b `fp_ln_gather_pca`, the LN + gather half): the reference

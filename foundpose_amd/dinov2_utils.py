@@ -116,6 +116,10 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._ws: Dict[Tuple[int, int, int], Tuple[_lib.VitWorkspace, list]] = {}
         self._graphs: Dict[Tuple[int, int, int], tuple] = {}
         self.num_patches: Optional[Tuple[int, int]] = None
+        # sticky device-side saturation counters (fp_vit_workspace.sat): [0] split-fp16 clamps (f16x3 mode), [1] e4m3 clamps (fp8 mode);
+        # one pair per extractor, shared by all its workspaces; only ever incremented by the kernels, zeroed by reset_saturation()
+        self._sat: Optional[torch.Tensor] = None
+        self._fp8_sat_warned = False
 
     # ---- device placement (same call pattern as the reference: extractor.to(device))
     def to(self, device=None, *args, **kwargs):  # type: ignore[override]
@@ -377,8 +381,39 @@ class DinoFeatureExtractor(torch.nn.Module):
                 ws.ld_y, ws.ld_h = a.dim + self._ld_pad8, a.hidden + self._ld_pad8
             ws.ld_qkv = em * 3 * a.dim + self._ld_pad_qkv
             ws.m_pad, ws.m_patch_pad = m_pad, mp_pad
+            if self._sat is None:
+                self._sat = torch.zeros(2, dtype=torch.int32, device=dev)
+            ws.sat = ptr(self._sat)
             self._ws[key] = (ws, bufs)
         return self._ws[key]
+
+    # ---- saturation report (f16x3 / fp8 modes)
+    def saturation_counts(self) -> Tuple[int, int]:
+        """(split-fp16 clamps, e4m3 clamps) reported by the kernels since the last reset_saturation(); synchronises.  Counted per
+        reporting thread: non-zero means at least one live activation left the representable range of its operand row."""
+        if self._sat is None:
+            return 0, 0
+        a, b = self._sat.tolist()
+        return int(a), int(b)
+
+    def reset_saturation(self) -> None:
+        if self._sat is not None:
+            self._sat.zero_()
+
+    def check_saturation(self) -> None:
+        """Raises FoundPoseSaturationError if the f16x3 mode clamped an activation since the last reset (sticky: it keeps raising until
+        reset_saturation()); warns once if the fp8 mode clamped beyond its calibration scales (expected now and then with static
+        scales, but never silent).  Synchronises.  forward() calls it; the batched engine's results call it when they are read."""
+        n16, n8 = self.saturation_counts()
+        if n16 and self.precision == "f16x3":
+            raise _lib.FoundPoseSaturationError(
+                f"precision='f16x3': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
+                f"LayerNorm outputs / q / k / v, > {65504 / _lib.SPLIT_SCALE_HID:.0f} for hidden activations): the features are not the fp32 "
+                "arithmetic's.  Use precision='fp32' for this checkpoint (or reset_saturation() to acknowledge).")
+        if n8 and self.precision == "fp8" and not self._fp8_sat_warned:
+            import warnings
+            self._fp8_sat_warned = True
+            warnings.warn(f"precision='fp8': {n8} kernel thread(s) clamped an activation at +-448 (inputs beyond the static calibration scales)")
 
     # ---- forward
     def forward_tokens(self, images: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
@@ -594,6 +629,8 @@ class DinoFeatureExtractor(torch.nn.Module):
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
         B, _, H, W = images.shape
         fmap, cls = self.forward_tokens(images)
+        if self.precision in ("f16x3", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
+            self.check_saturation()   # one host sync; the reference's forward is synchronous too (CPU tensors)
         gh, gw = self._grid(H, W)
         # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output
         return {"cls_tokens": cls, "feature_maps": fmap.reshape(B, gh, gw, self.arch.dim).permute(0, 3, 1, 2)}

@@ -164,6 +164,8 @@ class FoundPoseEngine:
             self._mark("proj")
             res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
             self._mark("corresp")
+            if self.extractor.precision in ("f16x3", "fp8"):
+                res.extractor = self.extractor   # corresp_list() checks the sticky saturation counters of the backbone
             return res
         main, side = torch.cuda.current_stream(), self.side_stream
         produced = torch.cuda.Event()
@@ -178,6 +180,8 @@ class FoundPoseEngine:
             self._mark("corresp")
             res.ready = torch.cuda.Event()
             res.ready.record(side)
+        if self.extractor.precision in ("f16x3", "fp8"):
+            res.extractor = self.extractor
         return res
 
     @property

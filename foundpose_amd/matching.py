@@ -32,6 +32,8 @@ class MatchResult:
     coord_3d: torch.Tensor         # [B, n, K, 3] f32
     query_tfidf: Optional[torch.Tensor] = None  # [B, W] (debug)
     word_ids: Optional[torch.Tensor] = None     # [sumQ, k]
+    extractor: Optional[object] = None          # set by the engine in the f16x3 / fp8 modes: corresp_list() asks it whether an activation was
+                                                # clamped on the way (sticky device-side counters, DinoFeatureExtractor.check_saturation)
     ready: Optional["torch.cuda.Event"] = None  # set when the matching ran on the engine's side stream (overlap_matching): the tensors are
                                                 # complete once this event has fired; wait() makes the current stream wait for it
 
@@ -52,6 +54,10 @@ class MatchResult:
     def corresp_list(self, b: int, debug: bool = False) -> List[Dict]:
         """The reference's List[Dict] for detection b (keys as in corresp_util.py:142-163)."""
         self.wait()
+        if self.extractor is not None:   # f16x3: raises FoundPoseSaturationError if the backbone clamped an activation (checked once per result)
+            ex, self.extractor = self.extractor, None
+            torch.cuda.current_stream().synchronize()
+            ex.check_saturation()
         counts = self.counts[b].tolist()
         tids = self.template_ids[b].tolist()
         out = []

@@ -227,6 +227,50 @@ def parity_stats(got: List[List[Dict]], ref: List[List[Dict]]) -> Dict:
             "corresp_overlap": round(float(np.mean(overlap)), 4) if overlap else None}
 
 
+def stage_flips(got: List[List[Dict]], ref: List[List[Dict]], got_words=None, ref_words=None) -> Dict:
+    """Where two runs of the path part ways, attributed to the stage that decided it (each run: per detection the reference's
+    per-template dicts; *_words: per detection the [Q, k] nearest visual words, optional):
+      word_rows_differ ....... query patches whose k nearest words differ (visual-word k-NN, template_util.py:13-29)
+      template_lists_differ .. detections whose top-n template lists differ (tf-idf retrieval, template_util.py:167-174)
+      and over the (detection, slot) pairs of detections with identical template lists:
+      nn_flips ............... query patches selected by BOTH runs that map to different object features: a flipped nearest-neighbour
+                               argmin (corresp_util.py:46); slots_with_nn_flip counts the slots that have one
+      slots_selection_differs  slots whose selected query-patch SETS differ: some cycle distance changed (a flipped argmin in either
+                               direction) and moved a patch across the top-k cut (corresp_util.py:49-61)
+      slots_order_only ....... slots with the same (patch, feature) pairs in a different ORDER: torch.topk's introselect is a
+                               function of the whole distance array, so one changed distance elsewhere reorders ties."""
+    import numpy as np
+    out = {"detections": len(got), "word_rows_differ": None, "word_rows": None, "template_lists_differ": 0, "slots_compared": 0, "nn_flips": 0,
+           "slots_with_nn_flip": 0, "slots_selection_differs": 0, "slots_order_only": 0, "slots_identical": 0}
+    if got_words is not None and ref_words is not None:
+        rows = diff = 0
+        for a, b in zip(got_words, ref_words):
+            a, b = _np(a).astype(np.int64), _np(b).astype(np.int64)
+            rows += a.shape[0]
+            diff += int((a != b).any(axis=1).sum())
+        out["word_rows"], out["word_rows_differ"] = rows, diff
+    for a, b in zip(got, ref):
+        if [int(x["template_id"]) for x in a] != [int(x["template_id"]) for x in b]:
+            out["template_lists_differ"] += 1
+            continue
+        for x, y in zip(a, b):
+            qa, qb = _np(x["coord_2d_ids"]).astype(np.int64), _np(y["coord_2d_ids"]).astype(np.int64)
+            va, vb = _np(x["nn_vertex_ids"]).astype(np.int64), _np(y["nn_vertex_ids"]).astype(np.int64)
+            out["slots_compared"] += 1
+            if np.array_equal(qa, qb) and np.array_equal(va, vb):
+                out["slots_identical"] += 1
+                continue
+            ma, mb = dict(zip(qa.tolist(), va.tolist())), dict(zip(qb.tolist(), vb.tolist()))
+            flips = sum(1 for q, v in ma.items() if q in mb and mb[q] != v)
+            out["nn_flips"] += flips
+            out["slots_with_nn_flip"] += int(flips > 0)
+            if set(ma) != set(mb):
+                out["slots_selection_differs"] += 1
+            elif flips == 0:
+                out["slots_order_only"] += 1
+    return out
+
+
 def planted_stats(got: List[List[Dict]], targets: Sequence[int], n_planted: int = 5) -> Dict:
     """Against the planted answer: detections whose top-n list is exactly t_b .. t_b+n-1, and whose best is t_b."""
     exact = top1 = 0

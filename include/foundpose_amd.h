@@ -42,7 +42,7 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of 
  *  multiplies like any other number, so a modest scale costs nothing on O(1) activations and leaves three decades of head room for
  *  the outlier channels of real checkpoints.) */
 
-#define FP_ABI_VERSION 12
+#define FP_ABI_VERSION 13
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -240,6 +240,15 @@ typedef struct {
   void* xb;      /* ln_fold only: [m_pad, D] bf16 copy of the residual stream (row stride ld_y), the A operand of qkv / fc1 */
   float* stats;  /* ln_fold only: [D / 128 + 1, m_pad, 2] fp32: partial row sums (sum x, sum x^2) per 128-column group of the
                     producer, then one slot of (rstd, mean * rstd) per row */
+  int32_t* sat;  /* may be NULL; else [2] STICKY saturation counters, only ever incremented (the caller zeroes and reads them):
+                    [0] FP_F16X3: a producer of split-fp16 rows (LayerNorm, the qkv / GELU / SwiGLU epilogues) clamped |s x| > 65504,
+                        i.e. an activation beyond +-4094 (LayerNorm outputs, q, k, v) or +-16376 (hidden) -- the near-exact mode's
+                        features are then NOT the fp32 arithmetic's; the Python extractor raises FoundPoseSaturationError on it;
+                    [1] FP_FP8: a quantising producer (LayerNorm, attention output, GELU / SwiGLU epilogue) clamped |s x| > 448
+                        (an input beyond its static calibration scale).
+                    Counted per reporting thread, not per element: non-zero means "at least one live output row clamped".
+                    The attention output and the softmax probabilities of the f16x3 mode cannot clamp (a convex combination of v rows
+                    that fit their scale; p <= 2) and do not report; padding rows never report. */
 } fp_vit_workspace;
 
 /* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token

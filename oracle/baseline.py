@@ -66,29 +66,34 @@ def run_detection(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor,
     return t, out
 
 
-def exact_matching(query_points, query_features, small: Dict, fetch_template, top_n: int = 5, top_k: int = 300, topk_mode: str = "torch"):
+def exact_matching(query_points, query_features, small: Dict, fetch_template, top_n: int = 5, top_k: int = 300, topk_mode: str = "torch",
+                   return_words: bool = False):
     """establish_correspondences (utils/corresp_util.py:73-169) in the oracle's pinned arithmetic (oracle/match.py:
     fixed-order fp32 chains, the reference's torch.topk tie order) on a bank that is too large to copy to the host as a
     whole: `small` holds feat_cluster_centroids / feat_cluster_idfs / template_descs / template_desc_opts, and
     fetch_template(tid) -> (features [P, d] of that template, index of its first feature row in the object)."""
     qp = np.ascontiguousarray(np.asarray(query_points, np.float32))
     qf = np.ascontiguousarray(np.asarray(query_features, np.float32))
-    tids, tscores, _ = om.tfidf_matching(qf, small, top_n, topk_mode)
+    tids, tscores, dbg = om.tfidf_matching(qf, small, top_n, topk_mode)
     out: List[Dict] = []
     for c, tid in enumerate(tids):
         feats, first = fetch_template(int(tid))
         q_ids, o_ids, dists, scores, _ = om.cyclic_buddies(qp, qf, np.ascontiguousarray(np.asarray(feats, np.float32)), top_k, topk_mode)
         out.append({"template_id": int(tid), "template_score": np.float32(tscores[c]), "coord_2d_ids": q_ids,
                     "nn_vertex_ids": first + o_ids, "nn_dists": dists, "coord_conf": scores})
+    if return_words:
+        return out, dbg["word_ids"]
     return out
 
 
 @torch.no_grad()
-def oracle_a_features(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor, pca_components=None, pca_mean=None):
+def oracle_a_features(sd, arch, layer: int, image: torch.Tensor, mask: torch.Tensor, pca_components=None, pca_mean=None, quant=None):
     """Oracle A's query side of one detection: fp32 extractor (blocks 0..layer only -- the later blocks the reference
-    also runs do not feed the hooked output), mask-filtered grid points, bilinear samples, PCA.  -> (points, features)."""
+    also runs do not feed the hooked output), mask-filtered grid points, bilinear samples, PCA.  -> (points, features).
+    quant="bf16": ORACLE B (hard part 2) -- the same computation with every GEMM / attention operand rounded to bf16 at the
+    device's cast points (oracle/vit.py), fp32 accumulation; everything behind the backbone stays the fp32 arithmetic."""
     S = image.shape[-1]
-    fmap = ov.extractor_forward(sd, arch, image.unsqueeze(0), layer, True)["feature_maps"][0]
+    fmap = ov.extractor_forward(sd, arch, image.unsqueeze(0), layer, True, quant=quant)["feature_maps"][0]
     qp = ov.filter_points_by_mask(ov.generate_grid_points((S, S), 14.0), mask)
     qf = ov.sample_feature_map_at_points(fmap, qp, (S, S)).contiguous()
     if pca_components is not None:

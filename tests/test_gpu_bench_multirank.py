@@ -26,6 +26,11 @@ def test_bench_two_ranks_dry_run():
     assert d["value"] > 0 and abs(d["value"] - 2 * 8 * 2 / (d["ms_per_step"] * 2 / 1e3)) < 0.02 * d["value"]  # whole-job rate
     assert "cpu_baseline" not in d and "roofline" in d      # the CPU baseline is timed at N = 1 only
     assert d["ranks_seen"] == 2                              # both ranks' records arrived in the gather
+    # what makes a real N > 1 scaling run diagnosable: every rank's own step time and the exchange step alone
+    mg = d["multi_gpu"]
+    assert len(mg["per_rank_ms_per_step"]["all"]) == 2 and 0 < mg["per_rank_ms_per_step"]["min"] <= mg["per_rank_ms_per_step"]["max"]
+    assert abs(mg["per_rank_ms_per_step"]["max"] - d["ms_per_step"]) < 1e-2 * d["ms_per_step"] + 1e-3    # `value` is built on the MAX over ranks
+    assert mg["gather_ms"]["max_over_ranks"] >= mg["gather_ms"]["mean_over_ranks"] > 0 and mg["gather_ms"]["record_bytes_per_rank"] == 8 * 5 * (3 + 300 * 9) * 4
     assert d["config"]["tie_order"] == "torch" and d["parity"]["planted"]["planted_top1"] == 8
 
 

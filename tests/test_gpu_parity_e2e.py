@@ -121,6 +121,80 @@ def test_config1_lmo_geometry_vs_oracle_a():
     assert stats["bf16"]["templates_equal"] == 1 and stats["bf16"]["corresp_overlap"] >= 0.9
 
 
+def test_bf16_mode_index_exact_vs_oracle_b_on_fixture_with_verified_margins():
+    """SURVEY 7, hard part 2: "indices must be bit-exact vs oracle B on fixtures with verified decision margins".  Oracle B =
+    oracle/vit.py with quant="bf16" (GEMM / attention operands rounded to bf16 at the device's cast points, fp32 accumulate) ->
+    oracle/match.py.  The fixture: BASELINE config 2's geometry with every query patch planted in each of the five templates (no
+    patch without a counterpart, whose nearest neighbour would be arbitrary).  The margins are VERIFIED, not assumed: for every
+    decision of the sampled detections -- the 3rd vs 4th nearest word of a patch, the best vs second-best template patch of a query
+    patch and the best vs second-best query patch of a template patch -- the gap of the squared distances must exceed what the largest
+    measured feature deviation between the device and oracle B can move it by (|d_b^2 - d_a^2| <= 2 delta (d_a + d_b) + 2 delta^2).
+    Then the benchmarked bf16 mode must reproduce oracle B index for index: words, templates, correspondences."""
+    import numpy as np
+    from foundpose_amd import projector_util
+    from oracle import match as om
+    arch = ARCHS["vitl14-reg"]
+    batch, templates = 8, 200
+    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    wl = workload.build_planted_workload(ex32, batch, 518, 1, templates, seed=17, crop_seed=9, noise=(0.05, 0.10, 0.15, 0.20, 0.25),
+                                         patch_frac=(1.0, 1.0, 1.0, 1.0, 1.0))
+    del ex32
+    bank = DeviceBank(wl.repres)
+    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    res = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj, keep_debug=True)
+    got = [res.corresp_list(b) for b in range(batch)]
+    counts = [int(wl.masks[b, 7::14, 7::14].sum()) for b in range(batch)]
+    q_off = np.concatenate([[0], np.cumsum(counts)])
+    sd = synthetic.make_vit_state_dict(arch, seed=1234)
+    repre = wl.repres[0]
+    proj = repre.feat_raw_projectors[0]
+    f2t = repre.feat_to_template_ids.cpu().long()
+    off = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(torch.bincount(f2t, minlength=templates), 0)])
+    fv = repre.feat_vectors.cpu()
+    words = repre.feat_cluster_centroids.cpu().numpy()
+    small = {"feat_cluster_centroids": words, "feat_cluster_idfs": repre.feat_cluster_idfs.cpu().numpy(),
+             "template_descs": repre.template_descs.cpu().numpy(), "template_desc_opts": repre.template_desc_opts._asdict()}
+    fetch = lambda t: (fv[int(off[t]):int(off[t + 1])].numpy(), int(off[t]))
+    grid = feature_util.generate_grid_points((518, 518), 14.0).cuda()
+    sample, ora_b, words_b, words_dev = [0, batch - 1], [], [], []
+    min_ratio = float("inf")
+    for b in sample:
+        qp, qf_b = baseline.oracle_a_features(sd, arch, 18, wl.crops[b].cpu(), wl.masks[b].cpu(), proj.components.cpu(), proj.mean.cpu(), quant="bf16")
+        o, wb = baseline.exact_matching(qp.numpy(), qf_b.numpy(), small, fetch, 5, 300, "torch", return_words=True)
+        ora_b.append(o)
+        words_b.append(np.sort(wb, axis=1))
+        words_dev.append(np.sort(res.word_ids[q_off[b]:q_off[b + 1]].cpu().numpy(), axis=1))
+        # the device's own projected features of this detection (drop-in calls), to measure delta
+        fmap = exbf(wl.crops[b:b + 1])["feature_maps"][0]
+        pts = feature_util.filter_points_by_mask(grid, wl.masks[b])
+        qf_d = projector_util.project_features(feature_util.sample_feature_map_at_points(fmap, pts, (518, 518)).contiguous(), repre.feat_raw_projectors).cpu().numpy()
+        assert np.array_equal(pts.cpu().numpy(), qp.numpy())
+        delta = float(np.linalg.norm(qf_d - qf_b.numpy(), axis=1).max())
+
+        def verify(d2, k):   # rows of squared distances: gap between the k-th and (k+1)-th smallest vs what delta can move
+            part = np.sort(d2, axis=1)[:, :k + 1]
+            gap = part[:, k] - part[:, k - 1]
+            need = 2.0 * delta * (np.sqrt(part[:, k]) + np.sqrt(part[:, k - 1])) + 2.0 * delta * delta
+            return float((gap / need).min())
+        q = qf_b.numpy().astype(np.float64)
+        d2 = lambda x, y: np.maximum(0.0, (x * x).sum(1)[:, None] + (y * y).sum(1)[None, :] - 2.0 * x @ y.T)
+        min_ratio = min(min_ratio, verify(d2(q, words.astype(np.float64)), 3))
+        for c in o:
+            tf = fetch(c["template_id"])[0].astype(np.float64)
+            dm = d2(q, tf)
+            min_ratio = min(min_ratio, verify(dm, 1), verify(dm.T, 1))
+    print(f"\n[margin fixture] smallest decision margin / worst-case movement = {min_ratio:.2f} (must be > 1)")
+    assert min_ratio > 1.0, "the fixture's decision margins do not cover the bf16 feature deviation: not a margin fixture"
+    flips = workload.stage_flips([got[b] for b in sample], ora_b, words_dev, words_b)
+    stats = workload.parity_stats([got[b] for b in sample], ora_b)
+    print(f"[margin fixture] bf16 device vs oracle B: {stats}\n[margin fixture] by stage: {flips}")
+    assert flips["word_rows_differ"] == 0 and flips["template_lists_differ"] == 0
+    assert stats["templates_equal"] == len(sample) and stats["corresp_equal"] == stats["slots_compared"] == 5 * len(sample)
+    # and every detection of the batch finds its five planted templates (as a set: their tf-idf descriptors tie by construction)
+    for b in range(batch):
+        assert sorted(int(c["template_id"]) for c in got[b]) == [int(wl.targets[b]) + r for r in range(5)]
+
+
 def test_default_backbone_dinov2_vitl14_vs_oracle_a():
     """The reference's DEFAULT extractor (`InferOpts.extractor_name = "dinov2_vitl14"`, scripts/infer.py:75): ViT-L/14 WITHOUT register
     tokens, short form -> hooked block 9 (dinov2_utils.py:62-64), N = 1370 tokens at 518 px.  BASELINE config 2's shape (one object,

@@ -251,3 +251,62 @@ def test_extractor_f16x3_with_massive_activation_channels():
         assert bool(torch.isfinite(outs[prec]).all())
     e32, e3 = rel_err(outs["fp32"], ref), rel_err(outs["f16x3"], ref)
     assert e3 < 3 * e32 + 1e-5 and e3 < 1e-4, (e3, e32)
+    assert ex.saturation_counts() == (0, 0)          # ... and the device-side counters agree: nothing was clamped
+
+
+@pytest.mark.parametrize("where", ["layernorm", "qkv", "hidden"])
+def test_f16x3_saturation_is_loud(where):
+    """An activation beyond the range of its split-fp16 row (+-4094 for LayerNorm outputs and q / k / v, +-16376 for the hidden
+    activations) is clamped by the producer kernel -- and REPORTED: the sticky device-side counter (fp_vit_workspace.sat) goes up, the
+    extractor's forward raises FoundPoseSaturationError and keeps raising until reset_saturation(), and a result of the batched engine
+    raises when it is read.  The same extractor on weights without the outlier reports nothing (padding rows never do)."""
+    from foundpose_amd import _lib, engine as fe, feature_util, workload
+    from foundpose_amd.bank import DeviceBank
+    arch = ARCHS["vits14-reg"]
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=3_norm=1"
+    sd = {k: v.clone() for k, v in synthetic.make_vit_state_dict(arch, seed=5).items()}
+    if where == "layernorm":
+        sd["blocks.1.norm1.bias"][7] = 5000.0          # LayerNorm output channel 7 = 5000 + ... > 4094
+    elif where == "qkv":
+        sd["blocks.2.attn.qkv.bias"][arch.dim + 3] = -6000.0   # a key channel at -6000
+    else:
+        sd["blocks.0.mlp.fc1.bias"][11] = 20000.0      # gelu(20000) = 20000 > 16376
+    imgs = synthetic.make_crops(3, 112, seed=2).cuda()
+    ex = feature_util.make_feature_extractor(name, state_dict=sd, precision="f16x3").to("cuda")
+    with pytest.raises(_lib.FoundPoseSaturationError, match="clamped an activation"):
+        ex(imgs)
+    n16, n8 = ex.saturation_counts()
+    assert n16 > 0 and n8 == 0
+    with pytest.raises(_lib.FoundPoseSaturationError):    # sticky
+        ex.check_saturation()
+    ex.reset_saturation()
+    assert ex.saturation_counts() == (0, 0)
+    # the fp32 mode computes the same weights without complaint (no operand rows to leave)
+    ex32 = feature_util.make_feature_extractor(name, state_dict=sd, precision="fp32").to("cuda")
+    assert bool(torch.isfinite(ex32(imgs)["feature_maps"]).all())
+    # through the engine: the result raises when its correspondences are read
+    clean = feature_util.make_feature_extractor(name, seed=5, precision="f16x3").to("cuda")
+    wl = workload.build_planted_workload(clean, 3, 112, 1, 40, seed=3, crop_seed=2)
+    bank = DeviceBank(wl.repres)
+    res = fe.FoundPoseEngine(clean, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
+    assert len(res.corresp_list(0)) == 5 and clean.saturation_counts() == (0, 0)     # clean weights: nothing reported, token selection included
+    res = fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
+    with pytest.raises(_lib.FoundPoseSaturationError):
+        res.corresp_list(0)
+
+
+def test_fp8_saturation_is_reported():
+    """The fp8 mode quantises with STATIC scales: an activation beyond them is clamped at +-448.  With honest calibration scales on the
+    calibration maxima (and 2x head room) nothing clamps; with scales 8x too large the counter goes up and the forward warns (once)."""
+    from foundpose_amd import feature_util
+    name = "dinov2_version=vitb14-reg_stride=14_facet=token_layer=2_norm=1"
+    imgs = synthetic.make_crops(2, 112, seed=4).cuda()
+    ex = feature_util.make_feature_extractor(name, seed=7, precision="fp8").to("cuda")
+    scales = ex.calibrate_fp8(imgs)
+    roomy = feature_util.make_feature_extractor(name, seed=7, precision="fp8", act_scales=scales * 0.5).to("cuda")   # 2x head room over the calibration maxima
+    roomy(imgs)
+    assert roomy.saturation_counts() == (0, 0)
+    bad = feature_util.make_feature_extractor(name, seed=7, precision="fp8", act_scales=scales * 8.0).to("cuda")
+    with pytest.warns(UserWarning, match="clamped an activation at"):
+        bad(imgs)
+    assert bad.saturation_counts()[1] > 0 and bad.saturation_counts()[0] == 0
