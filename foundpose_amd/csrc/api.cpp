@@ -55,11 +55,29 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
   return launch_normalize_rows(x, n, d, eps, out, ST(stream));
 }
 
+// The two-stage search of csrc/knn_cand.hip (fp16-MFMA candidate pass with a derived bound + exact re-scoring; outputs bit-identical to
+// the all-pairs exact tile) is built and tested but NOT the default: measured on the bench shapes it is slower than the exact-fp32 tile it
+// was meant to replace (word 3-NN 245 vs 218 us, cyclic tiles 421 vs 338 us: profiles/EXPERIMENTS.md "two-stage k-NN").  FP_KNN_CAND=1
+// switches it on (read per call, so a test can compare both paths in one process).
+static bool knn_cand_enabled() {
+  const char* e = getenv("FP_KNN_CAND");
+  return e != nullptr && atoi(e) != 0;
+}
+
 int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n, int d,
               int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream) {
   FP_REQUIRE(q && q_sqnorm && db && db_sqnorm && scratch && out_idx, "fp_knn_l2: null pointer");
   FP_REQUIRE(k >= 1 && n >= 1 && d >= 4, "fp_knn_l2: bad sizes (n=%d d=%d k=%d)", n, d, k);
   if (m == 0) return FP_OK;
+  // 2 <= k <= 4 against a database of some size (the visual-word search: k = 3, 2048 words), opt-in (FP_KNN_CAND=1): fp16-MFMA candidate
+  // pass + exact fp32 chains on the candidates (knn_cand.hip) -- the same d2 / indices as the all-pairs exact tile below, bit for bit.
+  if (k >= 2 && n >= 256 && knn_cand_enabled() && knn_cand_supported(k, d) && out_d2) {
+    KnnCandArgs c;
+    memset(&c, 0, sizeof(c));
+    c.A = q; c.B = db; c.ld = d; c.a_sqn = q_sqnorm; c.b_sqn = db_sqnorm; c.K = d; c.M = m; c.N = n;
+    c.k = k; c.pairs = 1; c.row_stride = m; c.out_d2 = out_d2; c.out_idx = out_idx;
+    return knn_cand_launch(c, m, scratch, ST(stream));
+  }
   F32TileArgs a = zero_tile_args();
   a.A = q; a.lda = d; a.B = db; a.ldb = d; a.K = d; a.M = m; a.N = n;
   a.a_sqnorm = q_sqnorm; a.b_sqnorm = db_sqnorm;
@@ -160,6 +178,26 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   FP_REQUIRE(q_max >= 1 && p_max >= 1 && n_slots >= 1, "fp_cyclic_buddies: bad sizes");
   const int pairs = num_det * n_slots;
   if (pairs == 0) return FP_OK;
+  CyclicArgs c;
+  memset(&c, 0, sizeof(c));
+  if (knn_cand_enabled() && knn_cand_supported(1, d)) {
+    // the two 1-NN searches of a pair (corresp_util.py:46-47) by candidate pass + exact re-scoring (knn_cand.hip): query patch -> nearest
+    // template patch into row_best [pairs, q_max], template patch -> nearest query patch into col_best [pairs, p_max]; the same keys
+    // (d2, index; ties -> lowest index) the all-pairs tile below leaves, so everything downstream is unchanged
+    unsigned long long* row_best = reinterpret_cast<unsigned long long*>(scratch);
+    unsigned long long* col_best = row_best + (size_t)pairs * q_max;
+    void* cand = col_best + (size_t)pairs * p_max;
+    KnnCandArgs kc;
+    memset(&kc, 0, sizeof(kc));
+    kc.A = query_feats; kc.B = bank_feats; kc.ld = d; kc.a_sqn = query_sqnorm; kc.b_sqn = bank_sqnorm; kc.K = d;
+    kc.a_seg_off = q_off; kc.pair_a_div = n_slots; kc.b_seg_off = tpl_off; kc.pair_b_seg = tpl_ids; kc.pair_b_base = tpl_base;
+    kc.k = 1; kc.pairs = pairs;
+    kc.swap = 0; kc.row_stride = q_max; kc.out_keys = row_best;
+    TRY(knn_cand_launch(kc, q_max, cand, ST(stream)));
+    kc.swap = 1; kc.row_stride = p_max; kc.out_keys = col_best;
+    TRY(knn_cand_launch(kc, p_max, cand, ST(stream)));
+    c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max; c.row_parts = 1; c.col_parts = 1;
+  } else {
   // partial nearest-neighbour tables, one slice per distance tile (no atomics, no preset): [pairs, col tiles, q_max] + [pairs, row tiles, p_max]
   const int row_parts = (p_max + 127) / 128, col_parts = (q_max + 127) / 128;
   unsigned long long* row_best = reinterpret_cast<unsigned long long*>(scratch);
@@ -171,12 +209,11 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   a.a_sqnorm = query_sqnorm; a.b_sqnorm = bank_sqnorm;
   a.row_best = row_best; a.row_stride = q_max; a.col_best = col_best; a.col_stride = p_max; a.best_parts = 1;
   TRY(f32_tile_launch(F32_EPI_DIST_ARGMIN, a, q_max, p_max, pairs, ST(stream)));
-  CyclicArgs c;
-  memset(&c, 0, sizeof(c));
-  c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_base = tpl_base; c.tpl_off = tpl_off; c.feat_base = feat_base;
-  c.points = query_points; c.vertices = vertices;
   c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max;
   c.row_parts = row_parts; c.col_parts = col_parts;
+  }
+  c.q_off = q_off; c.tpl_ids = tpl_ids; c.tpl_base = tpl_base; c.tpl_off = tpl_off; c.feat_base = feat_base;
+  c.points = query_points; c.vertices = vertices;
   c.n_slots = n_slots; c.top_k = top_k; c.k_max = k_max; c.q_max = q_max; c.tie_mode = tie_mode;
   c.out_count = out_count; c.out_q_ids = out_q_ids; c.out_feat_ids = out_feat_ids; c.out_dists = out_dists;
   c.out_conf = out_conf; c.out_coord_2d = out_coord_2d; c.out_coord_3d = out_coord_3d;

@@ -18,6 +18,7 @@
 // What bounds it, and what was tried and did not help: DESIGN.md section 5 "GEMM analysis".
 #include <cstdlib>
 
+#include <cstring>
 #include "common.hpp"
 #include "kernels.hpp"
 
@@ -70,6 +71,33 @@ FP_DEVICE f32x2 gelu_pk(f32x2 x) {
   q = __builtin_elementwise_fma(q, s, f32x2{3.986083959e-01f, 3.986083959e-01f});
   const f32x2 phi = __builtin_elementwise_fma(xc, q, f32x2{0.5f, 0.5f});
   return x * phi;
+}
+
+// GELU in its erf form at fp32 accuracy (the f16x3 mode's fc1 epilogue; the reference's nn.GELU() inside the backbone's Mlp).
+// erfc(z) exp(z^2) is a degree-7 polynomial in t = 1 / (1 + 0.3275911 z) on z >= 0 (the Abramowitz-Stegun 7.1.26 form with two more
+// terms, refitted minimax against scipy's erfcx: |d erf| <= 3.5e-9 before rounding), and gelu(x) = x/2 + |x|/2 erf(|x| / sqrt 2), so
+// no sign handling and no cancellation for x > 0.  Evaluated in fp32 on two elements per instruction (v_pk_fma_f32) + one v_rcp_f32 and
+// one v_exp_f32 each: max |error| 4.2e-7 over [-12, 12] against the exact function -- closer to it than torch's own CPU gelu (1.2e-6,
+// tools/gelu_accuracy.py) and than the f16x3 products (2^-22 relative) -- at ~12 instruction-equivalents per element; ocml's erff cost ~35
+// and a sixth of the fc1 launch.
+FP_DEVICE f32x2 gelu_erf_pk(f32x2 x) {
+  const f32x2 hx = x * f32x2{0.5f, 0.5f};
+  const f32x2 hax = {__builtin_fabsf(hx[0]), __builtin_fabsf(hx[1])};
+  const f32x2 z = hax * f32x2{1.41421356237309504880f, 1.41421356237309504880f};   // |x| / sqrt 2
+  const f32x2 den = __builtin_elementwise_fma(z, f32x2{0.3275911f, 0.3275911f}, f32x2{1.f, 1.f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+  f32x2 q = f32x2{-0.29844723923966754f, -0.29844723923966754f};
+  q = __builtin_elementwise_fma(q, t, f32x2{1.5048025775340452f, 1.5048025775340452f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-2.0855161249300567f, -2.0855161249300567f});
+  q = __builtin_elementwise_fma(q, t, f32x2{2.040068178110667f, 2.040068178110667f});
+  q = __builtin_elementwise_fma(q, t, f32x2{-0.7490454190655901f, -0.7490454190655901f});
+  q = __builtin_elementwise_fma(q, t, f32x2{0.4310967998728252f, 0.4310967998728252f});
+  q = __builtin_elementwise_fma(q, t, f32x2{0.15704123123125485f, 0.15704123123125485f});
+  q = q * t;
+  const f32x2 a = z * (z * f32x2{-1.44269504088896340736f, -1.44269504088896340736f});
+  const f32x2 e = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};                 // exp(-z^2)
+  const f32x2 erfz = __builtin_elementwise_fma(-q, e, f32x2{1.f, 1.f});                           // erf(|x| / sqrt 2)
+  return __builtin_elementwise_fma(hax, erfz, hx);
 }
 
 // Sum over aligned groups of 32 lanes with DPP moves; the total is valid in the LAST lane of each group (lane & 31 == 31).
@@ -411,9 +439,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
           }
           if constexpr (EPI == GEMM_EPI_GELU_BF16) {
-            if constexpr (SP) {  // exact erf form (the fp32 path's, f32_tile.hip): this mode does not approximate
+            if constexpr (SP) {  // the erf form at fp32 accuracy: this mode does not approximate below the arithmetic it emulates
+#ifdef FP_SPLIT_GELU_OCML   // (measurement build: ocml's erff, the round-3 epilogue)
               v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f)); v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
               v2 = 0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752440f)); v3 = 0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752440f));
+#else
+              const f32x2 g01 = gelu_erf_pk(f32x2{v0, v1}), g23 = gelu_erf_pk(f32x2{v2, v3});
+              v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
+#endif
             } else {
               const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
               v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
@@ -585,10 +618,18 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   // walk down M inside one group of 4 n-tiles, so each W K-slice is shared by 8 workgroups (A by 4) and the group's W
   // panel stays in the XCD's L2: L2 hit rate 64 -> 75 %, fc1 412 -> 399 us.  (N = 1024 is 4 n-tiles wide: the default
   // order already has that shape, and the raster's intra-order measured 4 % slower there.)
+  // FP_GEMM_RAST: 0 = off, 1 = the 8 x 4 default, "RxG" = another super-tile of R m-tiles x G n-tiles (R * G = 32; measurements:
+  // profiles/EXPERIMENTS.md "super-tile shapes" -- 4x8 / 2x16 / 16x2 all lose to 8x4: only a 4-n-tile W panel (2 MiB) survives in a 4-MiB L2
+  // next to the streaming A slab, and the A re-fetch per n-group that remains is what a wider group would remove)
   static const int env_rast = getenv("FP_GEMM_RAST") ? atoi(getenv("FP_GEMM_RAST")) : 1;
-  if (env_rast && BM == 256 && (a.N / BN) % 4 == 0 && (a.N / BN) > 4 && grid >= 512) {
-    a.rast_r = 8; a.rast_gn = 4;
-    grid = ((a.M / BM + 7) / 8) * ((a.N / BN) / 4) * 32;
+  static const int env_gn = (getenv("FP_GEMM_RAST") && strchr(getenv("FP_GEMM_RAST"), 'x')) ? atoi(strchr(getenv("FP_GEMM_RAST"), 'x') + 1) : 0;
+  // default: 4 x 8 when the output is a multiple of 8 n-tiles wide (fc1: 16), else 8 x 4 (qkv: 12) -- same-box pipeline A/B, three
+  // alternations: 1043.0 detections/s against 1038.2 with 8 x 4 everywhere (profiles/EXPERIMENTS.md)
+  const int wide8 = (a.N / BN) % 8 == 0;
+  const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
+  if (env_rast && rr * gn == 32 && BM == 256 && (a.N / BN) % gn == 0 && (a.N / BN) > 4 && grid >= 512) {
+    a.rast_r = rr; a.rast_gn = gn;
+    grid = ((a.M / BM + rr - 1) / rr) * ((a.N / BN) / gn) * 32;
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;

@@ -40,6 +40,25 @@ struct F32TileArgs {
 
 int f32_tile_launch(int epi, const F32TileArgs& a, int max_m, int max_n, int pairs, hipStream_t st);
 
+// ---------------------------------------------------------------- knn_cand.hip
+// Exact L2 k-NN (k <= 4, dimension 64 / 128 / 256) in two stages: fp16-MFMA candidate pass with a derived bound + exact fp32 chains
+// on the candidates -- the outputs of the all-pairs exact tile (DIST_TOPK / DIST_ARGMIN) bit for bit.  Segment tables as in F32TileArgs.
+struct KnnCandArgs {
+  const float* A; const float* B; int ld;   // [*, K] fp32, one row stride for both sides
+  const float* a_sqn; const float* b_sqn;   // squared norms (k-ascending fma chains) of the rows of A / B
+  int K, M, N;                              // unsegmented: rows of A, rows of B
+  const int* a_seg_off; int pair_a_div;     // pair -> A segment pair / pair_a_div (null: the whole of A)
+  const int* b_seg_off; const int* pair_b_seg; const int* pair_b_base;   // pair -> B segment pair_b_seg[pair] (+ base of the pair's group); < 0: empty pair
+  int swap;                                 // 0: rows = the A segment, database = the B segment; 1: rows = the B segment, database = the A segment
+  int k, pairs, row_stride;                 // neighbours per row; problems; rows reserved per pair in the per-row tables (>= the longest row segment)
+  unsigned long long* lists; int* counts;   // (set by the launcher from the scratch block)
+  unsigned long long* out_keys;             // [pairs * row_stride, k] (d2 bits << 32 | index) ascending, ~0 past the database; may be null
+  float* out_d2; int* out_idx;              // [pairs * row_stride, k]; may be null
+};
+size_t knn_cand_scratch_bytes(int k, long long rows);   // rows = pairs * row_stride
+bool knn_cand_supported(int k, int K);
+int knn_cand_launch(const KnnCandArgs& a, int max_rows, void* scratch, hipStream_t st);
+
 // ---------------------------------------------------------------- match.hip
 struct CyclicArgs {
   const int* q_off;        // [B+1] query-point segment per detection

@@ -927,7 +927,8 @@ __global__ __launch_bounds__(256) void cyclic_select_kernel(CyclicArgs a) {
   const int f0 = a.tpl_off[tpl];
   // the distance tiles left one slice of nearest-neighbour keys per tile: the nearest over the whole template / crop is the
   // smallest key over the live tiles (keys order by distance, then index: the same winner an atomicMin would have kept)
-  const int np = (a.tpl_off[tpl + 1] - f0 + 127) / 128, nq = (Q + 127) / 128;
+  // (row_parts / col_parts == 1: the two-stage search of knn_cand.hip left ONE finished key per row / column)
+  const int np = a.row_parts == 1 ? 1 : (a.tpl_off[tpl + 1] - f0 + 127) / 128, nq = a.col_parts == 1 ? 1 : (Q + 127) / 128;
   const unsigned long long* rb = a.row_best + (size_t)pair * a.row_parts * a.row_stride;
   const unsigned long long* cb = a.col_best + (size_t)pair * a.col_parts * a.col_stride;
   const float* pts = a.points + (size_t)q0 * 2;

@@ -9,7 +9,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import _lib
-from ._lib import call, ptr, stream, require_cuda
+from ._lib import call, knn_scratch_bytes, ptr, stream, require_cuda
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -54,7 +54,7 @@ def knn_l2(q: torch.Tensor, db: torch.Tensor, k: int, q_sqnorm: Optional[torch.T
     d2 = torch.empty(m, k_eff, dtype=torch.float32, device=q.device)
     idx = torch.empty(m, k_eff, dtype=torch.int32, device=q.device)
     if m > 0:
-        per_row = 8 if k_eff == 1 else (((n + 127) // 128) * k_eff * 8 if k_eff <= 8 else n * 4)
+        per_row = knn_scratch_bytes(1, n, k_eff)
         chunk = max(1, min(m, _KNN_SCRATCH_BYTES // per_row))
         scratch = torch.empty(chunk * per_row, dtype=torch.uint8, device=q.device)
         for r0 in range(0, m, chunk):

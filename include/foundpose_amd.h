@@ -58,9 +58,16 @@ int fp_sqnorm_rows(const float* x, int64_t n, int d, float* out, fp_stream_t str
 int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, fp_stream_t stream);
 
 /* Exact brute-force L2 k-NN: KNN.fit + KNN.search with metric "l2" (utils/knn_util.py:38-106).
- * q [m,d], db [n,d], precomputed squared norms of both.  Scratch: k == 1: m*8 bytes; 2 <= k <= 8: m * ceil(n/128) * k * 8
- * bytes (per-tile candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared), out_idx [m,k] int32,
- * ascending, ties -> lowest index, (inf, -1) past the database size. */
+ * q [m,d], db [n,d], precomputed squared norms of both.  Scratch: FP_KNN_SCRATCH_BYTES(m, n, k): k == 1: m*8 bytes; 2 <= k <= 8:
+ * m * max(ceil(n/128) * k * 8, 352) bytes (candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared),
+ * out_idx [m,k] int32, ascending, ties -> lowest index, (inf, -1) past the database size.
+ * Opt-in (environment FP_KNN_CAND=1; measured slower than the all-pairs tile on the benchmark shapes, so not the default): 2 <= k <= 4
+ * with d = 64 / 128 / 256, n >= 256 (the visual-word search: k = 3, d = 256) runs in two stages -- an fp16-MFMA candidate pass whose
+ * error bound is derived from the operands' norms (csrc/knn_cand.hip), then the exact fp32 chain on the candidates -- with outputs
+ * bit-identical to the all-pairs exact-fp32 tile that serves every other case; rows the bound cannot cover (values beyond the fp16
+ * range, more near-ties than a candidate list holds) are computed by exact brute force inside the second stage. */
+#define FP_KNN_SCRATCH_BYTES(m, n, k) \
+  ((k) == 1 ? (size_t)(m) * 8 : ((k) <= 8 ? (size_t)(m) * ((size_t)(((n) + 127) / 128) * (k) * 8 > 352 ? (size_t)(((n) + 127) / 128) * (k) * 8 : 352) : (size_t)(m) * (n) * 4))
 int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n,
               int d, int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream);
 
@@ -123,14 +130,21 @@ int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, 
  *   tpl_ids [B*n_slots] template ids, <0 = empty slot: object-local (as fp_cosine_topk reports them) when tpl_base [B] = first
  *   template of each detection's object is given, GLOBAL ids when tpl_base is NULL
  *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
- *   scratch: FP_CYCLIC_SCRATCH_BYTES(B * n_slots, q_max, p_max) bytes (one slice of nearest-neighbour keys per 128 x 128
- *   distance tile; nothing has to be preset)
+ *   scratch: FP_CYCLIC_SCRATCH_BYTES(B * n_slots, q_max, p_max) bytes (nearest-neighbour keys of both directions + the candidate
+ *   lists of the two-stage search, or one slice of keys per 128 x 128 distance tile of the all-pairs form; nothing has to be preset)
+ *   FP_KNN_CAND=1 (opt-in, see fp_knn_l2) and d = 64 / 128 / 256: the two 1-NN searches run as fp16-MFMA candidate pass + exact re-scoring
+ *   (csrc/knn_cand.hip, same keys bit for bit); otherwise the all-pairs exact-fp32 tile
  * outputs, padded to k_max >= top_k per (detection, slot): count, query ids, object feature ids (= the
  * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d.  tie_mode as in fp_cosine_topk: 1 makes
  * the order (and the choice among tied distances at the top_k boundary) identical to the reference's
  * torch.topk(-cycle_dists, k). */
-#define FP_CYCLIC_SCRATCH_BYTES(pairs, q_max, p_max) \
+#define FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) \
   (8 * (size_t)(pairs) * ((size_t)(((p_max) + 127) / 128) * (size_t)(q_max) + (size_t)(((q_max) + 127) / 128) * (size_t)(p_max)))
+#define FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max) \
+  (8 * (size_t)(pairs) * ((size_t)(q_max) + (size_t)(p_max)) + 224 * (size_t)(pairs) * (size_t)((q_max) > (p_max) ? (q_max) : (p_max)))
+#define FP_CYCLIC_SCRATCH_BYTES(pairs, q_max, p_max) \
+  (FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) > FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max) ? FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) \
+                                                                                             : FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max))
 int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const float* query_points,
                       const int32_t* q_off, int num_det, int q_max, const float* bank_feats,
                       const float* bank_sqnorm, const int32_t* tpl_off, int p_max, const float* vertices,

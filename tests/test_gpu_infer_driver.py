@@ -67,7 +67,10 @@ def test_infer_driver_synthetic_scene(tmp_path):
     # ---- the driver
     frames = lambda lid: iter([{"scene_id": 1, "im_id": 3, "image": image, "camera": cam}])
     out_dir = str(tmp_path / "inference")
-    paths = infer.infer(opts, frames, infer_pose_util.load_detections_in_bop_format(str(det_path)), {1: repre_util.load_object_repre(rdir)}, out_dir, extractor=ex)
+    # (one target instance x num_preds_factor 2 = both detections; without targets AND without annotations the reference skips the image,
+    #  scripts/infer.py:317-321 -- checked at the end)
+    paths = infer.infer(opts, frames, infer_pose_util.load_detections_in_bop_format(str(det_path)), {1: repre_util.load_object_repre(rdir)}, out_dir, extractor=ex,
+                        num_target_insts={1: {(1, 3): 1}})
     est = json.load(open(os.path.join(out_dir, "1", "estimated-poses.json")))
     assert len(est) == 2
     for e in est:
@@ -105,3 +108,18 @@ def test_infer_driver_synthetic_scene(tmp_path):
     one = run("t1", {1: {(1, 3): 1}})          # one target instance: only the top-scoring detection
     assert [int(e["inst_id"]) for e in one] == [0]
     assert run("t0", {1: {(1, 3): 0}}) == [] and run("tmiss", {1: {(2, 9): 3}}) == [] and run("tobj", {5: {(1, 3): 2}}) == []
+    assert run("tnone", None) == []            # no targets and no ground-truth annotations: num_target_insts = 0, the image is skipped (infer.py:317-321)
+
+    # ---- ground-truth annotations instead of targets (infer.py:286-305, 317): only annotations of THIS object that are visible enough count
+    class Anno:
+        def __init__(self, lid, vis, b):
+            self.lid, self.visibilities, self.masks_modal, self.boxes_amodal = lid, vis, masks[b], np.array(boxes_xyxy[b], np.float32)
+    def run_gt(tag, annos):
+        d = str(tmp_path / tag)
+        fr = lambda lid: iter([{"scene_id": 1, "im_id": 3, "image": image, "camera": cam, "gt_annos": annos}])
+        infer.infer(o1, fr, dets_l, rep, d, extractor=ex)
+        f = os.path.join(d, "1", "estimated-poses.json")
+        return json.load(open(f)) if os.path.exists(f) else []
+    assert len(run_gt("g2", [Anno(1, 0.9, 0), Anno(1, 0.5, 1)])) == 2          # two visible annotations of object 1 -> two predictions
+    assert len(run_gt("g1", [Anno(1, 0.9, 0), Anno(1, 0.05, 1), Anno(2, 0.9, 1)])) == 1   # visibility 0.05 <= min_visibility 0.1, and another object's annotation
+    assert run_gt("g0", [Anno(1, float("nan"), 0), Anno(2, 0.9, 1)]) == []     # annotations present but none qualifies: the frame is skipped

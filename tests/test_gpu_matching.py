@@ -784,3 +784,81 @@ def test_prefiltered_retrieval_multi_object_groups():
     for tie_mode in (0, 1):
         a, b = _both_retrievals(desc_n, bank_n, seg, off, nt, 5, tie_mode, 35)
         _assert_same(a, b, f"multi-object tie_mode={tie_mode}")
+
+
+# ------------------------------------------------------------------ the opt-in two-stage k-NN (csrc/knn_cand.hip) == the all-pairs exact tile, bit for bit
+def _knn_both(monkeypatch, q, db, k):
+    from foundpose_amd import ops
+    out = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("FP_KNN_CAND", on)
+        d2, idx = ops.knn_l2(cu(q), cu(db), k)
+        torch.cuda.synchronize()
+        out.append((d2.cpu().numpy().copy(), idx.cpu().numpy().copy()))
+    return out
+
+
+@pytest.mark.parametrize("m,n,K,k", [(5, 300, 64, 3), (70, 300, 64, 2), (200, 700, 128, 3), (300, 2048, 256, 3), (1000, 2048, 256, 3), (37, 1000, 256, 4), (129, 257, 256, 3)])
+def test_two_stage_knn_equals_exact_tile(monkeypatch, m, n, K, k):
+    """fp16-MFMA candidate pass + exact fp32 chains on the candidates (FP_KNN_CAND=1): distances and indices equal the all-pairs exact-fp32
+    tile's and the oracle's, bit for bit, on unstructured data (every distance within a few percent of every other: the hardest case for a
+    candidate window) at several shapes incl. ragged row blocks and database tails."""
+    rng = np.random.default_rng(m + n + K)
+    q, db = rng.standard_normal((m, K)).astype(np.float32), rng.standard_normal((n, K)).astype(np.float32)
+    (d0, i0), (d1, i1) = _knn_both(monkeypatch, q, db, k)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32))
+    o_d2, o_idx = clib.l2_knn(q, db, k)
+    assert np.array_equal(i1, o_idx) and np.array_equal(d1, o_d2)
+
+
+def test_two_stage_knn_adversarial_rows(monkeypatch):
+    """Rows built against the candidate logic: exact duplicates in the database (ties -> lowest index), a query that IS a database row
+    (distance 0: the clamp), every database row identical (more candidates than a list holds -> the brute-force rows of stage 2), values
+    beyond the fp16 range and a NaN-free but huge dynamic range (-> brute force), tiny values in the fp16 subnormal range, zero vectors."""
+    rng = np.random.default_rng(5)
+    n, K, k = 1024, 256, 3
+    db = rng.standard_normal((n, K)).astype(np.float32)
+    db[700] = db[3]; db[701] = db[3]; db[20] = db[900]
+    q = rng.standard_normal((40, K)).astype(np.float32)
+    q[0] = db[3]                      # three exact ties at distance 0
+    q[1] = db[900] + 1e-4             # near-ties between rows 20 and 900
+    q[2] = 0.0
+    q[3] *= 1e-6                      # fp16-subnormal elements
+    q[4] *= 3e4                       # elements beyond 65504 -> the row is taken by brute force
+    (d0, i0), (d1, i1) = _knn_both(monkeypatch, q, db, k)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32))
+    assert i1[0].tolist() == [3, 700, 701] and d1[0].tolist() == [0.0, 0.0, 0.0]
+    same = np.repeat(db[:1], n, 0)    # every row inside every window
+    (d0, i0), (d1, i1) = _knn_both(monkeypatch, q[:8], same, k)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32)) and i1[5].tolist() == [0, 1, 2]
+    big = db.copy(); big[77] *= 1e5   # a database row beyond the fp16 range: every row of the launch falls back
+    (d0, i0), (d1, i1) = _knn_both(monkeypatch, q, big, k)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32))
+    tiny = (db * 1e-7).astype(np.float32)
+    (d0, i0), (d1, i1) = _knn_both(monkeypatch, (q * 1e-7).astype(np.float32), tiny, k)
+    assert np.array_equal(i0, i1) and np.array_equal(d0.view(np.int32), d1.view(np.int32))
+
+
+@pytest.mark.parametrize("Q,P", [(5, 140), (140, 5), (133, 133), (517, 389), (389, 517), (1, 300), (300, 1)])
+def test_two_stage_cyclic_equals_exact_tile(monkeypatch, Q, P):
+    """The two 1-NN searches of cyclic_buddies_matching through the two-stage path (segmented, both directions): ids, cycle distances and
+    scores equal the all-pairs path's and the oracle's, ties (duplicated query / template patches) included."""
+    from foundpose_amd import corresp_util
+    rng = np.random.default_rng(Q * 1000 + P + 1)
+    obj = rng.standard_normal((P, 64)).astype(np.float32)
+    qf = rng.standard_normal((Q, 64)).astype(np.float32)
+    n_copy = min(Q, P) // 2
+    qf[:n_copy] = obj[rng.permutation(P)[:n_copy]]
+    if Q > 3:
+        qf[Q - 1] = qf[0]
+    if P > 3:
+        obj[P - 1] = obj[1]
+    pts = (rng.integers(0, 37, (Q, 2)) * 14 + 7).astype(np.float32)
+    got = []
+    for on in ("0", "1"):
+        monkeypatch.setenv("FP_KNN_CAND", on)
+        got.append([t.cpu().numpy().copy() for t in corresp_util.cyclic_buddies_matching(cu(pts), cu(qf), None, cu(obj), None, 300)])
+    for a_, b_ in zip(*got):
+        assert np.array_equal(a_, b_, equal_nan=True)
+    o_q, o_o, o_d, o_s, _ = om.cyclic_buddies(pts, qf, obj, 300, topk_mode="torch")
+    assert np.array_equal(got[1][0], o_q) and np.array_equal(got[1][1], o_o) and np.array_equal(got[1][2], o_d)

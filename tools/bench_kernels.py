@@ -41,6 +41,16 @@ def main():
             for tile in (0, 256, 128):   # 0 = the launcher's choice (incl. the tail split of near-whole round counts)
                 ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
                 print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+    if "gemmsplit" in what:   # the f16x3 mode's GEMMs: split-fp16 operands, three fp16 MFMAs per product (TF/s = fp32-product equivalent)
+        for name, n, k, epi, osc in (("qkv(bias)", 3 * D, D, 0, 16.0), ("proj(ls)", D, D, 3, 0.0), ("fc1(gelu)", 4 * D, D, 1, 4.0), ("fc2(ls)", D, 4 * D, 3, 0.0)):
+            a = ops.split16_pack(torch.randn(M, k, device=dev), 16.0, 64)
+            wf = torch.randn(n, k, device=dev) * 0.02
+            w = ops.split16_pack(wf, ops.pow2_scale(wf), 64)
+            bias, gamma = torch.randn(n, device=dev), torch.randn(n, device=dev)
+            out = torch.zeros(M, n, dtype=torch.float32, device=dev) if epi == 3 else torch.zeros(M, 2 * n, dtype=torch.float16, device=dev)
+            for rep in range(2):
+                ms = timeit(lambda: ops.gemm_split(a, w, bias, 1.0 / (16.0 * ops.pow2_scale(wf)), gamma=gamma, out=out, epilogue=epi, out_scale=osc, m_valid=B * N))
+                print(f"gemm f16x3 {name:10s} M={M} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "fp8" in what:
         for name, n, k, epi in (("qkv(bias)", 3 * D, D, 0), ("proj(ls)", D, D, 3), ("fc1(gelu)", 4 * D, D, 1), ("fc2(ls)", D, 4 * D, 3)):
             a = ops.quantize_fp8(torch.randn(M, k, device=dev), 100.0)
