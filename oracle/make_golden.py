@@ -302,7 +302,8 @@ def gen_extractor_noreg(ref):
     # the hub architectures through their SHORT names (layer 9) and one long name; 518 (table as is) and 420 (LM-O crop size)
     cases = (("vitl14", "dinov2_vitl14", 518, 8, 3), ("vitl14", "dinov2_vitl14", 420, 8, 2),
              ("vits14", "dinov2_vits14", 420, 4, 2), ("vitb14", "dinov2_vitb14", 518, 8, 3),
-             ("vitb14", "dinov2_version=vitb14_stride=14_facet=token_layer=11_norm=1", 420, 8, 2))
+             ("vitb14", "dinov2_version=vitb14_stride=14_facet=token_layer=11_norm=1", 420, 8, 2),
+             ("vitg14", "dinov2_vitg14", 224, 16, 1))    # BASELINE config 5's "ViT-g/14" without registers: SwiGLU FFN, 24 heads, interpolated table
     for version, name, S, cs, ss in cases:
         arch = ARCHS[version]
         sd = synthetic.make_vit_state_dict(arch, seed=1234)

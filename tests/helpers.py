@@ -36,7 +36,7 @@ def match_case_inputs(name):
     return c, g, repre, pts.numpy(), feats.numpy()
 
 
-NOREG_CASES = (("vitl14", 518), ("vitl14", 420), ("vits14", 420), ("vitb14", 518), ("vitb14", 420))
+NOREG_CASES = (("vitl14", 518), ("vitl14", 420), ("vits14", 420), ("vitb14", 518), ("vitb14", 420), ("vitg14", 224))
 
 
 def noreg_case(version, S):

@@ -18,19 +18,30 @@ from oracle import vit as ov
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def vitg_sd():
-    return synthetic.make_vit_state_dict(ARCHS["vitg14-reg"], seed=3)
+_SD = {}
 
 
-def test_vitg14_fp8_batch32_vs_oracle_c(vitg_sd):
-    arch, layer = ARCHS["vitg14-reg"], 4
-    name = f"dinov2_version=vitg14-reg_stride=14_facet=token_layer={layer}_norm=1"
+@pytest.fixture(params=["vitg14-reg", "vitg14"])   # BASELINE config 5 says "ViT-g/14": with the register tokens and, as literally named, without
+def version(request):
+    return request.param
+
+
+@pytest.fixture
+def vitg_sd(version):
+    if version not in _SD:
+        _SD.clear()            # one 1.1 B-parameter state dict in host memory at a time
+        _SD[version] = synthetic.make_vit_state_dict(ARCHS[version], seed=3)
+    return _SD[version]
+
+
+def test_vitg14_fp8_batch32_vs_oracle_c(vitg_sd, version):
+    arch, layer = ARCHS[version], 4
+    name = f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1"
     ex = feature_util.make_feature_extractor(name, state_dict=vitg_sd, precision="fp8").to("cuda")
     imgs = synthetic.make_crops(32, 518, seed=0)
     scales = ex.calibrate_fp8(imgs.cuda())
     fm = ex(imgs.cuda())["feature_maps"]
-    assert fm.shape == (32, 1536, 37, 37) and bool(torch.isfinite(fm).all())
+    assert fm.shape == (32, 1536, 37, 37) and bool(torch.isfinite(fm).all()) and ex.arch.registers == (4 if version.endswith("-reg") else 0)
     b = 7
     ref_c = ov.extractor_forward(vitg_sd, arch, imgs[b:b + 1], layer, True, fp8_act=scales)["feature_maps"][0]
     ref_32 = ov.extractor_forward(vitg_sd, arch, imgs[b:b + 1], layer, True)["feature_maps"][0]
@@ -38,7 +49,7 @@ def test_vitg14_fp8_batch32_vs_oracle_c(vitg_sd):
     scale = float(ref_32.abs().max())
     e_c, e_32 = float((got - ref_c).abs().max()) / scale, float((got - ref_32).abs().max()) / scale
     rms_32 = float((got - ref_32).pow(2).mean().sqrt()) / scale
-    print(f"\nViT-g/14-reg fp8, layer {layer}, crop {b} of 32: vs oracle C {e_c:.4f}, vs fp32 oracle max {e_32:.4f} rms {rms_32:.4f} (of the feature scale)")
+    print(f"\n{version} fp8, layer {layer}, crop {b} of 32: vs oracle C {e_c:.4f}, vs fp32 oracle max {e_32:.4f} rms {rms_32:.4f} (of the feature scale)")
     assert e_c < 5e-2       # same quantisation points: bf16-level agreement
     assert e_32 < 0.3 and rms_32 < 4e-2   # fp8 noise against the exact model
     # batch invariance with static scales: the crop alone == the crop inside the batch
@@ -46,8 +57,8 @@ def test_vitg14_fp8_batch32_vs_oracle_c(vitg_sd):
     assert torch.equal(ex1(imgs[b:b + 1].cuda())["feature_maps"][0].cpu(), got)
 
 
-def test_config5_share_fp8_engine_on_planted_bank(vitg_sd):
-    name = "dinov2_version=vitg14-reg_stride=14_facet=token_layer=39_norm=1"
+def test_config5_share_fp8_engine_on_planted_bank(vitg_sd, version):
+    name = f"dinov2_version={version}_stride=14_facet=token_layer=39_norm=1"
     B, T = 128, 50000
     ex32 = feature_util.make_feature_extractor(name, state_dict=vitg_sd, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, B, 518, 1, T, seed=5, crop_seed=9)
@@ -67,6 +78,6 @@ def test_config5_share_fp8_engine_on_planted_bank(vitg_sd):
     got8 = [res8.corresp_list(b) for b in range(B)]
     p32, p8 = workload.planted_stats(got32, wl.targets.tolist()), workload.planted_stats(got8, wl.targets.tolist())
     agree = workload.parity_stats(got8, got32)
-    print(f"\n[config5 share] planted: fp32 {p32} fp8 {p8}\n[config5 share] fp8 vs fp32 mode: {agree}")
+    print(f"\n[config5 share, {version}] planted: fp32 {p32} fp8 {p8}\n[config5 share] fp8 vs fp32 mode: {agree}")
     assert p32["planted_top5_in_order"] == B and p8["planted_top5_in_order"] == B
     assert agree["templates_equal"] == B and agree["corresp_overlap"] >= 0.85

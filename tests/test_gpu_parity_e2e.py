@@ -34,9 +34,11 @@ def _run(eng, wl, chunk):
     return out
 
 
-@pytest.mark.parametrize("config,batch,objects,templates,n_cpu", [("config2", 32, 1, 800, 3), ("config3", 256, 8, 800, 2)])
-def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, templates, n_cpu):
-    arch = ARCHS["vitl14-reg"]
+@pytest.mark.parametrize("config,batch,objects,templates,n_cpu,version", [("config2", 32, 1, 800, 3, "vitl14-reg"), ("config3", 256, 8, 800, 2, "vitl14-reg"),
+                                                                           ("config3", 256, 8, 800, 1, "vitl14")])   # ... and config 3 as literally named: no register tokens
+def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, templates, n_cpu, version):
+    arch = ARCHS[version]
+    NAME = f"dinov2_version={version}_stride=14_facet=token_layer=18_norm=1"
     ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, batch, 518, objects, templates, seed=11, crop_seed=3)
     bank = DeviceBank(wl.repres)
