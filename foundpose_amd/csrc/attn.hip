@@ -240,7 +240,10 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // same 256 queries, <= 128 VGPRs, 4 waves/SIMD: more waves to overlap, twice the LDS fragment traffic per flop).
 // NW = waves per block (default 512 / (64 QB): a 256-query block); QB = 2 with NW = 8 is a 512-query block: a staged K/V tile then serves
 // twice the queries (variant 3, measured in DESIGN section 5).  Each wave stages GW = 8 / NW of the tile's eight 8-key row groups.
-template <int QB, int NW = 8 / QB>
+// PF (variant 4, measurement): the NEXT tile's eight K fragments are read into registers under the current tile's P V MFMAs (its DMA was
+// issued at the top of this tile and has landed by then: the compiler drains vmcnt before the first transpose read anyway; one extra
+// barrier publishes the other waves' pieces), so the next tile's score MFMAs start without waiting for LDS.  Same arithmetic.
+template <int QB, int NW = 8 / QB, bool PF = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   constexpr int QBLK = NW * 32 * QB, GW = 8 / NW;
   __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
@@ -338,6 +341,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   // the LDS-DMA of the iteration (one full load latency exposed per tile)
   __builtin_amdgcn_s_waitcnt(0x0f70);
   __syncthreads();
+  bf16x8 kfn[PF ? 4 : 1][2];   // PF: the K fragments of the tile about to be scored
+  if constexpr (PF) {
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(KV[0][0], ks * 32 + l31, ds * 2 + kh);
+  }
   // one key tile; RAGGED (the last tile when N % 64 != 0) is a separate instantiation so that the full tiles carry no
   // masking code at all (inlined into one loop the compiler if-converts the mask into 120 selects per tile)
   auto tile = [&](int kt, auto ragged, auto qblocks) {
@@ -351,8 +361,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     // VALU-only stretch -- the kernel measured 1.5 % SLOWER: 362 vs 356 us; issued after the tile's first two K fragment reads: 344 vs 338.)
     if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
 #endif
+    bf16x8 pf[QC][4];
     if (active) {
-      __builtin_amdgcn_iglp_opt(1);  // the compiler's MFMA / LDS interleaving strategy 1 for the tile body: +0.5 % same-box (0, 2, 3: -1...-2 %)
+      if constexpr (!PF) __builtin_amdgcn_iglp_opt(1);  // the compiler's MFMA / LDS interleaving strategy 1 for the tile body: +0.5 % same-box (0, 2, 3: -1...-2 %); (its solver does not terminate on the PF body)
       // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
       f32x16 sacc[QC][2];
       // four independent accumulation chains (2 key halves x 2 query blocks) interleaved over the four 16-d steps (two chains, key
@@ -371,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           bf16x8 kf = qf[0][ds];
           kf[0] = (__bf16)(float)((kt + ks) & 3);
 #else
-          const bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
+          const bf16x8 kf = PF ? kfn[PF ? ds : 0][ks] : read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
 #endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
@@ -396,7 +407,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
         }
       }
 #endif
-      bf16x8 pf[QC][4];
 #pragma unroll
       for (int qb = 0; qb < QC; ++qb) {
         if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
@@ -469,6 +479,23 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           }
       }
       // ---- O^T += V^T P^T over 4 steps of 16 keys; one V^T fragment serves both query blocks
+    }
+    if constexpr (PF && !RAGGED) {
+      if (kt + 1 < nkt) {     // (block-uniform, inactive waves included) the next tile's DMA has landed in every wave: publish it
+        __builtin_amdgcn_s_waitcnt(0x0f70);
+        __syncthreads();
+      }
+    }
+    if (active) {
+      if constexpr (PF && !RAGGED) {
+        if (kt + 1 < nkt) {   // ... and read its K fragments under the P V MFMAs below
+          const char* Kn = KV[(kt + 1) & 1][0];
+#pragma unroll
+          for (int ds = 0; ds < 4; ++ds)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(Kn, ks * 32 + l31, ds * 2 + kh);
+        }
+      }
 #if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
       asm volatile("s_waitcnt lgkmcnt(0)"  // the asm reads above (the compiler does not count them)
                    : "+v"(vlo[0][0]), "+v"(vhi[0][0]), "+v"(vlo[0][1]), "+v"(vhi[0][1]), "+v"(vlo[1][0]), "+v"(vhi[1][0]), "+v"(vlo[1][1]), "+v"(vhi[1][1]),
@@ -1008,7 +1035,7 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
   if (dtype == FP_DTYPE_BF16) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && (a.out_fp8_scale > 0.f ? a.ld_out % 4 == 0 : a.ld_out % 8 == 0), "attention(bf16): leading dims must keep 16-byte alignment");
-    FP_REQUIRE(a.variant >= 0 && a.variant <= 3, "attention: unknown kernel variant %d", a.variant);
+    FP_REQUIRE(a.variant >= 0 && a.variant <= 4, "attention: unknown kernel variant %d", a.variant);
 #ifdef FP_ATTN_DEFAULT_VARIANT  // (measurement build for same-box A/B runs of the whole pipeline: that split where 0 was asked for)
     const int variant = a.variant == 0 ? FP_ATTN_DEFAULT_VARIANT : a.variant;
 #else
@@ -1022,6 +1049,7 @@ int attn_launch(const AttnArgs& a, int dtype, hipStream_t st) {
     if (w64 && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull) {
       const unsigned grid = (unsigned)(cdiv(sel ? a.max_sel : a.n_tok, variant == 3 ? 512 : 256) * a.heads * a.batch);
       if (variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
+      else if (variant == 4) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, true>), dim3(grid), dim3(256), 0, st, a);
       else if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {
