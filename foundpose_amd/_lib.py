@@ -126,7 +126,7 @@ def cosine_prefilter_scratch_floats(num_det: int, max_templates: int) -> int:
 def cyclic_scratch_bytes(pairs: int, q_max: int, p_max: int) -> int:
     """FP_CYCLIC_SCRATCH_BYTES of include/foundpose_amd.h."""
     tiles = 8 * pairs * (((p_max + 127) // 128) * q_max + ((q_max + 127) // 128) * p_max)
-    cand = 8 * pairs * (q_max + p_max) + 224 * pairs * max(q_max, p_max)
+    cand = 8 * pairs * (q_max + p_max) + 448 * pairs * max(q_max, p_max)
     return max(tiles, cand)
 
 
@@ -135,7 +135,7 @@ def knn_scratch_bytes(m: int, n: int, k: int) -> int:
     if k == 1:
         return m * 8
     if k <= 8:
-        return m * max(((n + 127) // 128) * k * 8, 352)
+        return m * max(((n + 127) // 128) * k * 8, 704)
     return m * n * 4
 
 

@@ -57,7 +57,7 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
 
 // The two-stage search of csrc/knn_cand.hip (fp16-MFMA candidate pass with a derived bound + exact re-scoring; outputs bit-identical to
 // the all-pairs exact tile) is built and tested but NOT the default: measured on the bench shapes it is slower than the exact-fp32 tile it
-// was meant to replace (word 3-NN 245 vs 218 us, cyclic tiles 421 vs 338 us: profiles/EXPERIMENTS.md "two-stage k-NN").  FP_KNN_CAND=1
+// was meant to replace (word 3-NN 234 vs 221 us, cyclic searches 419 vs 338 us: profiles/EXPERIMENTS.md "Two-stage k-NN").  FP_KNN_CAND=1
 // switches it on (read per call, so a test can compare both paths in one process).
 static bool knn_cand_enabled() {
   const char* e = getenv("FP_KNN_CAND");
@@ -76,7 +76,7 @@ int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, con
     memset(&c, 0, sizeof(c));
     c.A = q; c.B = db; c.ld = d; c.a_sqn = q_sqnorm; c.b_sqn = db_sqnorm; c.K = d; c.M = m; c.N = n;
     c.k = k; c.pairs = 1; c.row_stride = m; c.out_d2 = out_d2; c.out_idx = out_idx;
-    return knn_cand_launch(c, m, scratch, ST(stream));
+    return knn_cand_launch(c, m, n, scratch, ST(stream));
   }
   F32TileArgs a = zero_tile_args();
   a.A = q; a.lda = d; a.B = db; a.ldb = d; a.K = d; a.M = m; a.N = n;
@@ -193,9 +193,9 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
     kc.a_seg_off = q_off; kc.pair_a_div = n_slots; kc.b_seg_off = tpl_off; kc.pair_b_seg = tpl_ids; kc.pair_b_base = tpl_base;
     kc.k = 1; kc.pairs = pairs;
     kc.swap = 0; kc.row_stride = q_max; kc.out_keys = row_best;
-    TRY(knn_cand_launch(kc, q_max, cand, ST(stream)));
+    TRY(knn_cand_launch(kc, q_max, p_max, cand, ST(stream)));
     kc.swap = 1; kc.row_stride = p_max; kc.out_keys = col_best;
-    TRY(knn_cand_launch(kc, p_max, cand, ST(stream)));
+    TRY(knn_cand_launch(kc, p_max, q_max, cand, ST(stream)));
     c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max; c.row_parts = 1; c.col_parts = 1;
   } else {
   // partial nearest-neighbour tables, one slice per distance tile (no atomics, no preset): [pairs, col tiles, q_max] + [pairs, row tiles, p_max]

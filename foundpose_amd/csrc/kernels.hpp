@@ -57,7 +57,7 @@ struct KnnCandArgs {
 };
 size_t knn_cand_scratch_bytes(int k, long long rows);   // rows = pairs * row_stride
 bool knn_cand_supported(int k, int K);
-int knn_cand_launch(const KnnCandArgs& a, int max_rows, void* scratch, hipStream_t st);
+int knn_cand_launch(const KnnCandArgs& a, int max_rows, int max_db, void* scratch, hipStream_t st);   // max_db: the longest database segment (sizes the split)
 
 // ---------------------------------------------------------------- match.hip
 struct CyclicArgs {

@@ -28,8 +28,9 @@
 
 namespace {
 
-constexpr int KC_ROWS = 64;   // rows per workgroup (two 32-row MFMA blocks)
-constexpr int KC_LISTS = 4;   // partial candidate lists per row: (database half, k-half of the MFMA output layout)
+constexpr int KC_ROWS = 128;  // rows per workgroup: four waves x one 32-row MFMA block, all four sharing every staged database tile
+constexpr int KC_LISTS = 8;   // partial candidate lists per row: (database split <= 4, k-half of the MFMA output layout)
+constexpr int KC_SPLIT = 512; // database rows per split: a launch covers the database with up to 4 workgroups per row block
 constexpr int kc_cap(int k) { return k == 1 ? 6 : 10; }  // entries per partial list
 
 struct KcProblem {
@@ -70,6 +71,15 @@ FP_DEVICE KcProblem kc_problem(const KnnCandArgs& a, int pair) {
   return p;
 }
 
+// database rows [lo, hi) of split `sp` when the segment is cut into `ns` splits of whole 64-row staging steps
+FP_DEVICE void kc_split_range(int y_cnt, int ns, int sp, int& lo, int& hi) {
+  const int steps = (y_cnt + 63) >> 6, per = (steps + ns - 1) / ns;
+  lo = sp * per * 64;
+  hi = (sp + 1) * per * 64;
+  lo = lo < y_cnt ? lo : y_cnt;
+  hi = hi < y_cnt ? hi : y_cnt;
+}
+
 FP_DEVICE unsigned pack_f16x2_rne(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, f16x2));
 }
@@ -77,6 +87,8 @@ FP_DEVICE bool beyond_f16(float4 v) {  // true for |v| > 65504 and for NaN (the 
   return !(fabsf(v.x) <= 65504.f && fabsf(v.y) <= 65504.f && fabsf(v.z) <= 65504.f && fabsf(v.w) <= 65504.f);
 }
 
+// Stage 1.  grid (row blocks of 128, pairs, database splits).  A workgroup keeps its 128 rows as MFMA B fragments in registers (a wave: 32
+// rows) and streams its share of the database through LDS, 64 rows per step (fp32 -> fp16 on the way), two MFMA tiles per wave and step.
 template <int KMAX, int K>
 __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
   constexpr int CAP = kc_cap(KMAX);
@@ -86,18 +98,25 @@ __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
   char* ybuf = smem;                                // [2 stages][64 rows][RS]
   float* ynh = reinterpret_cast<float*>(smem + 2 * 64 * RS);   // [2][64]  -|y|^2 / 2 of the staged rows (-inf: past the segment)
   float* red = ynh + 128;                           // [4] block reduction, [4] = bad-database flag
-  float* kth = red + 8;                             // [2 database halves][2 row blocks][64 lanes]: the k-th best score each wave has seen for its rows
-  unsigned long long* lds_lists = reinterpret_cast<unsigned long long*>(kth + 256);   // [256 threads][CAP]: this thread's candidate list
-  const int pair = blockIdx.y;
+  unsigned long long* lds_lists = reinterpret_cast<unsigned long long*>(red + 8);   // [256 threads][CAP]: this thread's candidate list
+  const int pair = blockIdx.y, sp = blockIdx.z;
   const KcProblem p = kc_problem(a, pair);
   const int r0 = blockIdx.x * KC_ROWS;
   if (!p.live || r0 >= p.x_cnt) return;
+  int y_lo, y_hi;
+  kc_split_range(p.y_cnt, gridDim.z, sp, y_lo, y_hi);
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, kh = lane >> 5, rblk = wave & 1, half = wave >> 1;
-  const int row = r0 + rblk * 32 + l31;
+  const int l31 = lane & 31, kh = lane >> 5;
+  const int row = r0 + wave * 32 + l31;
   const bool row_live = row < p.x_cnt;
+  const size_t row_slot = (size_t)pair * a.row_stride + (row_live ? row : 0);
+  int2* cnt_out = reinterpret_cast<int2*>(a.counts) + row_slot * KC_LISTS + sp * 2 + kh;
+  if (y_lo >= y_hi) {                               // (block-uniform) an empty split of a short segment: empty lists, weakest threshold
+    if (row_live) *cnt_out = make_int2(0, __float_as_int(-INFINITY));
+    return;
+  }
 
-  // ---- the largest squared norm of the database segment
+  // ---- the largest squared norm of the database segment (the whole segment: one bound for all splits)
   float ym = 0.f;
   for (int j = tid; j < p.y_cnt; j += 256) ym = fmaxf(ym, p.ys[p.y_off + j]);
   ym = wave_max(ym);
@@ -131,25 +150,21 @@ __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
   int cnt = 0;
   bool over = false;
   float thr = -INFINITY;
-  kth[tid] = -INFINITY;                             // (published by the barrier behind the first staging step)
-  const size_t row_slot = (size_t)pair * a.row_stride + (row_live ? row : 0);
   unsigned long long* my = lds_lists + tid * CAP;    // (in LDS: a list is re-read when it fills -- from global memory that cost ~5 k cycles a time)
 
-  // ---- staging: 64 database rows per step (tile 2 tp for the waves of half 0, tile 2 tp + 1 for half 1), fp32 -> fp16 on the way
-  const int ntp = (p.y_cnt + 63) >> 6;
-  constexpr int f4_per_row = K >> 2, nld = K >> 4;   // float4 per thread and step = 64 K / 4 / 256
-  // (two half-steps per staged tile pair, so that only nld / 2 loads are in flight beside the 64 query-fragment registers: the first half
-  //  flies under the MFMAs, the second under the selection epilogue)
-  constexpr int HL = nld / 2;
+  // ---- staging: 64 database rows per step, fp32 -> fp16 on the way, in two half-steps so that only nld / 2 loads are in flight beside the
+  //      query-fragment registers: the first half flies under the MFMAs, the second under the selection epilogue
+  const int ntp = (y_hi - y_lo + 63) >> 6;
+  constexpr int f4_per_row = K >> 2, nld = K >> 4, HL = nld / 2;   // float4 per thread and step = 64 K / 4 / 256
   float4 pre[HL];
   bool bad_y = false;
   auto load = [&](int tp, int h) {
 #pragma unroll
     for (int i = 0; i < HL; ++i) {
-      const int idx = tid + (h * HL + i) * 256, r = idx / f4_per_row, c = idx - r * f4_per_row, j = tp * 64 + r;
-      // a row past the segment loads the segment's last row (its score is forced to -inf through ynh and it is never emitted): no select
-      // on the loaded value -- `cond ? load : 0` compiled to a branch and a wait per load, i.e. 16 serialized L2 round trips per step
-      pre[i] = *reinterpret_cast<const float4*>(p.Y + (size_t)(p.y_off + (j < p.y_cnt ? j : p.y_cnt - 1)) * a.ld + c * 4);
+      const int idx = tid + (h * HL + i) * 256, r = idx / f4_per_row, c = idx - r * f4_per_row, j = y_lo + tp * 64 + r;
+      // a row past the split loads the segment's last row (its score is forced to -inf through ynh and it is never emitted): no select on
+      // the loaded value -- `cond ? load : 0` compiled to a branch and a wait per load, i.e. 16 serialized L2 round trips per step
+      pre[i] = *reinterpret_cast<const float4*>(p.Y + (size_t)(p.y_off + (j < y_hi ? j : p.y_cnt - 1)) * a.ld + c * 4);
     }
   };
   auto store = [&](int tp, int buf, int h) {
@@ -160,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
       *reinterpret_cast<uint2*>(ybuf + (buf * 64 + r) * RS + c * 8) = make_uint2(pack_f16x2_rne(pre[i].x, pre[i].y), pack_f16x2_rne(pre[i].z, pre[i].w));
     }
     if (h == 0 && tid < 64) {
-      const int j = tp * 64 + tid;
-      ynh[buf * 64 + tid] = j < p.y_cnt ? -0.5f * p.ys[p.y_off + j] : -INFINITY;
+      const int j = y_lo + tp * 64 + tid;
+      ynh[buf * 64 + tid] = j < y_hi ? -0.5f * p.ys[p.y_off + j] : -INFINITY;
     }
   };
   load(0, 0);
@@ -172,73 +187,68 @@ __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
   for (int tp = 0; tp < ntp; ++tp) {
     const int buf = tp & 1;
     if (tp + 1 < ntp) load(tp + 1, 0);
-    const int j0 = tp * 64 + half * 32;             // first database row of this wave's tile
-    f32x16 acc;
-    const bool tile_live = j0 < p.y_cnt;            // (wave-uniform)
-    if (tile_live) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-      const char* yrow = ybuf + (buf * 64 + half * 32 + l31) * RS + 16 * kh;
+    for (int tl = 0; tl < 2; ++tl) {                  // the two 32-row tiles of the step
+      const int j0 = y_lo + tp * 64 + tl * 32;
+      if (j0 < y_hi) {                                // (block-uniform)
+        f32x16 acc;
 #pragma unroll
-      for (int s = 0; s < ksteps; ++s) {
-        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(yrow + 32 * s), qf[s], acc, 0, 0, 0);
-        if (K == 256 && (s & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // fragment reads hoisted four steps ahead at most: with 64 query + 64 staging
-      }                                                                     // registers live, all 16 reads in flight at once would spill
-    }
-    if (tp + 1 < ntp) {
-      store(tp + 1, buf ^ 1, 0);
-      load(tp + 1, 1);
-    }
-    if (tile_live) {
-      // acc[r] = dot~(database row j0 + m, this lane's row), m = (r & 3) + 8 (r >> 2) + 4 kh
-      const float* nh = ynh + buf * 64 + half * 32 + 4 * kh;
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        const char* yrow = ybuf + (buf * 64 + tl * 32 + l31) * RS + 16 * kh;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float s = acc[r] + nh[(r & 3) + 8 * (r >> 2)];
-        acc[r] = s;
-        float v = s;
+        for (int s = 0; s < ksteps; ++s)
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(yrow + 32 * s), qf[s], acc, 0, 0, 0);
+        // acc[r] = dot~(database row j0 + m, this lane's row), m = (r & 3) + 8 (r >> 2) + 4 kh
+        const float* nh = ynh + buf * 64 + tl * 32 + 4 * kh;
 #pragma unroll
-        for (int t = 0; t < KMAX; ++t) {             // descending insertion: the larger stays, the smaller moves on
-          const float hi = fmaxf(best[t], v), lo = fminf(best[t], v);
-          best[t] = hi;
-          v = lo;
-        }
-      }
-      // the row's k-th best score so far: this lane's, its k-half partner's (the other 16 rows of every tile), and what the waves of the
-      // other database half published (possibly one step old: any earlier value is a valid, merely weaker, bound)
-      float kb = fmaxf(best[KMAX - 1], __shfl_xor(best[KMAX - 1], 32, 64));
-      kth[(half * 2 + rblk) * 64 + lane] = kb;
-      kb = fmaxf(kb, kth[((half ^ 1) * 2 + rblk) * 64 + lane]);
-      thr = fminf(kb, s_cap) - win;
-      // hits of this tile as a 16-bit mask (branch-free), then ONE short wave-uniform loop over the set bits: on unstructured data some
-      // lane of the 64 has a hit for nearly every r, and a branch per r ran the emission body 14 times per tile
-      unsigned hits = 0;
+        for (int r = 0; r < 16; ++r) {
+          const float sc = acc[r] + nh[(r & 3) + 8 * (r >> 2)];
+          acc[r] = sc;
+          float v = sc;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) hits |= (acc[r] >= thr ? 1u : 0u) << r;
-      if (j0 + 32 > p.y_cnt) {                       // (wave-uniform: the segment's last tile) rows past the segment never count
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (j0 + (r & 3) + 8 * (r >> 2) + 4 * kh >= p.y_cnt) hits &= ~(1u << r);
-      }
-      if (!row_live) hits = 0;
-      while (__builtin_amdgcn_ballot_w64(hits != 0)) {
-        if (hits) {
-          const int r = __builtin_ctz(hits);
-          hits &= hits - 1;
-          float sc = acc[0];
-#pragma unroll
-          for (int q = 1; q < 16; ++q) sc = r == q ? acc[q] : sc;
-          if (cnt == CAP) {                          // full: the threshold has only risen since the entries were written -- drop those it has passed
-            int w = 0;
-            for (int e = 0; e < CAP; ++e) {
-              const unsigned long long v = my[e];
-              if (__uint_as_float((unsigned)(v >> 32)) >= thr) my[w++] = v;
-            }
-            cnt = w;
+          for (int t = 0; t < KMAX; ++t) {            // descending insertion: the larger stays, the smaller moves on
+            const float hi = fmaxf(best[t], v), lo = fminf(best[t], v);
+            best[t] = hi;
+            v = lo;
           }
-          if (cnt < CAP) my[cnt++] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * kh);
-          else over = true;                          // more rows inside the window than a list holds: stage 2 takes the row by brute force
         }
+        // the row's k-th best score so far: this lane's and its k-half partner's (the other 16 rows of every tile)
+        const float kb = fmaxf(best[KMAX - 1], __shfl_xor(best[KMAX - 1], 32, 64));
+        thr = fminf(kb, s_cap) - win;
+        // hits of this tile as a 16-bit mask (branch-free), then ONE short wave-uniform loop over the set bits: on unstructured data some
+        // lane of the 64 has a hit for nearly every r, and a branch per r ran the emission body 14 times per tile
+        unsigned hits = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hits |= (acc[r] >= thr ? 1u : 0u) << r;
+        if (j0 + 32 > y_hi) {                         // (block-uniform: the split's last tile) rows past it never count
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            if (j0 + (r & 3) + 8 * (r >> 2) + 4 * kh >= y_hi) hits &= ~(1u << r);
+        }
+        if (!row_live) hits = 0;
+        while (__builtin_amdgcn_ballot_w64(hits != 0)) {
+          if (hits) {
+            const int r = __builtin_ctz(hits);
+            hits &= hits - 1;
+            float sc = acc[0];
+#pragma unroll
+            for (int q = 1; q < 16; ++q) sc = r == q ? acc[q] : sc;
+            if (cnt == CAP) {                         // full: the threshold has only risen since the entries were written -- drop those it has passed
+              int w = 0;
+              for (int e = 0; e < CAP; ++e) {
+                const unsigned long long v = my[e];
+                if (__uint_as_float((unsigned)(v >> 32)) >= thr) my[w++] = v;
+              }
+              cnt = w;
+            }
+            if (cnt < CAP) my[cnt++] = ((unsigned long long)__float_as_uint(sc) << 32) | (unsigned)(j0 + (r & 3) + 8 * (r >> 2) + 4 * kh);
+            else over = true;                         // more rows inside the window than a list holds: stage 2 takes the row by brute force
+          }
+        }
+      }
+      if (tl == 0 && tp + 1 < ntp) {
+        store(tp + 1, buf ^ 1, 0);
+        load(tp + 1, 1);
       }
     }
     if (tp + 1 < ntp) store(tp + 1, buf ^ 1, 1);
@@ -248,16 +258,16 @@ __global__ __launch_bounds__(256, 2) void knn_cand_kernel(KnnCandArgs a) {
   __syncthreads();
   if (row_live) {
     const bool brute = over || bad_x || red[4] != 0.f;
-    // (count, the list's final threshold): stage 2 re-scores only the entries at or above the LARGEST of the row's four thresholds
-    reinterpret_cast<int2*>(a.counts)[row_slot * KC_LISTS + half * 2 + kh] = make_int2(brute ? -1 : cnt, __float_as_int(thr));
-    unsigned long long* out = a.lists + (row_slot * KC_LISTS + half * 2 + kh) * CAP;
+    // (count, the list's final threshold): stage 2 re-scores only the entries at or above the LARGEST of the row's thresholds
+    *cnt_out = make_int2(brute ? -1 : cnt, __float_as_int(thr));
+    unsigned long long* out = a.lists + (row_slot * KC_LISTS + sp * 2 + kh) * CAP;
     if (!brute)
       for (int e = 0; e < cnt; ++e) out[e] = my[e];
   }
 }
 
 // The exact key of (x, y): k-ascending fma chain, one accumulator -- the arithmetic of the all-pairs exact tile.  The chain is 256 dependent
-// fmas; the next 16 elements of both rows are loaded while the current 16 are consumed, so its latency is the chain's, not the loads'.
+// fmas; the next 16 elements of both rows are loaded while the current 16 are consumed.
 FP_DEVICE unsigned long long kc_exact_key(const float* __restrict__ x, const float* __restrict__ y, int K, float qn, float yn, int j) {
   float acc = 0.f;
   float4 xa[4], ya[4], xb[4], yb[4];
@@ -300,9 +310,12 @@ FP_DEVICE unsigned long long group16_min_u64(unsigned long long v) {
   return v;
 }
 
-// 16 lanes per row (a row has 4 .. ~12 candidates), 4 rows per wave, 16 rows per workgroup.
+// Stage 2.  16 lanes per row, 4 rows per wave, 16 rows per workgroup.  Lane `sub` of a row walks the list slots sub, sub + 16, ... (every
+// lane reads its own entries: no serialized bookkeeping), re-scores the ones that pass the filter with the exact chain and keeps its k
+// best keys; a 16-lane merge finishes the row.  (Measured alternatives, slower: one wave per row with the candidates' rows staged through
+// LDS, and four lanes per candidate handing the accumulator from quarter to quarter -- both serialize the collection of the candidates.)
 template <int KMAX>
-__global__ __launch_bounds__(256) void knn_rescore_kernel(KnnCandArgs a, int k) {
+__global__ __launch_bounds__(256) void knn_rescore_kernel(KnnCandArgs a, int k, int nsplit) {
   constexpr int CAP = kc_cap(KMAX);
   const int sub = threadIdx.x & 15;
   const long long rg = (long long)blockIdx.x * 16 + (threadIdx.x >> 4);
@@ -319,19 +332,24 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(KnnCandArgs a, int k) 
   for (int s = 0; s < KMAX; ++s) best[s] = ~0ull;
   if (live) {
     const int2* cn = reinterpret_cast<const int2*>(a.counts) + row_slot * KC_LISTS;
-    const int c0 = cn[0].x, c1 = cn[1].x, c2 = cn[2].x, c3 = cn[3].x;
-    // a list's threshold min(k-th best it knew of, |x|^2 / 2) - 2 eps only rose while it was written; every one of the four is a valid
-    // bound for the whole row (header: superset), so the largest filters all lists
-    const float thr = fmaxf(fmaxf(__int_as_float(cn[0].y), __int_as_float(cn[1].y)), fmaxf(__int_as_float(cn[2].y), __int_as_float(cn[3].y)));
-    const bool brute = (c0 | c1 | c2 | c3) < 0;
+    const int nl = nsplit * 2;
+    // a list's threshold min(k-th best it knew of, |x|^2 / 2) - 2 eps only rose while it was written; every one of them is a valid bound
+    // for the whole row (header: superset), so the largest filters all lists
+    bool brute = false;
+    float thr = -INFINITY;
+    for (int l = 0; l < nl; ++l) {
+      const int2 c = cn[l];
+      brute |= c.x < 0;
+      thr = fmaxf(thr, __int_as_float(c.y));
+    }
     const float* x = p.X + (size_t)(p.x_off + row) * a.ld;
     const float qn = p.xs[p.x_off + row];
-    const int total = brute ? p.y_cnt : c0 + c1 + c2 + c3;   // brute: the row against the whole segment (rare: see the header)
+    const int total = brute ? p.y_cnt : nl * CAP;     // brute: the row against the whole segment (rare: see the header); else every list slot
     for (int e = sub; e < total; e += 16) {
       int j = e;
       if (!brute) {
-        const int l = e < c0 ? 0 : (e < c0 + c1 ? 1 : (e < c0 + c1 + c2 ? 2 : 3));
-        const int pos = e - (l > 0 ? c0 : 0) - (l > 1 ? c1 : 0) - (l > 2 ? c2 : 0);
+        const int l = e / CAP, pos = e - l * CAP;
+        if (pos >= cn[l].x) continue;
         const unsigned long long ent = a.lists[(row_slot * KC_LISTS + l) * CAP + pos];
         if (!(__uint_as_float((unsigned)(ent >> 32)) >= thr)) continue;   // written under an earlier, weaker threshold
         j = (int)(ent & 0xffffffffu);
@@ -365,34 +383,36 @@ __global__ __launch_bounds__(256) void knn_rescore_kernel(KnnCandArgs a, int k) 
 }
 
 template <int KMAX, int K>
-int launch_kk(const KnnCandArgs& a, int max_rows, hipStream_t st) {
-  constexpr int lds = 2 * 64 * (K * 2 + 16) + 128 * 4 + 8 * 4 + 256 * 4 + 256 * kc_cap(KMAX) * 8;
+int launch_kk(const KnnCandArgs& a, int max_rows, int max_db, hipStream_t st) {
+  constexpr int lds = 2 * 64 * (K * 2 + 16) + 128 * 4 + 8 * 4 + 256 * kc_cap(KMAX) * 8;
   static FpDeviceOnce attr;
   fp_allow_dynamic_lds(attr, &knn_cand_kernel<KMAX, K>, lds);
-  hipLaunchKernelGGL((knn_cand_kernel<KMAX, K>), dim3(cdiv(max_rows, KC_ROWS), a.pairs), dim3(256), lds, st, a);
+  int nsplit = (max_db + KC_SPLIT - 1) / KC_SPLIT;
+  nsplit = nsplit < 1 ? 1 : (nsplit > 4 ? 4 : nsplit);
+  hipLaunchKernelGGL((knn_cand_kernel<KMAX, K>), dim3(cdiv(max_rows, KC_ROWS), a.pairs, nsplit), dim3(256), lds, st, a);
   FP_CHECK_LAUNCH("knn_cand");
   const long long waves = (long long)a.pairs * a.row_stride;
-  hipLaunchKernelGGL(knn_rescore_kernel<KMAX>, dim3((unsigned)((waves + 15) / 16)), dim3(256), 0, st, a, a.k);
+  hipLaunchKernelGGL(knn_rescore_kernel<KMAX>, dim3((unsigned)((waves + 15) / 16)), dim3(256), 0, st, a, a.k, nsplit);
   FP_CHECK_LAUNCH("knn_rescore");
   return FP_OK;
 }
 
 template <int KMAX>
-int launch_k(const KnnCandArgs& a, int max_rows, hipStream_t st) {
+int launch_k(const KnnCandArgs& a, int max_rows, int max_db, hipStream_t st) {
   switch (a.K) {
-    case 64: return launch_kk<KMAX, 64>(a, max_rows, st);
-    case 128: return launch_kk<KMAX, 128>(a, max_rows, st);
-    default: return launch_kk<KMAX, 256>(a, max_rows, st);
+    case 64: return launch_kk<KMAX, 64>(a, max_rows, max_db, st);
+    case 128: return launch_kk<KMAX, 128>(a, max_rows, max_db, st);
+    default: return launch_kk<KMAX, 256>(a, max_rows, max_db, st);
   }
 }
 
 }  // namespace
 
-size_t knn_cand_scratch_bytes(int k, long long rows) { return (size_t)rows * ((size_t)KC_LISTS * kc_cap(k) * 8 + KC_LISTS * 8); }
+size_t knn_cand_scratch_bytes(int k, long long rows) { return (size_t)rows * ((size_t)KC_LISTS * kc_cap(k) * 8 + KC_LISTS * 8); }   // k = 1: 448 B, else 704 B per row
 
 bool knn_cand_supported(int k, int K) { return k >= 1 && k <= 4 && (K == 64 || K == 128 || K == 256); }
 
-int knn_cand_launch(const KnnCandArgs& a_in, int max_rows, void* scratch, hipStream_t st) {
+int knn_cand_launch(const KnnCandArgs& a_in, int max_rows, int max_db, void* scratch, hipStream_t st) {
   KnnCandArgs a = a_in;
   FP_REQUIRE(knn_cand_supported(a.k, a.K), "knn_cand: k (%d) must be 1..4 and the dimension (%d) 64, 128 or 256", a.k, a.K);
   FP_REQUIRE(a.ld % 4 == 0 && a.pairs >= 1 && a.row_stride >= 1 && max_rows >= 1 && scratch, "knn_cand: bad arguments");
@@ -400,9 +420,9 @@ int knn_cand_launch(const KnnCandArgs& a_in, int max_rows, void* scratch, hipStr
   a.lists = reinterpret_cast<unsigned long long*>(scratch);
   a.counts = reinterpret_cast<int*>(a.lists + (size_t)rows * KC_LISTS * kc_cap(a.k));
   switch (a.k) {
-    case 1: return launch_k<1>(a, max_rows, st);
-    case 2: return launch_k<2>(a, max_rows, st);
-    case 3: return launch_k<3>(a, max_rows, st);
-    default: return launch_k<4>(a, max_rows, st);
+    case 1: return launch_k<1>(a, max_rows, max_db, st);
+    case 2: return launch_k<2>(a, max_rows, max_db, st);
+    case 3: return launch_k<3>(a, max_rows, max_db, st);
+    default: return launch_k<4>(a, max_rows, max_db, st);
   }
 }

@@ -59,7 +59,7 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
 
 /* Exact brute-force L2 k-NN: KNN.fit + KNN.search with metric "l2" (utils/knn_util.py:38-106).
  * q [m,d], db [n,d], precomputed squared norms of both.  Scratch: FP_KNN_SCRATCH_BYTES(m, n, k): k == 1: m*8 bytes; 2 <= k <= 8:
- * m * max(ceil(n/128) * k * 8, 352) bytes (candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared),
+ * m * max(ceil(n/128) * k * 8, 704) bytes (candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared),
  * out_idx [m,k] int32, ascending, ties -> lowest index, (inf, -1) past the database size.
  * Opt-in (environment FP_KNN_CAND=1; measured slower than the all-pairs tile on the benchmark shapes, so not the default): 2 <= k <= 4
  * with d = 64 / 128 / 256, n >= 256 (the visual-word search: k = 3, d = 256) runs in two stages -- an fp16-MFMA candidate pass whose
@@ -67,7 +67,7 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
  * bit-identical to the all-pairs exact-fp32 tile that serves every other case; rows the bound cannot cover (values beyond the fp16
  * range, more near-ties than a candidate list holds) are computed by exact brute force inside the second stage. */
 #define FP_KNN_SCRATCH_BYTES(m, n, k) \
-  ((k) == 1 ? (size_t)(m) * 8 : ((k) <= 8 ? (size_t)(m) * ((size_t)(((n) + 127) / 128) * (k) * 8 > 352 ? (size_t)(((n) + 127) / 128) * (k) * 8 : 352) : (size_t)(m) * (n) * 4))
+  ((k) == 1 ? (size_t)(m) * 8 : ((k) <= 8 ? (size_t)(m) * ((size_t)(((n) + 127) / 128) * (k) * 8 > 704 ? (size_t)(((n) + 127) / 128) * (k) * 8 : 704) : (size_t)(m) * (n) * 4))
 int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n,
               int d, int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream);
 
@@ -141,7 +141,7 @@ int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, 
 #define FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) \
   (8 * (size_t)(pairs) * ((size_t)(((p_max) + 127) / 128) * (size_t)(q_max) + (size_t)(((q_max) + 127) / 128) * (size_t)(p_max)))
 #define FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max) \
-  (8 * (size_t)(pairs) * ((size_t)(q_max) + (size_t)(p_max)) + 224 * (size_t)(pairs) * (size_t)((q_max) > (p_max) ? (q_max) : (p_max)))
+  (8 * (size_t)(pairs) * ((size_t)(q_max) + (size_t)(p_max)) + 448 * (size_t)(pairs) * (size_t)((q_max) > (p_max) ? (q_max) : (p_max)))
 #define FP_CYCLIC_SCRATCH_BYTES(pairs, q_max, p_max) \
   (FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) > FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max) ? FP_CYCLIC_SCRATCH_TILES(pairs, q_max, p_max) \
                                                                                              : FP_CYCLIC_SCRATCH_CAND(pairs, q_max, p_max))

@@ -14,10 +14,10 @@ for (m, n, K, k) in [(70, 300, 64, 3), (1000, 2048, 256, 3), (16544, 2048, 256, 
     call("fp_knn_l2", ptr(q), ptr(qn), m, ptr(db), ptr(dn), n, K, k, ptr(scratch), ptr(d2), ptr(idx), stream())
     torch.cuda.synchronize()
     cap = 10
-    raw = scratch[m * 4 * cap * 8: m * 4 * cap * 8 + m * 32].view(torch.int32).reshape(m, 4, 2).cpu()
+    raw = scratch[m * 8 * cap * 8: m * 8 * cap * 8 + m * 64].view(torch.int32).reshape(m, 8, 2).cpu()[:, :2 * min(4, max(1, (n + 511) // 512))]
     counts = raw[:, :, 0].numpy()
     thr = raw[:, :, 1].contiguous().view(torch.float32).max(dim=1).values
-    ents = scratch[:m * 4 * cap * 8].view(torch.int64).reshape(m, 4, cap).cpu()
+    ents = scratch[:m * 8 * cap * 8].view(torch.int64).reshape(m, 8, cap).cpu()[:, :raw.shape[1]]
     sc = (ents >> 32).to(torch.int32).view(torch.float32) if False else torch.from_numpy((ents.numpy() >> 32).astype(np.int32).view(np.float32))
     valid = torch.arange(cap)[None, None, :] < torch.from_numpy(counts)[:, :, None]
     kept = ((sc >= thr[:, None, None]) & valid).sum(dim=(1, 2)).float()

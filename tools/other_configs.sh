@@ -9,3 +9,8 @@ python bench.py --mask full --cpu-detections 1 2>/dev/null | tail -1 > gpurun_ou
 for f in config3 config5_share full_mask; do python -c "
 import json; d=json.load(open('gpurun_out/${tag}_bench_$f.json')); p=d.get('parity_mode') or {}
 print('$f', d['value'], d['ms_per_step'], 'parity_mode', p.get('value'), p.get('index_exact_vs_fp32_mode'), (p.get('vs_fp32_mode') or {}).get('corresp_equal'), (p.get('vs_fp32_mode') or {}).get('slots_compared'))"; done
+# the reference's default backbone family (no register tokens) at the headline shape, and a batch whose GEMM tile counts are whole rounds
+python bench.py --version vitl14 --cpu-detections 1 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_vitl14_noreg.json
+python bench.py --batch 35 --no-cpu-baseline --parity-precision none 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_batch35.json
+for f in vitl14_noreg batch35; do python -c "
+import json; d=json.load(open('gpurun_out/${tag}_bench_$f.json')); print('$f', d['value'], d['ms_per_step'], d['roofline_vit_end_to_end']['frac'])"; done
