@@ -30,22 +30,22 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 # HBM-side bytes of one launch of the dominant kernel template from the rocprofv3 --pmc passes of THIS code (per the
 # guide's gfx950 corrections); keyed by (version, size, batch, precision).  Source file + commit are reported next to it.
 PMC_TRAFFIC = {
-    # gemm_bf16_kernel<RESID> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 395.0 KiB + WRITE_SIZE 266 567.7 KiB) x 1024
-    ("vitl14-reg", 518, 32, "bf16"): 820590285,
+    # gemm_bf16_kernel<RESID> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 372.6 KiB + WRITE_SIZE 266 565.0 KiB) x 1024
+    ("vitl14-reg", 518, 32, "bf16"): 820541133,
 }
-PMC_TRAFFIC_SOURCE = ("profiles/r3_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
-                      "final round-3 checkout; the kernel's code is unchanged since round 2: 819.7 MB there)")
+PMC_TRAFFIC_SOURCE = ("profiles/r4_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
+                      "final round-4 checkout; round 3: 820.6 MB, round 2: 819.7 MB -- the kernel's code is unchanged)")
 
 
 # Matrix-pipe utilisation of the ViT forward as the counters report it: sum of SQ_VALU_MFMA_BUSY_CYCLES over the bf16 step's ViT launches /
 # (1024 SIMDs x their GRBM_GUI_ACTIVE / 8 cycles), from the rocprofv3 --pmc pass of THIS code over `python bench.py --skip-probes`.  It is
 # higher than the FLOP fraction of the nominal 2.5 PFLOP/s because the chip holds ~2.0 of its 2.4 GHz under this load (DVFS).
 PMC_MFMA_UTIL = {
-    # per kernel: RESID 0.399 (144 launches x 551.3 k cycles), fc1 0.445 (76 x 769.0 k), attention 0.369 (76 x 637.9 k), qkv 0.467 (76 x 565.7 k),
-    # hooked block's 128^2 launches 0.256 (8 x 389.7 k), patch embed 0.222 (4 x 248.2 k), ln_finalize 0 (152 x 31.8 k)
-    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.406, "resid_gemm": 0.399, "fc1": 0.445, "qkv": 0.467, "attention": 0.369},
+    # per kernel: RESID 0.402 (144 launches x 547.5 k cycles), fc1 0.449 (76 x 762.5 k), attention 0.368 (76 x 638.8 k), qkv 0.469 (76 x 563.1 k),
+    # hooked block's 128^2 launches 0.267 (8 x 373.5 k), patch embed 0.220 (4 x 249.8 k), ln_finalize 0 (152 x 31.9 k)
+    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.405, "resid_gemm": 0.402, "fc1": 0.449, "qkv": 0.469, "attention": 0.368},
 }
-PMC_MFMA_UTIL_SOURCE = "profiles/r3_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-3 checkout)"
+PMC_MFMA_UTIL_SOURCE = "profiles/r4_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-4 checkout)"
 
 
 def synthetic_disc_patches(size):
