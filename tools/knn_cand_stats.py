@@ -1,3 +1,5 @@
+"""Candidate statistics of the opt-in two-stage k-NN (csrc/knn_cand.hip): brute-force rows, emitted and re-scored candidates per row,
+equality with the CPU oracle.   FP_KNN_CAND=1 python tools/knn_cand_stats.py   (on the GPU box)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
