@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8, FP_F16X3 = 0, 1, 2, 3
 SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -38,7 +38,7 @@ class VitModel(C.Structure):
 class VitWorkspace(C.Structure):
     _fields_ = [
         ("patches", vp), ("x", vp), ("y", vp), ("qkv", vp), ("h", vp), ("a8", vp),
-        ("ld_y", i32), ("ld_h", i32), ("ld_qkv", i32), ("m_pad", i32), ("m_patch_pad", i32), ("xb", vp), ("stats", vp), ("sat", vp),
+        ("ld_y", i32), ("ld_h", i32), ("ld_qkv", i32), ("m_pad", i32), ("m_patch_pad", i32), ("xb", vp), ("stats", vp), ("sat", vp), ("xl", vp),
     ]
 
 

@@ -316,7 +316,11 @@ int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.out = out; a.ldo = ldo; a.tile_override = tile;
-  if (epilogue == GEMM_EPI_RESID_F32) {  // producer: x += acc + bias, plus bf16(x) and the partial row sums
+  if (epilogue == GEMM_EPI_RESID_HILO) {  // producer on the (hi, lo) stream: `out` is the LOW-half array (bf16, row stride ld_xb), xb the high halves
+    FP_REQUIRE(xb && stats, "fp_gemm_bf16_ln: epilogue 8 needs xb, out (= the low halves) and stats");
+    a.xb = reinterpret_cast<__bf16*>(xb); a.ld_xb = ld_xb; a.xl = reinterpret_cast<__bf16*>(out); a.stats_out = reinterpret_cast<float2*>(stats);
+    a.out = nullptr;
+  } else if (epilogue == GEMM_EPI_RESID_F32) {  // producer: x += acc + bias, plus bf16(x) and the partial row sums
     FP_REQUIRE((xb == nullptr) == (stats == nullptr), "fp_gemm_bf16_ln: xb and stats go together");
     FP_REQUIRE(!xb || (N % 128 == 0 && ld_xb >= N && ld_xb % 4 == 0), "fp_gemm_bf16_ln: N must be a multiple of 128 and ld_xb cover the row");
     a.xb = reinterpret_cast<__bf16*>(xb); a.ld_xb = ld_xb; a.stats_out = reinterpret_cast<float2*>(stats);
@@ -549,8 +553,13 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     FP_REQUIRE(ws->xb && ws->stats, "fp_vit_forward: ln_fold needs workspace xb and stats");
     FP_REQUIRE(D % 128 == 0, "fp_vit_forward: ln_fold needs dim %% 128 == 0");
     ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
-    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st));
+    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st, ws->xl));
   }
+  // Blocks in FRONT of the hooked one keep the residual stream as (hi, lo) bf16 arrays (ws->xb, ws->xl) instead of fp32 + a bf16 copy: the
+  // residual GEMMs then read 4 and write 4 bytes per element instead of 4 + 6 (hi IS the next GEMM's A operand).  16 mantissa bits per update
+  // against the 8 of the bf16 operands everything is multiplied in.  The hooked block itself runs on an fp32 stream rebuilt from the pair
+  // (all rows, or the selected rows only), so the engine's token-selected form and the full form stay bit-identical.
+  const bool hilo = fold && ws->xl != nullptr;
   FP_REQUIRE(mode == VIT_FULL || fold || sp, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold, or an f16x3 model");
   float2* ln_row = stats + (size_t)ln_parts * ws->m_pad;  // (rstd, mean * rstd) per row, behind the partial-sum slots
   int rows_valid = Mtok, rows_pad = ws->m_pad;  // the selected tail of the hooked block narrows these to the compact rows
@@ -563,7 +572,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
     g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
-    if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; }
+    if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; g.xl = reinterpret_cast<__bf16*>(ws->xl); }
     return gemm_bf16_launch(epi, g, st);
   };
 
@@ -583,7 +592,8 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;
       TRY(attn_launch(as, FP_DTYPE_BF16, st));
       float* xs = reinterpret_cast<float*>(ws->qkv);  // qkv is dead after the attention: [num_sel, D] fp32 rows of the stream
-      TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xs, st));
+      if (hilo && layer > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, sel->rows, sel->num, D, xs, st));   // the blocks in front left (hi, lo) pairs
+      else TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xs, st));
       rows_valid = sel->num;
       rows_pad = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
       TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, true));
@@ -598,17 +608,20 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     if (fold) {
       // x += ls1 * proj(attn(ln1(x))): qkv reads bf16(x) and normalises in its epilogue; proj refreshes bf16(x) + row sums
       FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
+      const bool pair = hilo && i < layer;            // a block in front of the hooked one: (hi, lo) stream
+      const int resid = pair ? GEMM_EPI_RESID_HILO : GEMM_EPI_RESID_F32;
+      if (hilo && i == layer && i > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, nullptr, Mtok, D, ws->x, st));   // VIT_FULL: the hooked block's fp32 stream, all rows
       TRY(finalize());
       TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
       TRY(attn_launch(at, FP_DTYPE_BF16, st));
-      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, GEMM_EPI_RESID_F32, nullptr, true));
+      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, resid, nullptr, true));
       // x += ls2 * fc2(act(fc1(ln2(x))))
       TRY(finalize());
       if (m->ffn_swiglu)
         TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false));
       else
         TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false));
-      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, ws->x, D, GEMM_EPI_RESID_F32, nullptr, i < layer));
+      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, ws->x, D, resid, nullptr, i < layer));
       continue;
     }
     // x += ls1 * proj(attn(ln1(x)))

@@ -111,6 +111,15 @@ FP_DEVICE float row32_sum(float v) {
   return v;
 }
 
+// ... and over aligned groups of 16 lanes (valid in every lane of the group)
+FP_DEVICE float row16_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xF, 0xF, true));  // row_ror:4
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xF, 0xF, true));  // row_ror:8
+  return v;
+}
+
 // BM x BN block tile, WM x WN waves, each wave (BM/WM) x (BN/WN) = TM x TN MFMA tiles of 32x32.
 // F8: the operands are OCP fp8 (e4m3) instead of bf16.  An fp8 row of K elements is addressed as a bf16 row of K/2
 // elements (the host passes K/2, lda/2, ldw/2), so a K-tile is the same 128-B-per-row LDS image holding 128 k-values and
@@ -135,7 +144,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   static_assert(!(SP && F8) && (!SPOUT || SP), "split-fp16 and fp8 operands exclude each other; a split output needs split operands");
   static_assert(SPOUT == (SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "f16x3: the half-precision epilogues write split rows");
   constexpr int NW = WM * WN, NT = NW * 64, TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr bool RESID = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_RESID_F32;  // fp32 residual read-modify-write epilogues
+  constexpr bool HILO = EPI == GEMM_EPI_RESID_HILO;  // the residual stream as (hi, lo) bf16 arrays: hi IS the next GEMM's A operand
+  constexpr bool RESID = EPI == GEMM_EPI_LS_RESID_F32 || EPI == GEMM_EPI_RESID_F32 || HILO;  // residual read-modify-write epilogues
   constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
   // DMA issue is asymmetric on the 8-wave tile: only the waves of row wm == 0 fetch (every SIMD hosts one wave of each
   // row).  A global/buffer_load..lds blocks its wave for ~60-180 issue cycles; when all eight waves issue their pieces
@@ -389,8 +399,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       static_assert(SLAB_CHUNKS % NT == 0, "slab chunks must divide evenly over the block");
       float4 ext[PASSES];
       int orow_i[PASSES];  // output row (< 2^31), -1: a padding row (kept as one 32-bit value per pass: the epilogue is register-bound)
+      // (hi, lo) stream: a thread owns EIGHT consecutive columns per pass -- one 16-B load and one 16-B store per array, four memory
+      // instructions per 8 elements where the fp32 form issues six (the tail of a residual tile is bound by its memory instructions,
+      // not by its bytes: with 4-column chunks and 8-B accesses the pair measured 0.8 % slower than fp32 + bf16 copy, 1072 vs 1081)
+      constexpr int CPR8 = HILO ? OUT_COLS / 8 : 1, PASS8 = HILO ? SLAB_ROWS * CPR8 / NT : 1;
+      uint4 exh[PASS8], exl[PASS8];
+      if constexpr (HILO) {
+        static_assert(!HILO || (SLAB_ROWS * CPR8) % NT == 0, "slab chunks must divide evenly over the block");
   #pragma unroll
-      for (int it = 0; it < PASSES; ++it) {
+        for (int it = 0; it < PASS8; ++it) {
+          const int id = tid + it * NT;
+          const int r = id / CPR8, c = id - r * CPR8;
+          const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
+          const bool okr = gm_row < a.M_valid;
+          if (okr) {
+            exh[it] = *reinterpret_cast<const uint4*>(a.xb + (size_t)gm_row * a.ld_xb + n0 + c * 8);
+            exl[it] = *reinterpret_cast<const uint4*>(a.xl + (size_t)gm_row * a.ld_xb + n0 + c * 8);
+          }
+          orow_i[it] = okr ? gm_row : -1;
+        }
+      }
+  #pragma unroll
+      for (int it = 0; it < (HILO ? 0 : PASSES); ++it) {
         const int id = tid + it * NT;
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
         const int gm_row = m0 + (r >> 5) * (BM / WM) + tm * 32 + (r & 31);
@@ -489,8 +519,38 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       }
       __syncthreads();
       // (b) slab -> global, whole rows
+      if constexpr (HILO) {
   #pragma unroll
-      for (int it = 0; it < PASSES; ++it) {
+        for (int it = 0; it < PASS8; ++it) {
+          const int id = tid + it * NT;
+          const int r = id / CPR8, c = id - r * CPR8;
+          if (orow_i[it] < 0) continue;
+          const size_t orow_it = (size_t)orow_i[it];
+          const char* sp = slab + r * SLAB_STRIDE + c * 32;
+          const float4 s0 = *reinterpret_cast<const float4*>(sp), s1v = *reinterpret_cast<const float4*>(sp + 16);
+          const unsigned hw[4] = {exh[it].x, exh[it].y, exh[it].z, exh[it].w}, lw[4] = {exl[it].x, exl[it].y, exl[it].z, exl[it].w};
+          float v[8] = {s0.x, s0.y, s0.z, s0.w, s1v.x, s1v.y, s1v.z, s1v.w};
+          unsigned ho[4], lo[4];
+          float s1 = 0.f, s2 = 0.f;
+  #pragma unroll
+          for (int q = 0; q < 4; ++q) {   // x = hi + lo (exact in fp32: lo lies within 2^-9 of hi's last place), x' = x + (acc + bias)
+            v[2 * q] += __uint_as_float(hw[q] << 16) + __uint_as_float(lw[q] << 16);
+            v[2 * q + 1] += __uint_as_float(hw[q] & 0xffff0000u) + __uint_as_float(lw[q] & 0xffff0000u);
+            ho[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
+            lo[q] = pack_bf16x2(v[2 * q] - __uint_as_float(ho[q] << 16), v[2 * q + 1] - __uint_as_float(ho[q] & 0xffff0000u));
+            s1 += v[2 * q] + v[2 * q + 1];
+            s2 += fmaf(v[2 * q], v[2 * q], v[2 * q + 1] * v[2 * q + 1]);
+          }
+          *reinterpret_cast<uint4*>(a.xb + orow_it * a.ld_xb + n0 + c * 8) = make_uint4(ho[0], ho[1], ho[2], ho[3]);
+          *reinterpret_cast<uint4*>(a.xl + orow_it * a.ld_xb + n0 + c * 8) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+          // partial sums over 128-column groups = 16 lanes x 8 columns; the same tree whatever the tile width
+          s1 = row16_sum(s1);
+          s2 = row16_sum(s2);
+          if ((c & 15) == 15) a.stats_out[(size_t)(n0 / 128 + (c >> 4)) * a.M + orow_it] = make_float2(s1, s2);
+        }
+      }
+  #pragma unroll
+      for (int it = 0; it < (HILO ? 0 : PASSES); ++it) {
         const int id = tid + it * NT;
         const int r = id / CHUNKS_PER_ROW, c = id - r * CHUNKS_PER_ROW;
         if (orow_i[it] < 0) continue;
@@ -720,6 +780,9 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
     case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16>(a, st);
     case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
     case GEMM_EPI_RESID_F32: return launch<GEMM_EPI_RESID_F32>(a, st);
+    case GEMM_EPI_RESID_HILO:
+      FP_REQUIRE(a.xb && a.xl && a.stats_out && a.N % 128 == 0 && a.ld_xb >= a.N && a.ld_xb % 4 == 0, "gemm_bf16: the (hi, lo) residual epilogue needs xb, xl, stats and N %% 128 == 0");
+      return launch<GEMM_EPI_RESID_HILO>(a, st);
     case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
     case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);
     case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16>(a, st);

@@ -116,6 +116,8 @@ enum : int {
   GEMM_EPI_BIAS_F32 = 5,      // out(f32) = acc + bias
   GEMM_EPI_RESID_F32 = 7,     // out(f32) += acc + bias (LayerScale already folded into W and bias) + the LayerNorm-fold outputs (xb, stats)
   GEMM_EPI_SWIGLU_BF16 = 6,   // SwiGLU FFN: columns interleaved (x1_j, x2_j) -> out(bf16)[:, j] = silu(x1_j) * x2_j, [M, N/2]
+  GEMM_EPI_RESID_HILO = 8,    // as RESID_F32 with the residual stream held as TWO bf16 arrays: x = xb (hi) + xl (lo); reads both, adds acc + bias,
+                              // writes hi' = bf16(x'), lo' = bf16(x' - hi') and the LayerNorm row sums -- no fp32 stream, no separate bf16 copy
 };
 
 struct GemmBf16Args {
@@ -136,6 +138,7 @@ struct GemmBf16Args {
   // producer (LS_RESID): besides the fp32 residual stream it writes xb = bf16(x) -- the next GEMM's A operand -- and per
   // row the partial sums (sum x, sum x^2) of every 128-column group into stats[(column / 128) * M + row]
   __bf16* xb; int ld_xb;
+  __bf16* xl;                 // RESID_HILO: the low halves of the stream (row stride ld_xb), read and written next to xb
   float2* stats_out;
   // consumer (BIAS / GELU / SwiGLU epilogues; W carries the LayerNorm gain, bias the LayerNorm shift):
   //   out = epi(rstd_r * (acc - mean_r * colsum_n) + bias_n);  ln_stats [M] = (rstd_r, mean_r * rstd_r) from ln_finalize_launch
@@ -195,7 +198,10 @@ int query_select_launch(const unsigned char* masks, int B, int H, int W, const i
 // x [rows, dim] fp32 -> xb = bf16(x) [rows, ld_xb] and stats[0 * stats_stride + row] = (sum x, sum x^2), slots 1..parts-1 zero
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);
-int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st);
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st,
+                         void* xl = nullptr);   // xl: also write lo = bf16(x - bf16(x)) (row stride ld_xb)
+// out[r] = float(xb[row]) + float(xl[row]) (fp32 [n, dim]); row = rows[r], or r when rows is null: the (hi, lo) stream back as fp32
+int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st);
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
                     int out_dtype, hipStream_t st, float out_scale = 1.f);  // out_scale: FP_DTYPE_F16X3 rows only

@@ -359,14 +359,19 @@ __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __re
 // Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
 // LayerScale GEMM has produced yet.  One wave per row; slot 0 of the partial-sum table gets the whole row, the others zero.
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, int rows, int dim, __bf16* __restrict__ xb, int ld_xb,
-                                                            float2* __restrict__ stats, int stats_stride, int parts) {
+                                                            float2* __restrict__ stats, int stats_stride, int parts, __bf16* __restrict__ xl) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * dim;
   float s1 = 0.f, s2 = 0.f;
   for (int c = lane * 4; c < dim; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
-    *reinterpret_cast<uint2*>(xb + (size_t)row * ld_xb + c) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    const uint2 h = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    *reinterpret_cast<uint2*>(xb + (size_t)row * ld_xb + c) = h;
+    if (xl)   // the (hi, lo) residual stream: lo = bf16(x - hi)
+      *reinterpret_cast<uint2*>(xl + (size_t)row * ld_xb + c) =
+          make_uint2(pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u)),
+                     pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u)));
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
   }
@@ -501,6 +506,20 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
   for (int c = lane; c < dim / 4; c += 64) dst[c] = src[c];
 }
 
+// the (hi, lo) bf16 residual stream back as fp32 rows: out[r] = hi[row] + lo[row], row = rows[r] (the selected tokens of the hooked block) or r
+__global__ __launch_bounds__(256) void hilo_rows_kernel(const __bf16* __restrict__ xb, const __bf16* __restrict__ xl, int ld, const int* __restrict__ rows,
+                                                        int n, int dim, float* __restrict__ out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (r >= n) return;
+  const size_t row = rows ? (size_t)rows[r] : (size_t)r;
+  for (int c = lane * 4; c < dim; c += 256) {
+    const uint2 h = *reinterpret_cast<const uint2*>(xb + row * ld + c), l = *reinterpret_cast<const uint2*>(xl + row * ld + c);
+    *reinterpret_cast<float4*>(out + (size_t)r * dim + c) =
+        make_float4(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u),
+                    __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+  }
+}
+
 __global__ void prefix_tokens_kernel(const float* __restrict__ prefix, int n_prefix, int dim, float* __restrict__ tokens, int batch, int n_tok) {
   const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   const long long total = (long long)batch * n_prefix * dim;
@@ -630,11 +649,20 @@ int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, i
   return FP_OK;
 }
 
-int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st) {
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st, void* xl) {
   FP_REQUIRE(dim % 4 == 0 && ld_xb % 4 == 0 && parts >= 1 && parts <= 64, "rowstats_cast: dim / ld_xb must be multiples of 4, parts in [1, 64]");
   if (rows == 0) return FP_OK;
-  hipLaunchKernelGGL(rowstats_cast_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts);
+  hipLaunchKernelGGL(rowstats_cast_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
+                     reinterpret_cast<__bf16*>(xl));
   FP_CHECK_LAUNCH("rowstats_cast");
+  return FP_OK;
+}
+
+int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st) {
+  FP_REQUIRE(xb && xl && out && dim % 4 == 0 && ld % 4 == 0, "hilo_rows: bad arguments");
+  if (n == 0) return FP_OK;
+  hipLaunchKernelGGL(hilo_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(xb), reinterpret_cast<const __bf16*>(xl), ld, rows, n, dim, out);
+  FP_CHECK_LAUNCH("hilo_rows");
   return FP_OK;
 }
 

@@ -374,6 +374,9 @@ class DinoFeatureExtractor(torch.nn.Module):
                 bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=torch.bfloat16, device=dev))
                 bufs.append(torch.zeros(a.dim // 128 + 1, m_pad, 2, dtype=torch.float32, device=dev))
                 ws.xb, ws.stats = ptr(bufs[-2]), ptr(bufs[-1])
+                if os.environ.get("FP_RESID_HILO", "1") != "0":   # low halves of the (hi, lo) residual stream of the blocks in front of the hooked one (A/B switch)
+                    bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=torch.bfloat16, device=dev))
+                    ws.xl = ptr(bufs[-1])
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
             ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
             ws.ld_y, ws.ld_h = (em * a.dim + self._ld_pad, em * a.hidden + self._ld_pad) if self._ld_pad else (0, 0)

@@ -148,6 +148,20 @@ def gemm_bf16_resid_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: 
     return xb, stats
 
 
+def gemm_bf16_resid_hilo(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, xb: torch.Tensor, xl: torch.Tensor, tile: int = 0, m_valid: Optional[int] = None):
+    """Producer of the folded-LayerNorm chain on the (hi, lo) residual stream (epilogue 8): x = xb + xl (bf16 [M, N] each, updated in place) += a @ w.T + bias,
+    xb = bf16(x), xl = bf16(x - xb).  -> stats [N / 128, M, 2]."""
+    require_cuda(a, w, bias, xb, xl)
+    M, K = a.shape
+    N = w.shape[0]
+    if xb.dtype != torch.bfloat16 or xl.dtype != torch.bfloat16 or xb.stride(0) != xl.stride(0):
+        raise ValueError("xb / xl are bf16 arrays with one row stride")
+    stats = torch.zeros(N // 128, M, 2, dtype=torch.float32, device=a.device)
+    call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(xl), xl.stride(0),
+         8 | (tile << 8), None, None, ptr(xb), xb.stride(0), ptr(stats), stream())
+    return stats
+
+
 def ln_finalize(stats: torch.Tensor, dim: int, eps: float = 1e-6) -> torch.Tensor:
     """stats [parts, M, 2] -> ln_row [M, 2] = (rstd, mean * rstd)."""
     require_cuda(stats)

@@ -42,7 +42,7 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of 
  *  multiplies like any other number, so a modest scale costs nothing on O(1) activations and leaves three decades of head room for
  *  the outlier channels of real checkpoints.) */
 
-#define FP_ABI_VERSION 13
+#define FP_ABI_VERSION 14
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -263,6 +263,10 @@ typedef struct {
                     Counted per reporting thread, not per element: non-zero means "at least one live output row clamped".
                     The attention output and the softmax probabilities of the f16x3 mode cannot clamp (a convex combination of v rows
                     that fit their scale; p <= 2) and do not report; padding rows never report. */
+  void* xl;      /* ln_fold only, may be NULL: [m_pad, D] bf16 (row stride ld_y), the LOW halves of the residual stream.  When given, the blocks in
+                    front of the hooked one keep the stream as the pair (xb, xl) -- x = hi + lo, hi' = bf16(x'), lo' = bf16(x' - hi'): 16 mantissa
+                    bits per update -- and their residual GEMMs read 4 + write 4 bytes per element instead of 4 + 6 (no fp32 read-modify-write
+                    beside a separate bf16 copy); the hooked block runs on an fp32 stream rebuilt from the pair.  NULL: fp32 stream throughout. */
 } fp_vit_workspace;
 
 /* images [B,3,H,W] fp32 in [0,1] -> ws->x holds the output of blocks[layer] for every token
@@ -334,6 +338,8 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
 /* The GEMMs of a block with the LayerNorm folded in (fp_vit_model.ln_fold), exported for unit tests and benchmarks.
+ * epilogue 8 (producer on the (hi, lo) stream, fp_vit_workspace.xl): x = xb + out (both bf16 [M, ld_xb]: high and LOW halves), x' = x + acc + bias,
+ *   xb = bf16(x'), out = bf16(x' - xb), stats as for epilogue 7.
  * epilogue 7 (producer, proj / fc2 with LayerScale folded into W and bias): out(f32) += acc + bias; if xb != NULL also
  *   xb[M, ld_xb] = bf16(out) and stats[(col / 128) * M + row] = (sum, sum of squares) of the row over that 128-column
  *   group (float2 per slot, N / 128 slots of M rows).

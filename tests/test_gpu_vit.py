@@ -642,6 +642,51 @@ def test_folded_layernorm_gemm_pair(tile, M, D, N2):
         assert float((out - ref).abs().max()) < 1.5 * 2 ** -8 * float(ref.abs().max()), (epi, tile)
 
 
+@pytest.mark.parametrize("tile,M,D", [(128, 256, 256), (256, 512, 1024), (128, 384, 384)])
+def test_residual_gemm_on_the_hi_lo_stream(tile, M, D):
+    """Epilogue 8: the residual stream as two bf16 arrays (hi, lo).  Against epilogue 7 run on the fp32 stream x = hi + lo: the new high
+    halves ARE epilogue 7's bf16 copy (both round the same fp32 x') and the row sums agree to fp32 rounding; hi' + lo' reproduces x' to
+    16 mantissa bits; rows past M_valid are untouched."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + D)
+    h = torch.randn(M, 2 * D, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(D, 2 * D, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    b = torch.randn(D, generator=g).cuda()
+    x0 = torch.randn(M, D, generator=g) * 3 + 0.7
+    x0[:, 5] *= 200.0                                              # a massive-activation channel
+    hi = x0.to(torch.bfloat16)
+    lo = (x0 - hi.float()).to(torch.bfloat16)
+    x32 = (hi.float() + lo.float()).cuda()                        # the stream the pair represents (exact in fp32)
+    xb7, st7 = ops.gemm_bf16_resid_ln(h, w, b, x32, tile=tile, m_valid=M - 3)
+    xb8, xl8 = hi.clone().cuda(), lo.clone().cuda()
+    st8 = ops.gemm_bf16_resid_hilo(h, w, b, xb8, xl8, tile=tile, m_valid=M - 3)
+    assert torch.equal(xb8[:M - 3], xb7[:M - 3])
+    torch.testing.assert_close(st8[:, :M - 3], st7[:, :M - 3], rtol=2e-6, atol=1e-4)    # same addends, another tree (16 lanes x 8 columns vs 32 x 4)
+    got = xb8.float() + xl8.float()
+    err = (got[:M - 3] - x32[:M - 3]).abs() / x32[:M - 3].abs().clamp_min(1e-3)
+    assert float(err.max()) < 2 ** -15                            # hi: 8 bits, lo: 8 more (round to nearest twice)
+    assert torch.equal(xb8[M - 3:].cpu(), hi[M - 3:]) and torch.equal(xl8[M - 3:].cpu(), lo[M - 3:])
+
+
+@pytest.mark.parametrize("hilo", ["0", "1"])
+def test_hi_lo_stream_end_to_end_switch(monkeypatch, hilo):
+    """FP_RESID_HILO=0 keeps the fp32 residual stream in every block; =1 (default) holds it as (hi, lo) bf16 pairs in front of the hooked
+    block.  Both stay within the bf16 mode's distance from oracle B, and the engine's token-selected form == the full form bit for bit
+    in either setting (the hooked block always runs on an fp32 stream)."""
+    from foundpose_amd import feature_util
+    monkeypatch.setenv("FP_RESID_HILO", hilo)
+    arch = ARCHS["vits14-reg"]
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=5_norm=1"
+    sd = synthetic.make_vit_state_dict(arch, seed=4)
+    imgs = synthetic.make_crops(3, 224, seed=1)
+    ex = feature_util.make_feature_extractor(name, state_dict=sd, precision="bf16").to("cuda")
+    fm = ex(imgs.cuda())["feature_maps"].cpu()
+    ref_b = ov.extractor_forward(sd, arch, imgs, 5, True, quant="bf16")["feature_maps"]
+    assert rel_err(fm, ref_b) < 1.5e-2
+    one = ex(imgs[1:2].cuda())["feature_maps"].cpu()
+    assert torch.equal(one[0], fm[1])                              # batch invariance
+
+
 @pytest.mark.parametrize("version,size,precision", [("vits14-reg", 224, "fp32"), ("vits14-reg", 224, "bf16"), ("vitl14-reg", 518, "bf16")])
 def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
     """fp_vit_sample_features (final LayerNorm + bilinear sampling at the query points only, straight from the residual
