@@ -30,20 +30,21 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 # HBM-side bytes of one launch of the dominant kernel template from the rocprofv3 --pmc passes of THIS code (per the
 # guide's gfx950 corrections); keyed by (version, size, batch, precision).  Source file + commit are reported next to it.
 PMC_TRAFFIC = {
-    # gemm_bf16_kernel<RESID> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 372.6 KiB + WRITE_SIZE 266 565.0 KiB) x 1024
-    ("vitl14-reg", 518, 32, "bf16"): 820541133,
+    # gemm_bf16_kernel<RESID_HILO> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 328.4 KiB + WRITE_SIZE 178 620.9 KiB) x 1024
+    # (the fp32-stream kernel it replaced wrote 266 565 KiB: 6 B per element of the stream against 4 now)
+    ("vitl14-reg", 518, 32, "bf16"): 730396365,
 }
 PMC_TRAFFIC_SOURCE = ("profiles/r4_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
-                      "final round-4 checkout; round 3: 820.6 MB, round 2: 819.7 MB -- the kernel's code is unchanged)")
+                      "final round-4 checkout; the fp32-stream RESID kernel of rounds 2-3 and of this round's first pass: 819.7 / 820.6 / 820.5 MB)")
 
 
 # Matrix-pipe utilisation of the ViT forward as the counters report it: sum of SQ_VALU_MFMA_BUSY_CYCLES over the bf16 step's ViT launches /
 # (1024 SIMDs x their GRBM_GUI_ACTIVE / 8 cycles), from the rocprofv3 --pmc pass of THIS code over `python bench.py --skip-probes`.  It is
 # higher than the FLOP fraction of the nominal 2.5 PFLOP/s because the chip holds ~2.0 of its 2.4 GHz under this load (DVFS).
 PMC_MFMA_UTIL = {
-    # per kernel: RESID 0.402 (144 launches x 547.5 k cycles), fc1 0.449 (76 x 762.5 k), attention 0.368 (76 x 638.8 k), qkv 0.469 (76 x 563.1 k),
-    # hooked block's 128^2 launches 0.267 (8 x 373.5 k), patch embed 0.220 (4 x 249.8 k), ln_finalize 0 (152 x 31.9 k)
-    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.405, "resid_gemm": 0.402, "fc1": 0.449, "qkv": 0.469, "attention": 0.368},
+    # per kernel: RESID_HILO 0.421 (144 launches x 522.8 k cycles), fc1 0.456 (76 x 749.8 k), attention 0.371 (76 x 634.6 k), qkv 0.471 (76 x 561.1 k),
+    # hooked block's 128^2 launches 0.259 (8 x 385.1 k), patch embed 0.221 (4 x 249.5 k), ln_finalize / rowstats_cast / hilo_rows 0 (152 x 31.4 k, 4 x 165.6 k, 4 x 120.3 k)
+    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.415, "resid_gemm": 0.421, "fc1": 0.456, "qkv": 0.471, "attention": 0.371},
 }
 PMC_MFMA_UTIL_SOURCE = "profiles/r4_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-4 checkout)"
 
