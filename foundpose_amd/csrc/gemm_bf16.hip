@@ -160,7 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   constexpr int NISSUE = ASYM ? NW / 2 : NW;
   constexpr int A_INSTR = BM / 8 / NISSUE, B_INSTR = BN / 8 / NISSUE;  // DMA instructions per issuing wave per K-tile
   constexpr int PIECES = A_INSTR + B_INSTR;
-  static_assert(PIECES % 4 == 0, "staging split");
+  static_assert(PIECES % 4 == 0 || (!F8 && !SP), "staging split");  // the bf16 loop also takes uneven quarters (the 320-row tile: 18 pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, kh = lane >> 5;
@@ -183,6 +183,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     m0 = (lid / tiles_n) * BM;
     n0 = (lid % tiles_n) * BN;
   }
+  if (m0 >= a.M_valid) return;  // a tile of padding rows only (M is padded to whole tiles of every shape in use): nothing of it is ever stored
   const int kb = 0, ke = a.K / BK;
 
 #ifdef FP_GEMM_TIMELINE  // tools/build_variant.sh -DFP_GEMM_TIMELINE: per-workgroup shader-clock stamps (never in the shipped library)
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           } else
           if (more) {
 #pragma unroll
-            for (int q = 0; q < PER_KS; ++q) stage_piece(ks * PER_KS + q, t + 1, nxt);
+            for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + 1, nxt);
           }
           const int chunk = ks * 2 + kh;
           // the compiler's MFMA / LDS-read interleaving strategy 1 for this scheduling region: +0.75 % on the pipeline in same-box A/B
@@ -687,7 +688,7 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   // alternations: 1043.0 detections/s against 1038.2 with 8 x 4 everywhere (profiles/EXPERIMENTS.md)
   const int wide8 = (a.N / BN) % 8 == 0;
   const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
-  if (env_rast && rr * gn == 32 && BM == 256 && (a.N / BN) % gn == 0 && (a.N / BN) > 4 && grid >= 512) {
+  if (env_rast && rr * gn == 32 && BM >= 256 && (a.N / BN) % gn == 0 && (a.N / BN) > 4 && grid >= 512) {
     a.rast_r = rr; a.rast_gn = gn;
     grid = ((a.M / BM + rr - 1) / rr) * ((a.N / BN) / gn) * 32;
   }
@@ -712,6 +713,27 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   // (Measured and dropped, round 3: sending the m-tiles that hold the few tiles beyond a whole number of rounds -- qkv at the bench batch:
   //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us.  The stragglers of a single launch start while other CUs
   //  are still inside their eighth tile and cost far less than a round; a dependent second launch costs its own latency.)
+  // 320 x 256 tiles for the wide bf16 outputs (qkv, fc1): 160 accumulator registers per lane (256 VGPRs, no spill), 10 % fewer operand bytes
+  // through the L1 fill path per flop -- the path that bounds the main loop -- and another round count.  Same k order per output element:
+  // the results are bit-identical to the 256^2 tile's.  Isolated, M = 44 800 (the bench batch): qkv 273.8 -> 259.9 us, fc1 380.6 -> 365.9 us.
+  // Chosen when M is a whole number of both tile heights (the extractor pads to 1280 rows when that is cheap) and this estimate favours it:
+  // a launch costs its whole rounds plus min(1, f + 0.25) for a last round filled to f (its stragglers start while other CUs are still in
+  // their previous tile), times the tile height, times 0.94 for the taller tile (calibrated on the four launches above: 8.3 / 6.7 rounds of
+  // qkv, 11 / 8.9 of fc1).
+  if constexpr (!SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16)) {
+    const bool ok320 = a.M % 320 == 0 && a.N % 256 == 0;
+    bool take = force == 320 && ok320;
+    if (force == 0 && use_big && ok320) {
+      auto cost = [&](int bm, float eff) {
+        const float r = (float)(((a.M_valid + bm - 1) / bm) * (a.N / 256)) / (float)cus;
+        const float whole = floorf(r), f = r - whole;
+        return (whole + (f > 0.f ? fminf(1.f, f + 0.25f) : 0.f)) * (float)bm * eff;
+      };
+      static const bool off = getenv("FP_GEMM_TILE320") && atoi(getenv("FP_GEMM_TILE320")) == 0;  // A/B switch
+      take = !off && cost(320, 0.94f) < cost(256, 1.f);
+    }
+    if (take) return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+  }
   if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
 }
