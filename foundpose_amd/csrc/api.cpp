@@ -365,6 +365,8 @@ static int gemm_fp8_impl(const void* A, int lda, const void* W, int ldw, int M, 
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = col_scale; a.out = out; a.ldo = ldo;
   a.out_scale = out_scale; a.sat = sat;
+  a.tile_override = (epilogue >> 8) & 0xfff;  // tuning bits: 256 / 320 force that block tile (benchmarks, tests)
+  FP_REQUIRE(a.tile_override == 0 || a.tile_override == 256 || a.tile_override == 320, "fp_gemm_fp8: bad tile override %d", a.tile_override);
   return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
 }
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   constexpr int NISSUE = ASYM ? NW / 2 : NW;
   constexpr int A_INSTR = BM / 8 / NISSUE, B_INSTR = BN / 8 / NISSUE;  // DMA instructions per issuing wave per K-tile
   constexpr int PIECES = A_INSTR + B_INSTR;
-  static_assert(PIECES % 4 == 0 || (!F8 && !SP), "staging split");  // the bf16 loop also takes uneven quarters (the 320-row tile: 18 pieces)
+  static_assert(PIECES % 2 == 0, "staging split");  // quarters of the piece list per k-step (uneven for the 320-row tile: 18 pieces), halves in the fp8 / f16x3 loops
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN, l31 = lane & 31, kh = lane >> 5;
@@ -239,7 +239,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 
     {
       // ---- main loop: one barrier per K-tile, the next tile's DMA issued in four slices ahead of each k-step's MFMAs
-      constexpr int PER_KS = PIECES / 4;
       for (int t = kb; t < ke; ++t) {
         const int cur = (t - kb) & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t have landed
@@ -256,7 +255,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           for (int s = 0; s < 2; ++s) {
             if (more) {
 #pragma unroll
-              for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s * 2 * PER_KS + q, t + 1, nxt);
+              for (int q = 0; q < PIECES / 2; ++q) stage_piece(s * (PIECES / 2) + q, t + 1, nxt);
             }
             const int chunk = s * 4 + kh * 2;
             __builtin_amdgcn_iglp_opt(1);  // as in the bf16 loop below (+0.5 % on the fp8 pipeline)
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           for (int s2 = 0; s2 < 2; ++s2) {  // two 16-wide k-steps of the 32 k-values of this tile
             if (more) {
 #pragma unroll
-              for (int q = 0; q < 2 * PER_KS; ++q) stage_piece(s2 * 2 * PER_KS + q, t + 1, nxt);
+              for (int q = 0; q < PIECES / 2; ++q) stage_piece(s2 * (PIECES / 2) + q, t + 1, nxt);
             }
             const int ch = s2 * 2 + kh;  // hi chunk of this lane's 8 k-values; the lo chunk sits 4 chunks (64 B) further
             __builtin_amdgcn_iglp_opt(1);  // as in the bf16 loop below: +1 % on the f16x3 pipeline (strategy 0: -0.7 %)
@@ -700,6 +699,30 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   return FP_OK;
 }
 
+// 320 x 256 tiles: 160 accumulator registers per lane (<= 256 VGPRs, no spill), 10 % fewer operand bytes through the L1 fill path per flop --
+// the path that bounds the main loop -- and another round count.  Same k order per output element: results bit-identical to the 256^2 tile's.
+// Isolated, M = 44 800 (the bench batch): qkv 273.8 -> 259.9 us, fc1 380.6 -> 365.9 us; pipeline +1.5 % same-box.  Chosen when M is a whole
+// number of both tile heights (the extractor pads to 1280 rows when that is cheap) and this estimate favours it: a launch costs its whole
+// rounds plus min(1, f + 0.25) for a last round filled to f (after a few rounds the CUs have drifted apart and the stragglers of the last
+// round start while others are still inside their previous tile), times the tile height, times 0.94 for the taller tile -- calibrated on
+// the four launches above: 8.3 / 6.7 rounds of qkv, 11 / 8.9 of fc1.  Launches of fewer than `min_rounds` whole rounds keep the 256^2 tile:
+// with little drift a nearly idle last round costs a whole one (the residual GEMMs of the bench batch, 552 tiles = 2.16 rounds: fc2 395 vs
+// 354 us, proj 151 vs 137).  FP_GEMM_TILE320=0 is the A/B switch.
+static bool tall_tile_wins(const GemmBf16Args& a, int min_rounds) {
+  static const bool off = getenv("FP_GEMM_TILE320") && atoi(getenv("FP_GEMM_TILE320")) == 0;
+  if (off || a.M % 320 != 0 || a.M % 256 != 0 || a.N % 256 != 0) return false;
+  const int cus = fp_num_cus();
+  float whole320 = 0.f;
+  auto cost = [&](int bm, float eff, float* whole_out) {
+    const float r = (float)(((a.M_valid + bm - 1) / bm) * (a.N / 256)) / (float)cus;
+    const float whole = floorf(r), f = r - whole;
+    if (whole_out) *whole_out = whole;
+    return (whole + (f > 0.f ? fminf(1.f, f + 0.25f) : 0.f)) * (float)bm * eff;
+  };
+  const float c320 = cost(320, 0.94f, &whole320), c256 = cost(256, 1.f, nullptr);
+  return whole320 >= (float)min_rounds && c320 < c256;
+}
+
 // Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
 // otherwise 128x128 (4 waves, 2 blocks/CU).
 template <int EPI, bool SP = false, bool SPOUT = false>
@@ -713,26 +736,9 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   // (Measured and dropped, round 3: sending the m-tiles that hold the few tiles beyond a whole number of rounds -- qkv at the bench batch:
   //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us.  The stragglers of a single launch start while other CUs
   //  are still inside their eighth tile and cost far less than a round; a dependent second launch costs its own latency.)
-  // 320 x 256 tiles for the wide bf16 outputs (qkv, fc1): 160 accumulator registers per lane (256 VGPRs, no spill), 10 % fewer operand bytes
-  // through the L1 fill path per flop -- the path that bounds the main loop -- and another round count.  Same k order per output element:
-  // the results are bit-identical to the 256^2 tile's.  Isolated, M = 44 800 (the bench batch): qkv 273.8 -> 259.9 us, fc1 380.6 -> 365.9 us.
-  // Chosen when M is a whole number of both tile heights (the extractor pads to 1280 rows when that is cheap) and this estimate favours it:
-  // a launch costs its whole rounds plus min(1, f + 0.25) for a last round filled to f (its stragglers start while other CUs are still in
-  // their previous tile), times the tile height, times 0.94 for the taller tile (calibrated on the four launches above: 8.3 / 6.7 rounds of
-  // qkv, 11 / 8.9 of fc1).
-  if constexpr (!SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16)) {
-    const bool ok320 = a.M % 320 == 0 && a.N % 256 == 0;
-    bool take = force == 320 && ok320;
-    if (force == 0 && use_big && ok320) {
-      auto cost = [&](int bm, float eff) {
-        const float r = (float)(((a.M_valid + bm - 1) / bm) * (a.N / 256)) / (float)cus;
-        const float whole = floorf(r), f = r - whole;
-        return (whole + (f > 0.f ? fminf(1.f, f + 0.25f) : 0.f)) * (float)bm * eff;
-      };
-      static const bool off = getenv("FP_GEMM_TILE320") && atoi(getenv("FP_GEMM_TILE320")) == 0;  // A/B switch
-      take = !off && cost(320, 0.94f) < cost(256, 1.f);
-    }
-    if (take) return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+  if constexpr (!SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_RESID_HILO)) {
+    if ((force == 320 && a.M % 320 == 0 && a.N % 256 == 0) || (force == 0 && use_big && tall_tile_wins(a, EPI == GEMM_EPI_RESID_HILO ? 8 : 4)))
+      return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   }
   if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
@@ -749,18 +755,19 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   FP_REQUIRE(a.bias != nullptr && a.gamma != nullptr, "gemm_fp8: bias and the per-column scale are required");
   FP_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.ldo % 4 == 0, "gemm_fp8: leading dims must keep 16-byte alignment");
   a.K /= 2; a.lda /= 2; a.ldw /= 2;  // an fp8 row addressed as a bf16 row of half the length (see the kernel header)
+  const bool tall = a.tile_override == 320 ? a.M % 320 == 0 : (a.tile_override == 0 && tall_tile_wins(a, 4));   // (the residual epilogue keeps 256 rows)
   if (a.out_scale > 0.f) {  // fp8 output
     FP_REQUIRE(a.ldo % 16 == 0, "gemm_fp8: an fp8 output needs ldo %% 16 == 0");
-    if (epi == GEMM_EPI_GELU_BF16) return launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true, true>(a, st);
-    if (epi == GEMM_EPI_SWIGLU_BF16) return launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true, true>(a, st);
+    if (epi == GEMM_EPI_GELU_BF16) return tall ? launch_cfg<GEMM_EPI_GELU_BF16, 320, 256, 2, 4, true, true>(a, st) : launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true, true>(a, st);
+    if (epi == GEMM_EPI_SWIGLU_BF16) return tall ? launch_cfg<GEMM_EPI_SWIGLU_BF16, 320, 256, 2, 4, true, true>(a, st) : launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true, true>(a, st);
     fp_set_error("gemm_fp8: fp8 output exists for the GELU and SwiGLU epilogues only (epilogue %d)", epi);
     return FP_ERR_UNSUPPORTED;
   }
   switch (epi) {
-    case GEMM_EPI_BIAS_BF16: return launch_cfg<GEMM_EPI_BIAS_BF16, 256, 256, 2, 4, true>(a, st);
-    case GEMM_EPI_GELU_BF16: return launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_BIAS_BF16: return tall ? launch_cfg<GEMM_EPI_BIAS_BF16, 320, 256, 2, 4, true>(a, st) : launch_cfg<GEMM_EPI_BIAS_BF16, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_GELU_BF16: return tall ? launch_cfg<GEMM_EPI_GELU_BF16, 320, 256, 2, 4, true>(a, st) : launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true>(a, st);
     case GEMM_EPI_LS_RESID_F32: return launch_cfg<GEMM_EPI_LS_RESID_F32, 256, 256, 2, 4, true>(a, st);
-    case GEMM_EPI_SWIGLU_BF16: return launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true>(a, st);
+    case GEMM_EPI_SWIGLU_BF16: return tall ? launch_cfg<GEMM_EPI_SWIGLU_BF16, 320, 256, 2, 4, true>(a, st) : launch_cfg<GEMM_EPI_SWIGLU_BF16, 256, 256, 2, 4, true>(a, st);
   }
   fp_set_error("gemm_fp8: epilogue %d is not available for fp8 operands", epi);
   return FP_ERR_UNSUPPORTED;

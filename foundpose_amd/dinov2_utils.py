@@ -359,7 +359,7 @@ class DinoFeatureExtractor(torch.nn.Module):
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
             m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
             m1280 = (B * ntok + 1279) // 1280 * 1280
-            if self.fold_layernorm and m1280 * 100 <= m_pad * 103:   # ... and 320-row tiles for qkv / fc1 when whole tiles of both heights cost < 3 % more rows
+            if (self.fold_layernorm or self.precision == "fp8") and m1280 * 100 <= m_pad * 103:   # ... and 320-row tiles for qkv / fc1 when whole tiles of both heights cost < 3 % more rows
                 m_pad = m1280                                        # (tiles of padding rows only leave at once)
             mp_pad = (B * np_ + 255) // 256 * 256
             bufs = [

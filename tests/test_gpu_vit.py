@@ -606,6 +606,29 @@ def test_layernorm_fold_vs_kernel_sequence(version, size, layer):
     assert d < 2e-2 and ea < 3e-2 and ea < 1.5 * eb + 2e-3
 
 
+@pytest.mark.parametrize("M,N,K,m_valid", [(1280, 512, 128, 1280), (3840, 3072, 1024, 3140), (2560, 4096, 1024, 1374)])
+def test_gemm_320_row_tile_equals_256_row_tile(M, N, K, m_valid):
+    """The 320 x 256 block tile of the wide bf16 outputs (qkv, fc1) walks k in the same order per output element as the 256^2 tile: bias / GELU
+    outputs, plain and in the folded-LayerNorm form, are bit-identical; rows past m_valid (incl. whole tiles of padding rows, which leave
+    at once) stay untouched."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias, cs = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    ln_row = torch.stack([1 + torch.rand(M, generator=g), torch.randn(M, generator=g)], 1).contiguous().cuda()
+    for epi in (0, 1):
+        outs = []
+        for tile in (256, 320):
+            out = torch.full((M, N), 7.0, dtype=torch.bfloat16, device="cuda")
+            ops.gemm_bf16(a, w, bias, out=out, epilogue=epi | (tile << 8), m_valid=m_valid)
+            outs.append(out)
+        assert torch.equal(outs[0], outs[1]) and bool(torch.all(outs[1][m_valid:] == 7.0)) and bool(torch.any(outs[1][:m_valid] != 7.0))
+        f256 = ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, tile=256, m_valid=m_valid)
+        f320 = ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, tile=320, m_valid=m_valid)
+        assert torch.equal(f256[:m_valid], f320[:m_valid])
+
+
 @pytest.mark.parametrize("tile,M,D,N2", [(128, 256, 256, 512), (256, 512, 1024, 1024), (128, 384, 384, 1152)])
 def test_folded_layernorm_gemm_pair(tile, M, D, N2):
     """The two halves of the LayerNorm fold at op level: the residual GEMM (epilogue 7) emits bf16(x) and the row's partial

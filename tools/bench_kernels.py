@@ -41,6 +41,16 @@ def main():
             for tile in ((0, 256, 320, 256, 320) if epi in (0, 1) else (0, 256, 128)):   # 0 = the launcher's choice
                 ms = timeit(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
                 print(f"gemm {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+    if "gemmhilo" in what:   # the residual GEMMs on the (hi, lo) stream (epilogue 8), 256- vs 320-row tiles
+        for name, n, k in (("proj", D, D), ("fc2", D, 4 * D)):
+            a = torch.randn(M, k, device=dev).to(torch.bfloat16)
+            w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+            bias = torch.randn(n, device=dev)
+            xb = torch.randn(M, n, device=dev).to(torch.bfloat16)
+            xl = (torch.randn(M, n, device=dev) * 0.003).to(torch.bfloat16)
+            for tile in (256, 320, 256, 320):
+                ms = timeit(lambda: ops.gemm_bf16_resid_hilo(a, w, bias, xb, xl, tile=tile, m_valid=B * N))
+                print(f"gemm hilo {name:5s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
     if "gemmsplit" in what:   # the f16x3 mode's GEMMs: split-fp16 operands, three fp16 MFMAs per product (TF/s = fp32-product equivalent)
         for name, n, k, epi, osc in (("qkv(bias)", 3 * D, D, 0, 16.0), ("proj(ls)", D, D, 3, 0.0), ("fc1(gelu)", 4 * D, D, 1, 4.0), ("fc2(ls)", D, 4 * D, 3, 0.0)):
             a = ops.split16_pack(torch.randn(M, k, device=dev), 16.0, 64)
@@ -57,8 +67,9 @@ def main():
             w = ops.quantize_fp8(torch.randn(n, k, device=dev) * 0.02, 5000.0)
             bias, col = torch.randn(n, device=dev), torch.rand(n, device=dev) * 1e-5
             out = torch.zeros(M, n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
-            ms = timeit(lambda: ops.gemm_fp8(a, w, bias, col, out=out, epilogue=epi, m_valid=B * N))
-            print(f"gemm_fp8 {name:10s} M={M} N={n} K={k}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
+            for tile in ((256, 320, 256, 320) if epi != 3 else (256,)):
+                ms = timeit(lambda: ops.gemm_fp8(a, w, bias, col, out=out, epilogue=epi | (tile << 8), m_valid=B * N))
+                print(f"gemm_fp8 {name:10s} M={M} N={n} K={k} tile={tile}: {ms*1e3:8.1f} us  {2.0*B*N*n*k/ms/1e9:7.1f} TF/s", flush=True)
         x = torch.randn(M, 4 * D, device=dev).to(torch.bfloat16)
         ms = timeit(lambda: ops.quantize_fp8(x, 10.0))
         print(f"quantize_fp8 bf16 [{M}, {4*D}]: {ms*1e3:8.1f} us  {M*4*D*3/ms/1e6:7.1f} GB/s", flush=True)
