@@ -173,17 +173,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     // super-tile raster: consecutive lids fill a (rast_r x rast_gn) super-tile, super-tiles run down M inside one
     // group of rast_gn n-tiles before moving to the next group (holes of the ragged last super-row exit at once)
     const unsigned per = a.rast_r * a.rast_gn, st = lid / per, r = lid - st * per;
-    const unsigned SM = (a.M / BM + a.rast_r - 1) / a.rast_r;
+    const unsigned SM = (a.m_tiles + a.rast_r - 1) / a.rast_r;
     const unsigned sn = st / SM, sm = st - sn * SM;
     const unsigned tm = sm * a.rast_r + r % a.rast_r, tn = sn * a.rast_gn + r / a.rast_r;
-    if (tm >= a.M / BM) return;
+    if (tm >= (unsigned)a.m_tiles) return;
     m0 = tm * BM;
     n0 = tn * BN;
   } else {
     m0 = (lid / tiles_n) * BM;
     n0 = (lid % tiles_n) * BN;
   }
-  if (m0 >= a.M_valid) return;  // a tile of padding rows only (M is padded to whole tiles of every shape in use): nothing of it is ever stored
   const int kb = 0, ke = a.K / BK;
 
 #ifdef FP_GEMM_TIMELINE  // tools/build_variant.sh -DFP_GEMM_TIMELINE: per-workgroup shader-clock stamps (never in the shipped library)
@@ -671,7 +670,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
-  unsigned grid = (a.M / BM) * (a.N / BN);
+  // M is padded to whole tiles of every shape in use; tiles of padding rows only are not launched (they would all sit at the end of the
+  // tile order, i.e. in the last XCD's chunk, and leave that XCD short of work)
+  a.m_tiles = a.M / BM;
+  if (a.M_valid > 0 && (a.M_valid + BM - 1) / BM < a.m_tiles) a.m_tiles = (a.M_valid + BM - 1) / BM;
+  unsigned grid = a.m_tiles * (a.N / BN);
   a.rast_r = a.rast_gn = 0;
   // Tile order: by default row-major tile ids cut into one contiguous chunk per XCD.  For wide outputs (more than 4
   // n-tiles: fc1, qkv) a super-tile raster instead: an XCD's 32 concurrent workgroups form 8 m-tiles x 4 n-tiles and
@@ -689,7 +692,7 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
   if (env_rast && rr * gn == 32 && BM >= 256 && (a.N / BN) % gn == 0 && (a.N / BN) > 4 && grid >= 512) {
     a.rast_r = rr; a.rast_gn = gn;
-    grid = ((a.M / BM + rr - 1) / rr) * ((a.N / BN) / gn) * 32;
+    grid = ((a.m_tiles + rr - 1) / rr) * ((a.N / BN) / gn) * 32;
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;
