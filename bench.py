@@ -268,8 +268,8 @@ def main():
                        else "exact-fp32 MFMA GEMMs (k-ascending fmaf chains) + fp32 attention")}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
-        M = (B * n_tok + 255) // 256 * 256
         mv = B * n_tok
+        M = extractor.padded_rows(mv)   # the pipeline's row padding: the launcher picks the same tile shapes here as inside a step
         peak_mfma = PEAK_FP8_TFLOPS if args.precision == "fp8" else PEAK_BF16_TFLOPS
         # ---- roofline of the dominant kernel = the largest time bucket of a step: the LayerScale+residual GEMM template
         # (gemm_bf16_kernel<LS_RESID>), launched twice per block: attn.proj (K = D) and mlp.fc2 (K = hidden)

@@ -349,6 +349,15 @@ class DinoFeatureExtractor(torch.nn.Module):
             self._grids[key] = (pos[1:].to(self._device).contiguous(), prefix)
         return self._grids[key]
 
+    def padded_rows(self, rows: int) -> int:
+        """Rows of the activation buffers for `rows` tokens: whole 256-row GEMM tiles, and whole 320-row tiles as well (the taller tile of the
+        wide bf16 / fp8 GEMMs, csrc/gemm_bf16.hip) when that costs < 3 % more rows.  Row tiles without live rows are never launched."""
+        m_pad = (rows + 255) // 256 * 256
+        m1280 = (rows + 1279) // 1280 * 1280
+        if (self.fold_layernorm or self.precision == "fp8") and m1280 * 100 <= m_pad * 103:
+            m_pad = m1280
+        return m_pad
+
     def _workspace(self, B: int, gh: int, gw: int):
         key = (B, gh, gw, torch.cuda.current_stream().cuda_stream)  # one workspace per stream: concurrent sub-batches
         if key not in self._ws:
@@ -357,10 +366,7 @@ class DinoFeatureExtractor(torch.nn.Module):
             adt = torch.float32 if self.precision == "fp32" else (torch.float16 if sp else torch.bfloat16)
             em = 2 if sp else 1  # stored elements per logical element of an operand row (split rows: hi + lo halves)
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
-            m_pad = (B * ntok + 255) // 256 * 256  # 256-row GEMM tiles
-            m1280 = (B * ntok + 1279) // 1280 * 1280
-            if (self.fold_layernorm or self.precision == "fp8") and m1280 * 100 <= m_pad * 103:   # ... and 320-row tiles for qkv / fc1 when whole tiles of both heights cost < 3 % more rows
-                m_pad = m1280                                        # (tiles of padding rows only leave at once)
+            m_pad = self.padded_rows(B * ntok)
             mp_pad = (B * np_ + 255) // 256 * 256
             bufs = [
                 torch.zeros(mp_pad, em * self._model.patch_k_pad, dtype=adt, device=dev),

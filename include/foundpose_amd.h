@@ -249,7 +249,8 @@ typedef struct {
   void* a8;      /* FP_FP8 only: [m_pad, max(D, hidden)] bytes, the quantised input of the GEMM about to run; m_pad must
                     then be a multiple of 256 */
   int ld_y, ld_h, ld_qkv; /* row strides (elements) of y, h and qkv; 0 = dense (D / hidden / 3D) */
-  int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np) */
+  int m_pad;     /* rows allocated, multiple of 128, >= B*(1+R+Np); a multiple of 1280 (whole 256- AND 320-row tiles) lets the wide bf16 / fp8
+                    GEMMs of a large batch take their taller tile (DinoFeatureExtractor.padded_rows) */
   int m_patch_pad; /* multiple of 128, >= B*Np */
   void* xb;      /* ln_fold only: [m_pad, D] bf16 copy of the residual stream (row stride ld_y), the A operand of qkv / fc1 */
   float* stats;  /* ln_fold only: [D / 128 + 1, m_pad, 2] fp32: partial row sums (sum x, sum x^2) per 128-column group of the
@@ -334,7 +335,8 @@ int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bia
                  fp_stream_t stream);
 /* epilogue: 0 bias->bf16, 1 bias+gelu->bf16, 3 LayerScale*(.)+residual (fp32 in place), 5 bias->f32,
  * 6 SwiGLU (interleaved column pairs -> [M, N/2] bf16);
- * tuning bits: epilogue | (128 << 8) or | (256 << 8) forces that block tile (default: chosen from the shape) */
+ * tuning bits: epilogue | (128 << 8), | (256 << 8) or | (320 << 8) forces that block tile (default: chosen from the shape; 320 = the 320 x 256
+ * tile of the bias / GELU epilogues, M a multiple of 320; every tile gives the same bits).  Row tiles without live rows (>= M_valid) are not launched. */
 int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream);
 /* The GEMMs of a block with the LayerNorm folded in (fp_vit_model.ln_fold), exported for unit tests and benchmarks.
