@@ -667,6 +667,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
   }
 }
 
+// The super-tile raster of a launch (0 x 0: none -- row-major tile ids in one contiguous chunk per XCD).
+// FP_GEMM_RAST: 0 = off, 1 = the default below, "RxG" = another super-tile of R m-tiles x G n-tiles (R * G = 32; measurements:
+// profiles/EXPERIMENTS.md "super-tile shapes" -- 4x8 / 2x16 / 16x2 all lose to 8x4: only a 4-n-tile W panel (2 MiB) survives in a 4-MiB L2
+// next to the streaming A slab, and the A re-fetch per n-group that remains is what a wider group would remove).
+// Default: 4 x 8 when the output is a multiple of 8 n-tiles wide (fc1: 16), else 8 x 4 (qkv: 12) -- same-box pipeline A/B, three
+// alternations: 1043.0 detections/s against 1038.2 with 8 x 4 everywhere (profiles/EXPERIMENTS.md)
+struct GemmRaster { int r, gn; };
+static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
+  static const int env_rast = getenv("FP_GEMM_RAST") ? atoi(getenv("FP_GEMM_RAST")) : 1;
+  static const int env_gn = (getenv("FP_GEMM_RAST") && strchr(getenv("FP_GEMM_RAST"), 'x')) ? atoi(strchr(getenv("FP_GEMM_RAST"), 'x') + 1) : 0;
+  const int wide8 = n_tiles % 8 == 0;
+  const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
+  if (env_rast && rr * gn == 32 && bm >= 256 && n_tiles % gn == 0 && n_tiles > 4 && grid >= 512) return {rr, gn};
+  return {0, 0};
+}
+
 template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
@@ -681,18 +697,10 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   // walk down M inside one group of 4 n-tiles, so each W K-slice is shared by 8 workgroups (A by 4) and the group's W
   // panel stays in the XCD's L2: L2 hit rate 64 -> 75 %, fc1 412 -> 399 us.  (N = 1024 is 4 n-tiles wide: the default
   // order already has that shape, and the raster's intra-order measured 4 % slower there.)
-  // FP_GEMM_RAST: 0 = off, 1 = the 8 x 4 default, "RxG" = another super-tile of R m-tiles x G n-tiles (R * G = 32; measurements:
-  // profiles/EXPERIMENTS.md "super-tile shapes" -- 4x8 / 2x16 / 16x2 all lose to 8x4: only a 4-n-tile W panel (2 MiB) survives in a 4-MiB L2
-  // next to the streaming A slab, and the A re-fetch per n-group that remains is what a wider group would remove)
-  static const int env_rast = getenv("FP_GEMM_RAST") ? atoi(getenv("FP_GEMM_RAST")) : 1;
-  static const int env_gn = (getenv("FP_GEMM_RAST") && strchr(getenv("FP_GEMM_RAST"), 'x')) ? atoi(strchr(getenv("FP_GEMM_RAST"), 'x') + 1) : 0;
-  // default: 4 x 8 when the output is a multiple of 8 n-tiles wide (fc1: 16), else 8 x 4 (qkv: 12) -- same-box pipeline A/B, three
-  // alternations: 1043.0 detections/s against 1038.2 with 8 x 4 everywhere (profiles/EXPERIMENTS.md)
-  const int wide8 = (a.N / BN) % 8 == 0;
-  const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
-  if (env_rast && rr * gn == 32 && BM >= 256 && (a.N / BN) % gn == 0 && (a.N / BN) > 4 && grid >= 512) {
-    a.rast_r = rr; a.rast_gn = gn;
-    grid = ((a.m_tiles + rr - 1) / rr) * ((a.N / BN) / gn) * 32;
+  const GemmRaster ra = pick_raster(BM, a.N / BN, grid);
+  if (ra.r) {
+    a.rast_r = ra.r; a.rast_gn = ra.gn;
+    grid = ((a.m_tiles + ra.r - 1) / ra.r) * ((a.N / BN) / ra.gn) * 32;
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;
@@ -704,26 +712,24 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
 
 // 320 x 256 tiles: 160 accumulator registers per lane (<= 256 VGPRs, no spill), 10 % fewer operand bytes through the L1 fill path per flop --
 // the path that bounds the main loop -- and another round count.  Same k order per output element: results bit-identical to the 256^2 tile's.
-// Isolated, M = 44 800 (the bench batch): qkv 273.8 -> 259.9 us, fc1 380.6 -> 365.9 us; pipeline +1.5 % same-box.  Chosen when M is a whole
-// number of both tile heights (the extractor pads to 1280 rows when that is cheap) and this estimate favours it: a launch costs its whole
-// rounds plus min(1, f + 0.25) for a last round filled to f (after a few rounds the CUs have drifted apart and the stragglers of the last
-// round start while others are still inside their previous tile), times the tile height, times 0.94 for the taller tile -- calibrated on
-// the four launches above: 8.3 / 6.7 rounds of qkv, 11 / 8.9 of fc1.  Launches of fewer than `min_rounds` whole rounds keep the 256^2 tile:
-// with little drift a nearly idle last round costs a whole one (the residual GEMMs of the bench batch, 552 tiles = 2.16 rounds: fc2 395 vs
-// 354 us, proj 151 vs 137).  FP_GEMM_TILE320=0 is the A/B switch.
-static bool tall_tile_wins(const GemmBf16Args& a, int min_rounds) {
+// Chosen when M is a whole number of both tile heights (the extractor pads to 1280 rows when that is cheap) and the round count favours it.
+// A launch runs in XCD rounds: an XCD's 32 CUs take one super-tile of the raster (32 tiles; ragged super-rows leave holes) or the next 32
+// tiles of the XCD's chunk per round, and a partly filled last round costs a whole one -- a sweep over 18 batch sizes (profiles/EXPERIMENTS.md
+// "320 x 256 block tiles") shows steps exactly at these counts: qkv at the bench batch, 256^2: 22 x 3 = 66 super-tiles = 9 rounds of 31 us;
+// 320 x 256: 18 x 3 = 54 = 7 rounds of 37.5 us.  A round of the taller tile takes 1.21x (not 1.25x) the time: cost = rounds x height x 0.97.
+// The estimate picks the faster tile in 32 of the 36 cases of the recorded sweep (profiles/r4_gemm_tile_sweep.txt; three misses within 1 %, one
+// of 3 %) and 256 rows for the residual GEMMs of the bench batch (3 rounds either way).  FP_GEMM_TILE320=0 is the A/B switch.
+static int xcd_rounds(int bm, int m_valid, int n_tiles) {
+  const int m_tiles = (m_valid + bm - 1) / bm, xcds = 8, per_xcd = fp_num_cus() / xcds > 0 ? fp_num_cus() / xcds : 32;
+  const GemmRaster ra = pick_raster(bm, n_tiles, (unsigned)(m_tiles * n_tiles));
+  if (ra.r) return (((m_tiles + ra.r - 1) / ra.r) * (n_tiles / ra.gn) + xcds - 1) / xcds;
+  const int chunk = (m_tiles * n_tiles + xcds - 1) / xcds;
+  return (chunk + per_xcd - 1) / per_xcd;
+}
+static bool tall_tile_wins(const GemmBf16Args& a) {
   static const bool off = getenv("FP_GEMM_TILE320") && atoi(getenv("FP_GEMM_TILE320")) == 0;
   if (off || a.M % 320 != 0 || a.M % 256 != 0 || a.N % 256 != 0) return false;
-  const int cus = fp_num_cus();
-  float whole320 = 0.f;
-  auto cost = [&](int bm, float eff, float* whole_out) {
-    const float r = (float)(((a.M_valid + bm - 1) / bm) * (a.N / 256)) / (float)cus;
-    const float whole = floorf(r), f = r - whole;
-    if (whole_out) *whole_out = whole;
-    return (whole + (f > 0.f ? fminf(1.f, f + 0.25f) : 0.f)) * (float)bm * eff;
-  };
-  const float c320 = cost(320, 0.94f, &whole320), c256 = cost(256, 1.f, nullptr);
-  return whole320 >= (float)min_rounds && c320 < c256;
+  return (float)(xcd_rounds(320, a.M_valid, a.N / 256) * 320) * 0.97f < (float)(xcd_rounds(256, a.M_valid, a.N / 256) * 256);
 }
 
 // Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
@@ -737,10 +743,9 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   const int tiles_big = (a.M / 256) * (a.N / 256), cus = fp_num_cus();
   const bool use_big = big_ok && (force == 256 || (force == 0 && tiles_big >= cus && !(tiles_big > cus && tiles_big < cus + cus / 2)));
   // (Measured and dropped, round 3: sending the m-tiles that hold the few tiles beyond a whole number of rounds -- qkv at the bench batch:
-  //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us.  The stragglers of a single launch start while other CUs
-  //  are still inside their eighth tile and cost far less than a round; a dependent second launch costs its own latency.)
+  //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us; a dependent second launch costs its own latency.)
   if constexpr (!SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_RESID_HILO)) {
-    if ((force == 320 && a.M % 320 == 0 && a.N % 256 == 0) || (force == 0 && use_big && tall_tile_wins(a, EPI == GEMM_EPI_RESID_HILO ? 8 : 4)))
+    if ((force == 320 && a.M % 320 == 0 && a.N % 256 == 0) || (force == 0 && use_big && tall_tile_wins(a)))
       return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   }
   if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
@@ -758,7 +763,7 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   FP_REQUIRE(a.bias != nullptr && a.gamma != nullptr, "gemm_fp8: bias and the per-column scale are required");
   FP_REQUIRE(a.lda % 16 == 0 && a.ldw % 16 == 0 && a.ldo % 4 == 0, "gemm_fp8: leading dims must keep 16-byte alignment");
   a.K /= 2; a.lda /= 2; a.ldw /= 2;  // an fp8 row addressed as a bf16 row of half the length (see the kernel header)
-  const bool tall = a.tile_override == 320 ? a.M % 320 == 0 : (a.tile_override == 0 && tall_tile_wins(a, 4));   // (the residual epilogue keeps 256 rows)
+  const bool tall = a.tile_override == 320 ? a.M % 320 == 0 : (a.tile_override == 0 && tall_tile_wins(a));   // (the residual epilogue keeps 256 rows)
   if (a.out_scale > 0.f) {  // fp8 output
     FP_REQUIRE(a.ldo % 16 == 0, "gemm_fp8: an fp8 output needs ldo %% 16 == 0");
     if (epi == GEMM_EPI_GELU_BF16) return tall ? launch_cfg<GEMM_EPI_GELU_BF16, 320, 256, 2, 4, true, true>(a, st) : launch_cfg<GEMM_EPI_GELU_BF16, 256, 256, 2, 4, true, true>(a, st);

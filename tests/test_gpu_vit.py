@@ -529,6 +529,20 @@ def test_gemm_fp8_quantised_output(epi):
     assert float((got - want).abs().mean()) < 0.03 * float(want.abs().mean())
 
 
+@pytest.mark.parametrize("epi,out_scale", [(0, 0.0), (1, 0.0), (6, 0.0), (1, 3.0), (6, 3.0)])
+def test_gemm_fp8_320_row_tile_equals_256_row_tile(epi, out_scale):
+    """fp8 GEMMs (bias / GELU / SwiGLU, bf16 and e4m3 outputs): the 320-row block tile gives the 256-row tile's bits."""
+    from foundpose_amd import ops
+    M, N, K, mv = 2560, 1024, 512, 2000
+    g = torch.Generator().manual_seed(epi + 7)
+    a = ops.quantize_fp8(torch.randn(M, K, generator=g).cuda(), 60.0)
+    w = ops.quantize_fp8((torch.randn(N, K, generator=g) * 0.05).cuda(), 2000.0)
+    bias, col = torch.randn(N, generator=g).cuda(), (torch.rand(N, generator=g) * 1e-5 + 1e-6).cuda()
+    outs = [ops.gemm_fp8(a, w, bias, col, epilogue=epi | (tile << 8), m_valid=mv, out_scale=out_scale) for tile in (256, 320)]
+    assert torch.equal(outs[0][:mv].view(torch.uint8), outs[1][:mv].view(torch.uint8))
+    assert not bool(outs[1][mv:].view(torch.uint8).any())
+
+
 def test_gemm_fp8_loud_failures():
     from foundpose_amd import ops
     from foundpose_amd._lib import FoundPoseNativeError
