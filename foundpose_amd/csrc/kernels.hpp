@@ -171,6 +171,7 @@ struct AttnArgs {
   // bf16 work split (bit-identical outputs): 0 = 64 queries per wave, K/V by LDS-DMA (default); 1 = 32 queries per wave, register
   // staging (the cross-check); 2 = the DMA kernel with one 32-query block per wave, 8 waves per 256-query block
   int variant;
+  int tail_last;                 // set by the launcher (bf16 w64 kernel): the last (short) query tile of every (image, head) pair goes to the END of its XCD's block sequence
   float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
   int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps (the split-fp16
                                  // output is a convex combination of v rows that already fit their scale: it cannot clamp)
