@@ -1,5 +1,8 @@
+"""qkv / fc1 GEMM (folded-LayerNorm form) at 18 batch sizes with 256- and 320-row block tiles: the data the launcher's tile chooser
+(csrc/gemm_bf16.hip::tall_tile_wins, XCD rounds) is calibrated and validated on.   python tools/gemm_tile_sweep.py > profiles/rN_gemm_tile_sweep.txt"""
 import torch, sys
-sys.path.insert(0, '/root/repo')
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from foundpose_amd import ops
 from tools.bench_kernels import timeit
 dev = 'cuda'; K = 1024
