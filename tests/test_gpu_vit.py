@@ -705,6 +705,57 @@ def test_residual_gemm_on_the_hi_lo_stream(tile, M, D):
     assert torch.equal(xb8[M - 3:].cpu(), hi[M - 3:]) and torch.equal(xl8[M - 3:].cpu(), lo[M - 3:])
 
 
+@pytest.mark.parametrize("K", [1024, 4096])
+def test_residual_gemm_hi_lo_320_row_tile_equals_256_row_tile(K):
+    """Epilogue 8 on the 320-row block tile (the residual GEMMs of large batches): hi', lo' and the row sums equal the 256-row tile's
+    bit for bit; rows past M_valid untouched."""
+    from foundpose_amd import ops
+    M, N, mv = 2560, 1024, 2200
+    g = torch.Generator().manual_seed(K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.02).to(torch.bfloat16).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    xb0 = torch.randn(M, N, generator=g).to(torch.bfloat16).cuda()
+    xl0 = (torch.randn(M, N, generator=g) * 0.003).to(torch.bfloat16).cuda()
+    outs = []
+    for tile in (256, 320):
+        xb, xl = xb0.clone(), xl0.clone()
+        st = ops.gemm_bf16_resid_hilo(a, w, bias, xb, xl, tile=tile, m_valid=mv)
+        outs.append((xb, xl, st))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2][:, :mv], outs[1][2][:, :mv])
+    assert torch.equal(outs[1][0][mv:], xb0[mv:]) and torch.equal(outs[1][1][mv:], xl0[mv:]) and not torch.equal(outs[1][0][:mv], xb0[:mv])
+
+
+_TALL_TILE_SCRIPT = """
+import hashlib, sys, torch
+sys.path.insert(0, %r)
+from foundpose_amd import feature_util, synthetic
+from foundpose_amd.vit_config import ARCHS
+arch = ARCHS["vitl14-reg"]
+sd = synthetic.make_vit_state_dict(arch, seed=4)
+ex = feature_util.make_feature_extractor("dinov2_version=vitl14-reg_stride=14_facet=token_layer=2_norm=1", state_dict=sd, precision="bf16").to("cuda")
+imgs = synthetic.make_crops(24, 518, seed=2).cuda()      # 24 x 1374 tokens = 32 976 rows: qkv, fc1 AND the residual GEMMs (516 tiles = 3 rounds -> 416 = 2) take the taller tile
+fm = ex(imgs)["feature_maps"]
+print("HASH", hashlib.sha256(fm.float().cpu().numpy().tobytes()).hexdigest(), ex.padded_rows(24 * 1374))
+"""
+
+
+def test_tall_gemm_tiles_leave_the_features_bit_identical():
+    """The whole bf16 forward with the 320-row tiles allowed (default) and forbidden (FP_GEMM_TILE320=0), in two processes (the switch is read
+    once): same feature maps bit for bit, at a batch whose residual GEMMs take the taller tile too."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = []
+    for sw in ("1", "0"):
+        env = dict(os.environ, FP_GEMM_TILE320=sw)
+        r = subprocess.run([sys.executable, "-c", _TALL_TILE_SCRIPT % root], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][0])
+    assert out[0] == out[1] and out[0].split()[2] == str((24 * 1374 + 1279) // 1280 * 1280)
+
+
 @pytest.mark.parametrize("hilo", ["0", "1"])
 def test_hi_lo_stream_end_to_end_switch(monkeypatch, hilo):
     """FP_RESID_HILO=0 keeps the fp32 residual stream in every block; =1 (default) holds it as (hi, lo) bf16 pairs in front of the hooked
