@@ -562,7 +562,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   // against the 8 of the bf16 operands everything is multiplied in.  The hooked block itself runs on an fp32 stream rebuilt from the pair
   // (all rows, or the selected rows only), so the engine's token-selected form and the full form stay bit-identical.
   const bool hilo = fold && ws->xl != nullptr;
-  FP_REQUIRE(mode == VIT_FULL || fold || sp, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold, or an f16x3 model");
+  FP_REQUIRE(mode == VIT_FULL || fold || sp || f8, "fp_vit_forward_prefix / fp_vit_block_selected: bf16 model with ln_fold, an fp8 or an f16x3 model");
   float2* ln_row = stats + (size_t)ln_parts * ws->m_pad;  // (rstd, mean * rstd) per row, behind the partial-sum slots
   int rows_valid = Mtok, rows_pad = ws->m_pad;  // the selected tail of the hooked block narrows these to the compact rows
   // (the residual GEMM files its partial sums with a stride of ITS row count: rows_pad)
@@ -680,21 +680,38 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       // row strides in bytes (= fp8 elements): a8 [m_pad, ld8y], hidden bytes [m_pad, ld8h], matrices [N, ld8wd / ld8wh]
       const int ld8y = ws->ld_y ? ws->ld_y : D, ld8h = ws->ld_h ? ws->ld_h : m->hidden;
       const int ld8wd = m->ld_w_dim ? m->ld_w_dim : D, ld8wh = m->ld_w_hidden ? m->ld_w_hidden : m->hidden;
+      // mode VIT_LAST_SELECTED (the hooked block for the selected tokens only, as in the bf16 and f16x3 branches): LayerNorm 1 and the qkv GEMM on
+      // all rows (keys / values need every token), attention takes its queries through the index list and writes compact e4m3 rows, the residual
+      // rows are gathered into the dead qkv buffer, and proj / LayerNorm 2 / fc1 / fc2 run on num_sel rows.  Per-row arithmetic (static scales,
+      // k-ordered GEMM chains) does not depend on where a row sits: the selected rows carry the bits the full block would have given them.
+      const bool selected = mode == VIT_LAST_SELECTED;
       LayerNormArgs l8 = ln;
       l8.out = ws->a8; l8.ld_out = ld8y; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
       TRY(layernorm_launch(l8, st));
       TRY(gemm_fp8_impl(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, ws->sat, stream));
       AttnArgs a8 = at;
       a8.out = ws->a8; a8.ld_out = ld8y; a8.out_fp8_scale = b.act_scale[1];
-      TRY(attn_launch(a8, FP_DTYPE_BF16, st));
-      TRY(gemm_fp8_impl(ws->a8, ld8y, b.proj_w, ld8wd, ws->m_pad, D, D, Mtok, b.proj_b, b.proj_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
+      float* xr = ws->x;  // the residual rows the rest of the block updates
+      int rv = Mtok, rp = ws->m_pad;
+      if (selected) {
+        a8.sel_rows = sel->rows; a8.sel_off = sel->off; a8.max_sel = sel->max_per_img;
+        TRY(attn_launch(a8, FP_DTYPE_BF16, st));
+        xr = reinterpret_cast<float*>(ws->qkv);  // qkv is dead after the attention: [num_sel, D] fp32 rows of the stream
+        TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xr, st));
+        rv = sel->num;
+        rp = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
+        l8.x = xr; l8.out_rows = rv; l8.out_rows_per_img = rv; l8.in_rows_per_img = rv;
+      } else {
+        TRY(attn_launch(a8, FP_DTYPE_BF16, st));
+      }
+      TRY(gemm_fp8_impl(ws->a8, ld8y, b.proj_w, ld8wd, rp, D, D, rv, b.proj_b, b.proj_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
       l8.weight = b.ln2_w; l8.bias = b.ln2_b; l8.out_scale = b.act_scale[2];
       TRY(layernorm_launch(l8, st));
       if (m->ffn_swiglu)
-        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, 2 * m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], ws->sat, stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, 2 * m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], ws->sat, stream));
       else
-        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, ws->m_pad, m->hidden, D, Mtok, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], ws->sat, stream));
-      TRY(gemm_fp8_impl(ws->h, ld8h, b.fc2_w, ld8wh, ws->m_pad, D, m->hidden, Mtok, b.fc2_b, b.fc2_s, ws->x, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], ws->sat, stream));
+      TRY(gemm_fp8_impl(ws->h, ld8h, b.fc2_w, ld8wh, rp, D, m->hidden, rv, b.fc2_b, b.fc2_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
       continue;
     }
     TRY(layernorm_launch(ln, st));

@@ -458,8 +458,8 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     @property
     def supports_token_selection(self) -> bool:
-        """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms, or f16x3."""
-        mode_ok = (self.precision == "bf16" and self.fold_layernorm) or self.precision == "f16x3"
+        """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms, fp8, or f16x3."""
+        mode_ok = (self.precision == "bf16" and self.fold_layernorm) or self.precision in ("f16x3", "fp8")
         return (self.facet == "token" and not self.use_graph and mode_ok and self.layer >= 0
                 and self.stride == self.patch_size)   # the selection maps query points to 14-px cells
 
@@ -473,7 +473,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         if self.facet != "token" or self.use_graph:
             raise NotImplementedError("forward_hidden serves the eager token path")
         if prefix_only and not self.supports_token_selection:
-            raise NotImplementedError("token selection needs the bf16 mode with folded LayerNorms, or the f16x3 mode")
+            raise NotImplementedError("token selection needs the bf16 mode with folded LayerNorms, the fp8 or the f16x3 mode")
         _lib.require_cuda(images)
         images = images.float().contiguous()
         B, _, H, W = images.shape

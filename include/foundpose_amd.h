@@ -290,7 +290,7 @@ int fp_vit_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B
 int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm, int img_w,
                            int img_h, const float* points, const int32_t* point_img, int num_points, float* out, fp_stream_t stream);
 
-/* Query-token selection in the hooked block (bf16 model with ln_fold, or f16x3 model).  The reference runs the backbone on every token and
+/* Query-token selection in the hooked block (bf16 model with ln_fold, fp8 model, or f16x3 model).  The reference runs the backbone on every token and
  * then reads the feature map at the query points only (utils/dinov2_utils.py:257,304 -> utils/feature_util.py:100-131 at the
  * points of scripts/infer.py:452-466): the hooked block's OUTPUT is needed for the patch tokens under the sampling taps and
  * for no other token, while its keys and values still come from all tokens.  Three calls replace fp_vit_forward +

@@ -797,7 +797,8 @@ def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
 
 
 @pytest.mark.parametrize("version,size,layer,precision", [("vits14-reg", 224, 3, "bf16"), ("vits14-reg", 224, 0, "bf16"), ("vitl14-reg", 518, 2, "bf16"),
-                                                         ("vits14-reg", 224, 3, "f16x3"), ("vits14-reg", 224, 0, "f16x3"), ("vitl14-reg", 518, 1, "f16x3")])
+                                                         ("vits14-reg", 224, 3, "f16x3"), ("vits14-reg", 224, 0, "f16x3"), ("vitl14-reg", 518, 1, "f16x3"),
+                                                         ("vitl14-reg", 518, 1, "fp8"), ("vitl14-reg", 224, 0, "fp8"), ("vitg14-reg", 224, 1, "fp8")])
 def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer, precision):
     """fp_vit_forward_prefix + fp_vit_block_selected + fp_vit_sample_features_selected: the hooked block computed only for
     the patch tokens the sampling reads (attention queries, proj, fc1, fc2 on the selected rows; keys / values all tokens)
@@ -809,6 +810,8 @@ def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer, pre
     assert ex.supports_token_selection
     B = 4
     imgs = synthetic.make_crops(B, size, seed=5).cuda()
+    if precision == "fp8":
+        ex.calibrate_fp8(imgs)   # the static activation scales are part of the fp8 model
     masks = torch.zeros(B, size, size, dtype=torch.uint8)
     masks[0] = synthetic.make_disc_mask(size)
     masks[1, size // 3: size // 3 + 20, 10: size - 30] = 1
