@@ -357,9 +357,13 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   }
   // one key tile; RAGGED (the last tile when N % 64 != 0) is a separate instantiation so that the full tiles carry no
   // masking code at all (inlined into one loop the compiler if-converts the mask into 120 selects per tile)
-  auto tile = [&](int kt, auto ragged, auto qblocks) {
+  auto tile = [&](int kt, auto ragged, auto qblocks, auto halfkeys) {
     constexpr bool RAGGED = decltype(ragged)::value;
     constexpr int QC = decltype(qblocks)::value;  // 32-query blocks this wave computes (QB, or 1 in a short tail tile)
+    // HALF: the ragged last tile holds <= 32 live keys (1374 tokens = 21 x 64 + 30): its second key half is all padding -- scores -inf,
+    // probabilities 0, V rows read as zeros -- and is skipped: the same sums without their zero addends
+    constexpr int KS = decltype(halfkeys)::value ? 1 : 2;
+    static_assert(RAGGED || KS == 2, "only the ragged tile can be half empty");
     const int key0 = kt * 64;
     const char* Ks = KV[kt & 1][0];
     const char* Vs = KV[kt & 1][1];
@@ -384,7 +388,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
 #ifdef FP_ATTN_NO_LDS  // (measurement builds: fragments from registers instead of LDS)
           bf16x8 kf = qf[0][ds];
           kf[0] = (__bf16)(float)((kt + ks) & 3);
@@ -419,15 +423,15 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
         if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
           const int lim = N - key0 - 4 * kh;
 #pragma unroll
-          for (int ks = 0; ks < 2; ++ks)
+          for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
               if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[qb][ks][r] = -INFINITY;
         }
         // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
-        float mx = fmaxf(sacc[qb][0][0], sacc[qb][1][0]);
+        float mx = KS == 2 ? fmaxf(sacc[qb][0][0], sacc[qb][KS - 1][0]) : sacc[qb][0][0];
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[qb][0][r]), sacc[qb][1][r]);  // v_max3_f32
+        for (int r = 1; r < 16; ++r) mx = KS == 2 ? fmaxf(fmaxf(mx, sacc[qb][0][r]), sacc[qb][KS - 1][r]) : fmaxf(mx, sacc[qb][0][r]);  // v_max3_f32
         {  // the query's other 32 scores live in lane ^ 32: one v_permlane32_swap (VALU) instead of a ds_bpermute round trip through LDS
           const unsigned mu = __builtin_bit_cast(unsigned, mx);
           const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);  // lanes < 32: {own, partner's}; >= 32: {partner's, own}
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
         float psum = 0.f;
         const float mc = m_run[qb] * c;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const float p = __builtin_amdgcn_exp2f(fmaf(sacc[qb][ks][r], c, -mc));
@@ -472,7 +476,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
         }
         l_run[qb] += psum;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 8 * kk;
@@ -509,7 +513,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
                      "+v"(vlo[2][0]), "+v"(vhi[2][0]), "+v"(vlo[2][1]), "+v"(vhi[2][1]), "+v"(vlo[3][0]), "+v"(vhi[3][0]), "+v"(vlo[3][1]), "+v"(vhi[3][1]));
 #endif
 #pragma unroll
-      for (int kstep = 0; kstep < 4; ++kstep)
+      for (int kstep = 0; kstep < 2 * KS; ++kstep)
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
           const char* vp = Vs + (vrd0 ^ (dt << 6)) + kstep * 2048;  // + 512 B = 4 keys on
@@ -539,8 +543,14 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   };
   const int nfull = N / 64;
   auto run = [&](auto qblocks) {
-    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, qblocks);
-    if (nfull < nkt) tile(nfull, std::true_type{}, qblocks);
+    for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, qblocks, std::false_type{});
+    if (nfull < nkt) {
+#ifndef FP_ATTN_NO_HALF  // (measurement build: the ragged tile always at full width)
+      if (!PF && N - nfull * 64 <= 32) tile(nfull, std::true_type{}, qblocks, std::true_type{});
+      else
+#endif
+      tile(nfull, std::true_type{}, qblocks, std::false_type{});
+    }
   };
   if constexpr (QB == 2) {
     if (short_tail) run(std::integral_constant<int, 1>{});
@@ -688,8 +698,10 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
 
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) as a builtin (see attn_bf16_w64_kernel)
   __syncthreads();
-  auto tile = [&](int kt, auto ragged) {
+  auto tile = [&](int kt, auto ragged, auto halfkeys) {
     constexpr bool RAGGED = decltype(ragged)::value;
+    constexpr int KS = decltype(halfkeys)::value ? 1 : 2;  // 1: the ragged tile's second key half is all padding and is skipped (attn_bf16_w64_kernel)
+    static_assert(RAGGED || KS == 2, "only the ragged tile can be half empty");
     const int key0 = kt * 64;
     const char* Ks = KV[kt & 1][0];
     const char* Vs = KV[kt & 1][1];
@@ -707,7 +719,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
         const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
         f16x8 kfh[2], kfl[2];
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        for (int ks = 0; ks < KS; ++ks) {
           const int row = ks * 32 + l31;
           const char* kr = Ks + row * 256;
           kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
@@ -715,24 +727,24 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
         }
         // the two key halves' chains interleaved (per accumulator the order stays lo.hi, hi.lo, hi.hi over ds ascending)
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
+        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
+        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
         sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
-        sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
+        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
       }
       if constexpr (RAGGED) {  // mask the padded keys
         const int lim = N - key0 - 4 * kh;
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks)
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
           for (int r = 0; r < 16; ++r)
             if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
       }
       // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
-      float mx = fmaxf(sacc[0][0], sacc[1][0]);
+      float mx = KS == 2 ? fmaxf(sacc[0][0], sacc[KS - 1][0]) : sacc[0][0];
 #pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+      for (int r = 1; r < 16; ++r) mx = KS == 2 ? fmaxf(fmaxf(mx, sacc[0][r]), sacc[KS - 1][r]) : fmaxf(mx, sacc[0][r]);
       {  // the query's other 32 scores live in lane ^ 32 (one v_permlane32_swap; results through temporaries, see attn_bf16_w64_kernel)
         const unsigned mu = __builtin_bit_cast(unsigned, mx);
         const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
@@ -753,7 +765,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
       const float mc = m_run * c;
       f16x8 ph[4], pl[4];
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
+      for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
@@ -786,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
       l_run += psum;
       // ---- O^T += V^T P^T over 4 steps of 16 keys; the two d-halves' chains interleaved (per accumulator: lo.hi, hi.lo, hi.hi, k-steps ascending)
 #pragma unroll
-      for (int kstep = 0; kstep < 4; ++kstep) {
+      for (int kstep = 0; kstep < 2 * KS; ++kstep) {
         f16x8 vfh[2], vfl[2];
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -813,8 +825,11 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     }
   };
   const int nfull = N / 64;
-  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{});
-  if (nfull < nkt) tile(nfull, std::true_type{});
+  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, std::false_type{});
+  if (nfull < nkt) {
+    if (N - nfull * 64 <= 32) tile(nfull, std::true_type{}, std::true_type{});
+    else tile(nfull, std::true_type{}, std::false_type{});
+  }
 
   if (active) {
     const int q = q0 + l31;
