@@ -527,12 +527,12 @@ __global__ __launch_bounds__(256) void cosine_final_kernel(const unsigned long l
 // strictly decreasing, the top-n SET and its ORDER are unique, so every correct top-k -- torch.topk's partial_sort /
 // nth_element + sort included -- returns exactly this list and the row's replay is skipped (flag 0).  Any equal pair, a
 // +-0 pair or a NaN among them sets the flag and topn_rows_strict_kernel redoes the row from the scores.
-__global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
-                                                         float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay) {
+FP_DEVICE void cand_merge_row(const unsigned long long* __restrict__ cand, int ncand, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
+                              int* __restrict__ need_replay, int row, int* tie_out) {
   // One 256-thread block per detection (a wave per detection walked the keys in six dependent rounds of loads: 8 us of latency):
   // every thread takes its keys in ONE round of loads, each wave extracts its best n + 1 with wave-wide minima, wave 0 merges the four lists.
   __shared__ unsigned long long wbest[4][COS_NMAX];
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const unsigned long long* c = cand + (size_t)row * ncand;
   unsigned long long k[8];
 #pragma unroll
@@ -581,6 +581,12 @@ __global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long lon
     }
   }
   if (need_replay && lane == 0) need_replay[row] = tie;
+  if (tie_out && need_replay && lane == 0) *tie_out = tie;
+}
+
+__global__ __launch_bounds__(256) void cand_merge_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
+                                                         float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay) {
+  cand_merge_row(cand, ncand, n_top, out_val, out_idx, need_replay, blockIdx.x, nullptr);
 }
 
 // Canonical top-n of each row (largest first, ties -> lowest index) straight from the scores, one 256-thread block per
@@ -679,16 +685,15 @@ __device__ __forceinline__ void strict_replay64(LaneHeap& heap, int k, float v, 
   }
 }
 
-__global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
-                                                               int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
-                                                               const int* __restrict__ need_replay) {
+// One row's top n in torch.topk's order, replayed from the row of scores by a whole 256-thread block (block-uniform call).
+FP_DEVICE void topn_row_strict(const float* __restrict__ vals, int ld, const int* __restrict__ row_len, int n_default, int n_top,
+                               float* __restrict__ out_val, int* __restrict__ out_idx, int row) {
   __shared__ __attribute__((aligned(16))) float head[2 * STRICT_HEAD];   // phase 1 staging; the short-row branch's (value, index) pairs
   __shared__ float cand_v[4][STRICT_CAND];
   __shared__ int cand_i[4][STRICT_CAND];
   __shared__ int cand_n[4];
   __shared__ float s_root_v;
-  const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (need_replay && !need_replay[row]) return;  // the row's top n + 1 scores are distinct: cand_merge_kernel's list is the answer
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int len = row_len ? row_len[row] : n_default;
   const float* r = vals + (size_t)row * ld;
   const int k = min(n_top, len);
@@ -788,6 +793,28 @@ __global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __re
       out_val[(size_t)row * n_top + lane] = lane < k ? heap.v : -INFINITY;
     }
   }
+}
+
+__global__ __launch_bounds__(256) void topn_rows_strict_kernel(const float* __restrict__ vals, int ld, const int* __restrict__ row_len,
+                                                               int n_default, int n_top, float* __restrict__ out_val, int* __restrict__ out_idx,
+                                                               const int* __restrict__ need_replay) {
+  const int row = blockIdx.x;
+  if (need_replay && !need_replay[row]) return;  // the row's top n + 1 scores are distinct: cand_merge_kernel's list is the answer
+  topn_row_strict(vals, ld, row_len, n_default, n_top, out_val, out_idx, row);
+}
+
+// cand_merge_kernel + the replay of the rows it flags, one launch: a row whose best n + 1 candidate scores tie is redone from its scores by
+// the same block (the two dependent launches were 7.5 + 5 us of a 37-us call).
+__global__ __launch_bounds__(256) void cand_merge_replay_kernel(const unsigned long long* __restrict__ cand, int ncand, int rows, int n_top,
+                                                                float* __restrict__ out_val, int* __restrict__ out_idx, int* __restrict__ need_replay,
+                                                                const float* __restrict__ vals, int ld, const int* __restrict__ row_len, int n_default) {
+  __shared__ int s_tie;
+  const int row = blockIdx.x;
+  if (threadIdx.x == 0) s_tie = need_replay ? 0 : 1;  // no flag array: every row is replayed, as with the two launches
+  __syncthreads();
+  cand_merge_row(cand, ncand, n_top, out_val, out_idx, need_replay, row, &s_tie);
+  __syncthreads();
+  if (s_tie) topn_row_strict(vals, ld, row_len, n_default, n_top, out_val, out_idx, row);  // (block-uniform) overwrites the merged list
 }
 
 // ------------------------------------------------------------------ tf-idf descriptor per detection
@@ -1334,6 +1361,13 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);
     FP_CHECK_LAUNCH("cosine_fused");
     if (want_cand) {
+      static const bool two_launches = getenv("FP_COSINE_MERGE_REPLAY") && atoi(getenv("FP_COSINE_MERGE_REPLAY")) == 0;  // A/B switch
+      if (tie_mode == 1 && !two_launches && n_top <= 32) {  // merge + the replay of tied rows in one launch (torch order)
+        hipLaunchKernelGGL(cand_merge_replay_kernel, dim3(num_det), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
+                           a.need_replay, a.sims, a.ld_sims, det_num_templates, max_templates);
+        FP_CHECK_LAUNCH("cand_merge_replay");
+        return FP_OK;
+      }
       hipLaunchKernelGGL(cand_merge_kernel, dim3(num_det), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
                          tie_mode == 1 ? a.need_replay : nullptr);
       FP_CHECK_LAUNCH("cand_merge");
