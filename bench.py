@@ -140,7 +140,7 @@ def main():
     name = f"dinov2_version={args.version}_stride=14_facet=token_layer={args.layer}_norm=1"
     B = args.batch
     # ---- planted workload: the fp32 mode of the library produces the features that are planted (the reference's arithmetic)
-    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to(dev)
+    ex32 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to(dev)
     full_mask = torch.ones(args.size, args.size, dtype=torch.uint8) if args.mask == "full" else None
     W_words = args.words or (4224 if args.mask == "full" else 2048)
     n_patches = (args.size // 14) ** 2 if args.mask == "full" else int(synthetic_disc_patches(args.size))
@@ -149,7 +149,7 @@ def main():
                                          words_per_texture=wpt)
     bank = DeviceBank(wl.repres, device=dev)
     images, masks, det_obj = wl.crops, wl.masks, wl.det_obj     # inputs resident in HBM before timing
-    extractor = feature_util.make_feature_extractor(name, seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
+    extractor = feature_util.make_feature_extractor(name, random_init_seed=1234, precision=args.precision, use_graph=args.graph).to(dev)
     if args.precision == "fp8":
         extractor.calibrate_fp8(images)  # static activation scales are part of the fp8 model (no implicit calibration)
     eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order, overlap_matching=args.overlap)
@@ -258,7 +258,7 @@ def main():
     # ---- the near-exact mode, driver-timed like the headline (same inputs, same engine code, `--parity-steps` steps after one warm-up)
     pm = None
     if args.parity_precision != "none" and args.parity_precision != args.precision:
-        ex_pm = ex32 if args.parity_precision == "fp32" else feature_util.make_feature_extractor(name, seed=1234, precision=args.parity_precision).to(dev)
+        ex_pm = ex32 if args.parity_precision == "fp32" else feature_util.make_feature_extractor(name, random_init_seed=1234, precision=args.parity_precision).to(dev)
         eng_pm = fe.FoundPoseEngine(ex_pm, bank, 14.0, 5, 300, tie_order=args.tie_order)
         step(eng_pm)
         el_pm, (_, last_pm) = timed(eng_pm, args.parity_steps)

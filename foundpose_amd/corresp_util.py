@@ -60,6 +60,7 @@ def establish_correspondences(
         raise ValueError(f"Unknown feature matching type ({feat_matching_type}).")
     assert object_repre.feat_vectors is not None
     assert object_repre.vertices is not None
+    template_util.check_top_n(top_n_templates, object_repre)   # torch.topk's error for an object with fewer templates (template_util.py:172)
     bank = template_util.get_device_bank(object_repre)
     res = match_batch(bank, query_features.to("cuda"), query_points.to("cuda"), [query_points.shape[0]], None,
                       top_n_templates, top_k_buddies, keep_debug=debug, tie_order=tie_order,

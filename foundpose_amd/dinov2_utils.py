@@ -5,7 +5,8 @@ Differences that do not change results:
   * blocks after `layer` are not executed (the reference runs the whole backbone and keeps only the hooked
     block's output, dinov2_utils.py:257) and no autograd graph is built;
   * weights: the reference downloads the pretrained hub checkpoint (`pretrained=True`, dinov2_utils.py:82);
-    there is no network here, so pass `state_dict=` (upstream DINOv2 key names) or get seeded random weights.
+    there is no network here, so the checkpoint is read from disk (`weights=`, $FOUNDPOSE_DINOV2_WEIGHTS, the torch hub cache) or
+    passed as `state_dict=`; without one the constructor RAISES (weights.py) -- random weights only with `random_init_seed=`.
 Not implemented: the "attn" facet (the reference's extract_descriptors asserts it away, dinov2_utils.py:285-290).  stride != 14 follows
 what the reference's patch_vit_resolution / _fix_pos_enc state (its own branch cannot run: see __init__).
 """
@@ -18,7 +19,7 @@ from typing import Dict, Optional, Tuple
 import torch
 import torch.nn.functional as F
 
-from . import _lib, synthetic
+from . import _lib, weights as _weights
 from ._lib import call, ptr, stream
 from .vit_config import ARCHS, ExtractorSpec, VitArch, parse_extractor_name
 
@@ -58,9 +59,13 @@ def _interpolate_pos_embed_strided(pos_embed: torch.Tensor, patch: int, stride: 
 
 
 class DinoFeatureExtractor(torch.nn.Module):
-    def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, seed: int = 1234,
-                 precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
+    def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, weights: Optional[str] = None,
+                 random_init_seed: Optional[int] = None, precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
                  act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True) -> None:
+        """Weights (the reference: hub model with pretrained=True, dinov2_utils.py:81-84): `state_dict=` (upstream key names), `weights=` (checkpoint
+        file, or directory holding the upstream file name), else $FOUNDPOSE_DINOV2_WEIGHTS, else the torch hub cache the reference's own call fills;
+        none of them -> FoundPoseWeightsError.  Random weights only on an explicit `random_init_seed=` (tests, benchmarks).  Every dict is checked
+        like load_state_dict(strict=True) (weights.validate_state_dict)."""
         super().__init__()
         self.use_graph = use_graph  # replay the forward's launch sequence as one hipGraph (static buffers per batch shape)
         if arch is not None:  # non-hub architecture (unit tests use a tiny one)
@@ -107,7 +112,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         # qkv / fc1 matrices, shift into their biases, LayerScale into the proj / fc2 matrices -- no LayerNorm kernel runs
         # inside the blocks (they were 6.5 % of a step).  fold_layernorm=False keeps the kernel-per-LayerNorm sequence.
         self.fold_layernorm = bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0"  # FP_LN_FOLD=0: A/B switch
-        self._sd = state_dict if state_dict is not None else synthetic.make_vit_state_dict(self.arch, seed)
+        self._sd, self.weights_source = _weights.resolve(self.model_base_name, self.arch, state_dict, weights, random_init_seed)
         self._device: Optional[torch.device] = None
         self._w: Dict[str, torch.Tensor] = {}
         self._model = None

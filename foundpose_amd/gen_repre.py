@@ -13,7 +13,7 @@ is upstream of this step and outside the path.
 import argparse
 import json
 import os
-from typing import Any, Dict, List, NamedTuple, Optional
+from typing import Any, Dict, List, NamedTuple, Optional, Sequence
 
 import numpy as np
 import torch
@@ -126,7 +126,7 @@ def finish_repre(opts: GenRepreOpts, repre: repre_util.FeatureBasedObjectRepre) 
 
 
 def generate_repre(opts: GenRepreOpts, dataset: str, lid: int, output_path: str, extractor=None, metadata: Optional[List[Dict[str, Any]]] = None,
-                   precision: str = "bf16") -> str:
+                   precision: str = "bf16", weights: Optional[str] = None) -> str:
     """-> the directory holding repre.pth and config.json (<output>/object_repre/<dataset>/<version>/<lid>)."""
     out_dir = repre_util.get_object_repre_dir_path(os.path.join(output_path, "object_repre"), opts.version, dataset, lid)
     if os.path.exists(out_dir) and not opts.overwrite:
@@ -137,8 +137,8 @@ def generate_repre(opts: GenRepreOpts, dataset: str, lid: int, output_path: str,
         cfg["template_desc_opts"] = opts.template_desc_opts._asdict()
     with open(os.path.join(out_dir, "config.json"), "w") as f:
         json.dump(cfg, f, indent=2)
-    if extractor is None:
-        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
+    if extractor is None:  # gen_repre.py:250-251; raises without a checkpoint (weights.py)
+        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision, weights=weights).to("cuda")
     if metadata is None:
         metadata = load_template_metadata(output_path, opts, lid)
     repre = finish_repre(opts, generate_raw_repre(opts, dataset, lid, extractor, metadata))
@@ -148,14 +148,16 @@ def generate_repre(opts: GenRepreOpts, dataset: str, lid: int, output_path: str,
     return out_dir
 
 
-def main() -> None:
+def main(argv: Optional[Sequence[str]] = None) -> None:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--opts", required=True)
     ap.add_argument("--output-path", required=True, help="root holding templates/ (input) and object_repre/ (output)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    args = ap.parse_args()
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16x3", "fp32"])
+    ap.add_argument("--weights", default=None, help="DINOv2 checkpoint file (upstream key names) or a directory holding the upstream file name; "
+                    "default $FOUNDPOSE_DINOV2_WEIGHTS, then the torch hub cache; without one the run fails (no random-weight fallback)")
+    args = ap.parse_args(argv)
     opts = load_opts(args.opts)
-    ex = feature_util.make_feature_extractor(opts.extractor_name, precision=args.precision).to("cuda")
+    ex = feature_util.make_feature_extractor(opts.extractor_name, precision=args.precision, weights=args.weights).to("cuda")
     for lid in opts.object_lids or []:
         print(generate_repre(opts, opts.object_dataset, lid, args.output_path, ex))
 

@@ -70,7 +70,7 @@ def load_opts(path_or_dict) -> InferOpts:
 
 def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBasedObjectRepre, frames: Iterable[Dict[str, Any]],
                  detections: Dict[Any, Any], extractor=None, num_target_insts: Optional[Dict[Tuple[int, int], int]] = None,
-                 precision: str = "bf16", seed: int = 0) -> eval_util.PoseEvaluator:
+                 precision: str = "bf16", seed: int = 0, weights: Optional[str] = None) -> eval_util.PoseEvaluator:
     """One object over a stream of frames (the body of infer.py's per-object loop).  A frame is
     {"scene_id", "im_id", "image": HWC uint8 or float [0,1] (numpy or tensor), "camera": PinholePlaneCameraModel (c2w)}."""
     if opts.match_template_type != "tfidf":
@@ -87,8 +87,8 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
     max_points = int(opts.crop_size[0] // opts.grid_cell_size) * int(opts.crop_size[1] // opts.grid_cell_size)
     if opts.max_num_queries < max_points:
         raise NotImplementedError(f"max_num_queries={opts.max_num_queries} could subsample the {max_points} grid points of a crop: not on the batched path")
-    if extractor is None:
-        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
+    if extractor is None:  # infer.py:125-128; the checkpoint: weights=, $FOUNDPOSE_DINOV2_WEIGHTS or the torch hub cache, else this raises
+        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision, weights=weights).to("cuda")
     bank = DeviceBank([repre])
     eng = fe.FoundPoseEngine(extractor, bank, opts.grid_cell_size, opts.match_top_n_templates, opts.match_top_k_buddies, tie_order="torch")
     eng.record_stage_times = True
@@ -171,14 +171,14 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
 
 
 def infer(opts: InferOpts, frames_by_object, detections, repres: Dict[int, repre_util.FeatureBasedObjectRepre], output_dir: str, extractor=None,
-          precision: str = "bf16", num_target_insts: Optional[Dict[int, Dict[Tuple[int, int], int]]] = None) -> List[str]:
+          precision: str = "bf16", num_target_insts: Optional[Dict[int, Dict[Tuple[int, int], int]]] = None, weights: Optional[str] = None) -> List[str]:
     """All objects: `frames_by_object(lid)` yields the frames that show object `lid`; one estimated-poses.json per object
     under <output_dir>/<lid>/ (infer.py:813-816), then the BOP19 csv.
     num_target_insts: {object lid: {(scene_id, im_id): inst_count}} from test_targets_bop19.json -- the number of poses to
     estimate per (image, object) is num_preds_factor x inst_count (infer.py:308-346); frames without an entry are skipped."""
     lids = list(opts.object_lids) if opts.object_lids is not None else sorted(repres)
     if extractor is None:
-        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision).to("cuda")
+        extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision, weights=weights).to("cuda")
     paths = []
     for lid in lids:
         ev = infer_object(opts, lid, repres[lid], frames_by_object(lid), detections, extractor,
@@ -214,7 +214,7 @@ def load_bop_frames(split_dir: str, targets: Sequence[Dict[str, int]], object_li
         yield {"scene_id": sid, "im_id": iid, "image": image, "camera": camera}
 
 
-def main() -> None:
+def main(argv: Optional[Sequence[str]] = None) -> None:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--opts", required=True, help="options JSON ({'infer_opts': {...}}, e.g. the reference's configs/infer/lmo.json)")
     ap.add_argument("--dataset-dir", required=True, help="BOP split directory (<datasets>/<dataset>/<split>)")
@@ -222,9 +222,14 @@ def main() -> None:
     ap.add_argument("--detections", required=True, help="CNOS detections in the BOP format")
     ap.add_argument("--repre-dir", required=True, help="<output>/object_repre (repre.pth under <version>/<dataset>/<lid>/)")
     ap.add_argument("--output-dir", required=True)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
-    args = ap.parse_args()
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16x3", "fp32"])
+    ap.add_argument("--weights", default=None, help="DINOv2 checkpoint: a .pth with the upstream key names, or a directory holding the upstream file "
+                    "(dinov2_vitl14_pretrain.pth, dinov2_vits14_reg4_pretrain.pth, ...); default $FOUNDPOSE_DINOV2_WEIGHTS, then the torch hub cache. "
+                    "Without a checkpoint the run fails: there is no random-weight fallback")
+    args = ap.parse_args(argv)
     opts = load_opts(args.opts)
+    # the checkpoint is resolved before anything else is read: a missing one must fail in seconds, not after the banks are loaded
+    extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=args.precision, weights=args.weights)
     with open(args.targets or os.path.join(os.path.dirname(os.path.abspath(args.dataset_dir)), "test_targets_bop19.json")) as f:
         targets = json.load(f)
     detections = infer_pose_util.load_detections_in_bop_format(args.detections)
@@ -234,7 +239,7 @@ def main() -> None:
     for t in targets:
         n_inst.setdefault(t["obj_id"], {})[(t["scene_id"], t["im_id"])] = t["inst_count"]
     out = infer(opts._replace(object_lids=list(lids)), lambda lid: load_bop_frames(args.dataset_dir, targets, lid), detections, repres, args.output_dir,
-                precision=args.precision, num_target_insts=n_inst)
+                extractor=extractor.to("cuda"), precision=args.precision, num_target_insts=n_inst)
     print("\n".join(out))
 
 

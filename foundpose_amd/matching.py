@@ -34,6 +34,7 @@ class MatchResult:
     word_ids: Optional[torch.Tensor] = None     # [sumQ, k]
     extractor: Optional[object] = None          # set by the engine in the f16x3 / fp8 modes: corresp_list() asks it whether an activation was
                                                 # clamped on the way (sticky device-side counters, DinoFeatureExtractor.check_saturation)
+    _sat_error: Optional[Exception] = None      # the saturation verdict of this result, once read (see corresp_list)
     ready: Optional["torch.cuda.Event"] = None  # set when the matching ran on the engine's side stream (overlap_matching): the tensors are
                                                 # complete once this event has fired; wait() makes the current stream wait for it
 
@@ -54,10 +55,17 @@ class MatchResult:
     def corresp_list(self, b: int, debug: bool = False) -> List[Dict]:
         """The reference's List[Dict] for detection b (keys as in corresp_util.py:142-163)."""
         self.wait()
-        if self.extractor is not None:   # f16x3: raises FoundPoseSaturationError if the backbone clamped an activation (checked once per result)
+        if self.extractor is not None:   # f16x3: raises FoundPoseSaturationError if the backbone clamped an activation
+            # the counters are read once per result; the verdict is kept, so EVERY access of a clamped result raises (any detection index,
+            # any number of times), not only the first one
             ex, self.extractor = self.extractor, None
             torch.cuda.current_stream().synchronize()
-            ex.check_saturation()
+            try:
+                ex.check_saturation()
+            except Exception as e:
+                self._sat_error = e
+        if self._sat_error is not None:
+            raise self._sat_error
         counts = self.counts[b].tolist()
         tids = self.template_ids[b].tolist()
         out = []

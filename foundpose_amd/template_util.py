@@ -18,6 +18,15 @@ def get_device_bank(object_repre: repre_util.FeatureBasedObjectRepre) -> DeviceB
     return bank
 
 
+def check_top_n(top_n_templates: int, object_repre: repre_util.FeatureBasedObjectRepre) -> None:
+    """The reference selects with torch.topk(scores, k=top_n_templates) (template_util.py:172), which raises when the object has fewer
+    templates than that; the drop-in functions raise the same error with the same message.  (The batched engine clamps instead: it
+    serves objects with different template counts in one batch and marks missing slots with template id -1.)"""
+    num_templates = int(object_repre.template_descs.shape[0])
+    if top_n_templates > num_templates:
+        raise RuntimeError(f"selected index k out of range (top_n_templates = {top_n_templates}, the object has {num_templates} templates)")
+
+
 def find_nearest_object_features(query_features: torch.Tensor, knn_index: knn_util.KNN) -> Tuple[torch.Tensor, torch.Tensor]:
     nn_dists, nn_ids = knn_index.search(query_features)
     return nn_ids, torch.sqrt(nn_dists)  # faiss-style squared distances -> L2
@@ -61,6 +70,7 @@ def tfidf_matching(query_features: torch.Tensor, object_repre: repre_util.Featur
         raise ValueError("Template descriptors need to be tfidf.")
     from .matching import match_batch  # local import: matching imports this module's bank helper
 
+    check_top_n(top_n_templates, object_repre)
     bank = get_device_bank(object_repre)
     qf = query_features.to("cuda", torch.float32)
     pts = torch.zeros(qf.shape[0], 2, dtype=torch.float32, device="cuda")

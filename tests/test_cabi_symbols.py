@@ -48,7 +48,7 @@ def test_bank_builder_entry_points_refuse_cpu_tensors_and_bad_names():
         feature_util.make_feature_extractor("resnet50")                      # feature_util.py:18-23 in the reference
     with pytest.raises(AssertionError, match="should divide patch_size"):                    # dinov2_utils.py:378-380 in the reference
         feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=5_facet=token_layer=9_norm=1")
-    assert feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=7_facet=token_layer=9_norm=1").stride == 7
+    assert feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=7_facet=token_layer=9_norm=1", random_init_seed=0).stride == 7
     with pytest.raises(NotImplementedError):
         feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=attn_layer=9_norm=1")
     with pytest.raises(ValueError):

@@ -45,13 +45,13 @@ def test_activation_rows_are_padded_to_whole_tiles_of_both_heights():
     (folded LayerNorm) or fp8 path can take the taller tile and the padding costs < 3 % more rows."""
     from foundpose_amd import feature_util
     name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=2_norm=1"
-    bf = feature_util.make_feature_extractor(name, seed=1, precision="bf16")
+    bf = feature_util.make_feature_extractor(name, random_init_seed=1, precision="bf16")
     assert bf.padded_rows(32 * 1374) == 44800 and bf.padded_rows(24 * 1374) == 33280      # the bench batch, and a batch of 24
     assert bf.padded_rows(1374) == 1536 and bf.padded_rows(5 * 261) == 1536                # small batches: 256-row tiles only
     assert bf.padded_rows(44800) == 44800 and bf.padded_rows(44801) == 46080
     for rows in (1, 255, 256, 257, 43968, 100000):
         assert bf.padded_rows(rows) % 256 == 0 and rows <= bf.padded_rows(rows) <= max(256, int(rows * 1.03) + 255)
-    f32 = feature_util.make_feature_extractor(name, seed=1, precision="fp32")
+    f32 = feature_util.make_feature_extractor(name, random_init_seed=1, precision="fp32")
     assert f32.padded_rows(32 * 1374) == 44032                                              # no taller tile in the fp32 mode
-    plain = feature_util.make_feature_extractor(name, seed=1, precision="bf16", fold_layernorm=False)
+    plain = feature_util.make_feature_extractor(name, random_init_seed=1, precision="bf16", fold_layernorm=False)
     assert plain.padded_rows(32 * 1374) == 44032

@@ -94,7 +94,7 @@ def test_build_object_repre_end_to_end_retrieval():
     """Templates -> ViT features -> PCA -> k-means words -> tf-idf descriptors -> bank; a query crop that IS template 7
     then retrieves template 7 first and its correspondences point back at template 7's own patches (distance 0)."""
     from foundpose_amd import bank_builder, corresp_util, feature_util, synthetic
-    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", seed=3).to("cuda")
+    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", random_init_seed=3).to("cuda")
     T, S = 24, 224
     templates = synthetic.make_crops(T, S, seed=11)
     masks = synthetic.make_disc_mask(S).unsqueeze(0).repeat(T, 1, 1)
@@ -117,7 +117,7 @@ def test_register_templates_in_3d_batched_equals_per_template():
     """bank_builder.register_templates_in_3d (batched) == feature_util.get_visual_features_registered_in_3d per template
     (the reference's per-template routine, feature_util.py:162-237), and the lifted vertices re-project onto their pixels."""
     from foundpose_amd import bank_builder, crop_util, feature_util, synthetic
-    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", seed=3).to("cuda")
+    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1", random_init_seed=3).to("cuda")
     T, S = 5, 224
     templates = synthetic.make_crops(T, S, seed=4).cuda()
     masks = synthetic.make_disc_mask(S).unsqueeze(0).repeat(T, 1, 1).cuda()

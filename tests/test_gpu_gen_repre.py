@@ -50,7 +50,7 @@ def test_gen_repre_from_templates_dir_then_inference(tmp_path):
     opts = gen_repre.load_opts({"gen_repre_opts": {"version": "v1", "templates_version": "v1", "object_dataset": "synth", "object_lids": [4],
                                                    "extractor_name": NAME, "grid_cell_size": 14.0, "apply_pca": True, "pca_components": 64,
                                                    "cluster_features": True, "cluster_num": 48, "template_desc_opts": {"desc_type": "tfidf"}}})
-    ex = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    ex = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
     out_dir = gen_repre.generate_repre(opts, "synth", 4, str(tmp_path), extractor=ex)
     assert out_dir == os.path.join(str(tmp_path), "object_repre", "synth", "v1", "4") and os.path.exists(os.path.join(out_dir, "config.json"))
     r = repre_util.load_object_repre(out_dir)

@@ -15,7 +15,8 @@ pytestmark = pytest.mark.gpu
 NAME = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1"
 
 
-def test_infer_driver_synthetic_scene(tmp_path):
+def _scene(tmp_path, ex):
+    """Options JSON, CNOS detections, one frame and a repre.pth whose templates 3 and 7 are the two instances' own crops -> the pieces of a run."""
     g = torch.Generator().manual_seed(0)
     H, W = 480, 640
     image = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy()
@@ -40,7 +41,6 @@ def test_infer_driver_synthetic_scene(tmp_path):
     assert opts.crop_size == (224, 224) and opts.pnp_refine_lm is True and opts.pnp_required_ransac_conf == 0.99
 
     # ---- the bank: the two instances' own crops as templates 3 and 7 (vertices from planted poses in their crop cameras)
-    ex = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
     img_f = torch.from_numpy(image).cuda().float() / 255.0
     boxes_xyxy = [[x, y, x + w, y + h] for x, y, w, h in boxes_xywh]
     crops, crop_masks, cams = crop_util.crop_detections(img_f, torch.from_numpy(masks).cuda(), boxes_xyxy, cam, (224, 224), 0.2)
@@ -64,6 +64,13 @@ def test_infer_driver_synthetic_scene(tmp_path):
     rdir = repre_util.get_object_repre_dir_path(str(tmp_path / "object_repre"), opts.repre_version, opts.object_dataset, 1)
     repre_util.save_object_repre(repre, rdir)
 
+    return dict(image=image, cam=cam, cams=cams, masks=masks, boxes_xyxy=boxes_xyxy, det_path=det_path, opts_path=opts_path, opts=opts, rdir=rdir, R=R, t=t)
+
+
+def test_infer_driver_synthetic_scene(tmp_path):
+    ex = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
+    sc = _scene(tmp_path, ex)
+    image, cam, cams, masks, boxes_xyxy, det_path, opts, rdir, R, t = (sc[k] for k in ("image", "cam", "cams", "masks", "boxes_xyxy", "det_path", "opts", "rdir", "R", "t"))
     # ---- the driver
     frames = lambda lid: iter([{"scene_id": 1, "im_id": 3, "image": image, "camera": cam}])
     out_dir = str(tmp_path / "inference")
@@ -123,3 +130,56 @@ def test_infer_driver_synthetic_scene(tmp_path):
     assert len(run_gt("g2", [Anno(1, 0.9, 0), Anno(1, 0.5, 1)])) == 2          # two visible annotations of object 1 -> two predictions
     assert len(run_gt("g1", [Anno(1, 0.9, 0), Anno(1, 0.05, 1), Anno(2, 0.9, 1)])) == 1   # visibility 0.05 <= min_visibility 0.1, and another object's annotation
     assert run_gt("g0", [Anno(1, float("nan"), 0), Anno(2, 0.9, 1)]) == []     # annotations present but none qualifies: the frame is skipped
+
+
+def test_cli_loads_an_upstream_layout_checkpoint_file(tmp_path):
+    """`python -m foundpose_amd.infer --weights <dir>`: the checkpoint file (upstream hub name, upstream key names, mask_token included) is what the
+    run computes with -- poses equal to those of an extractor built from the same state dict in memory -- and without a checkpoint the CLI raises
+    (/root/reference/utils/dinov2_utils.py:81-84: pretrained=True; scripts/infer.py:125-128)."""
+    from PIL import Image
+    from foundpose_amd import synthetic, weights
+    from foundpose_amd.vit_config import ARCHS
+    sd = synthetic.make_vit_state_dict(ARCHS["vits14-reg"], seed=77)
+    assert "mask_token" in sd
+    ckdir = tmp_path / "ckpt"
+    ckdir.mkdir()
+    torch.save(sd, ckdir / "dinov2_vits14_reg4_pretrain.pth")
+    ex = feature_util.make_feature_extractor(NAME, state_dict=sd, precision="fp32").to("cuda")
+    sc = _scene(tmp_path, ex)
+    # the BOP split on disk: <split>/<scene:06d>/rgb/<im:06d>.png + scene_camera.json, test_targets_bop19.json beside the split
+    split = tmp_path / "synth" / "test"
+    (split / "000001" / "rgb").mkdir(parents=True)
+    Image.fromarray(sc["image"]).save(split / "000001" / "rgb" / "000003.png")
+    cam = sc["cam"]
+    (split / "000001" / "scene_camera.json").write_text(json.dumps({"3": {"cam_K": [cam.f[0], 0, cam.c[0], 0, cam.f[1], cam.c[1], 0, 0, 1], "depth_scale": 1.0}}))
+    (tmp_path / "synth" / "test_targets_bop19.json").write_text(json.dumps([{"scene_id": 1, "im_id": 3, "obj_id": 1, "inst_count": 1}]))
+    argv = ["--opts", str(sc["opts_path"]), "--dataset-dir", str(split), "--detections", str(sc["det_path"]), "--repre-dir", str(tmp_path / "object_repre"),
+            "--precision", "fp32"]
+    old_hub = torch.hub.get_dir()
+    torch.hub.set_dir(str(tmp_path / "empty_hub"))
+    env = os.environ.pop(weights.ENV_VAR, None)
+    try:
+        with pytest.raises(weights.FoundPoseWeightsError, match="dinov2_vits14_reg4_pretrain.pth"):
+            infer.main(argv + ["--output-dir", str(tmp_path / "out_none")])
+        infer.main(argv + ["--output-dir", str(tmp_path / "out_cli"), "--weights", str(ckdir)])
+        os.environ[weights.ENV_VAR] = str(ckdir / "dinov2_vits14_reg4_pretrain.pth")
+        infer.main(argv + ["--output-dir", str(tmp_path / "out_env")])
+    finally:
+        torch.hub.set_dir(old_hub)
+        os.environ.pop(weights.ENV_VAR, None)
+        if env is not None:
+            os.environ[weights.ENV_VAR] = env
+    frames = lambda lid: iter([{"scene_id": 1, "im_id": 3, "image": sc["image"], "camera": cam}])
+    infer.infer(sc["opts"], frames, infer_pose_util.load_detections_in_bop_format(str(sc["det_path"])), {1: repre_util.load_object_repre(sc["rdir"])},
+                str(tmp_path / "out_mem"), extractor=ex, num_target_insts={1: {(1, 3): 1}})
+    want = json.load(open(tmp_path / "out_mem" / "1" / "estimated-poses.json"))
+    assert len(want) == 2
+    for tag in ("out_cli", "out_env"):
+        got = json.load(open(tmp_path / tag / "1" / "estimated-poses.json"))
+        assert [(e["inst_id"], e["R"], e["t"], e["score"]) for e in got] == [(e["inst_id"], e["R"], e["t"], e["score"]) for e in want], tag
+    # another checkpoint gives other poses scores: the file is really what is read (not a seed default)
+    torch.save(synthetic.make_vit_state_dict(ARCHS["vits14-reg"], seed=78), ckdir / "other.pth")
+    infer.main(argv + ["--output-dir", str(tmp_path / "out_other"), "--weights", str(ckdir / "other.pth")])
+    p = tmp_path / "out_other" / "1" / "estimated-poses.json"
+    other = json.load(open(p)) if p.exists() else []
+    assert [(e["R"], e["score"]) for e in other] != [(e["R"], e["score"]) for e in want]

@@ -39,14 +39,14 @@ def _run(eng, wl, chunk):
 def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, templates, n_cpu, version):
     arch = ARCHS[version]
     NAME = f"dinov2_version={version}_stride=14_facet=token_layer=18_norm=1"
-    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, batch, 518, objects, templates, seed=11, crop_seed=3)
     bank = DeviceBank(wl.repres)
     got32 = _run(fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order="torch"), wl, 32)
-    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    exbf = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="bf16").to("cuda")
     gotbf = _run(fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch"), wl, batch)  # the benchmarked call: one batch
     del exbf
-    ex3 = feature_util.make_feature_extractor(NAME, seed=1234, precision="f16x3").to("cuda")   # the near-exact mode bench.py times as `parity_mode`
+    ex3 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="f16x3").to("cuda")   # the near-exact mode bench.py times as `parity_mode`
     got3 = _run(fe.FoundPoseEngine(ex3, bank, 14.0, 5, 300, tie_order="torch"), wl, 32)
     del ex3
 
@@ -96,13 +96,13 @@ def test_config1_lmo_geometry_vs_oracle_a():
     tie order) index for index; the bf16 mode's agreement is reported and held to the same templates."""
     name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_logbin=0_norm=1"   # configs/infer/lmo.json:12
     arch = ARCHS["vits14-reg"]
-    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, 1, 420, 1, 100, seed=21, crop_seed=4)
     assert wl.crops.shape == (1, 3, 420, 420)
     bank = DeviceBank(wl.repres)
     runs = {"fp32": _run(fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order="torch"), wl, 1)}
     for prec in ("f16x3", "bf16"):
-        ex = feature_util.make_feature_extractor(name, seed=1234, precision=prec).to("cuda")
+        ex = feature_util.make_feature_extractor(name, random_init_seed=1234, precision=prec).to("cuda")
         runs[prec] = _run(fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch"), wl, 1)
     sd = synthetic.make_vit_state_dict(arch, seed=1234)
     repre = wl.repres[0]
@@ -137,12 +137,12 @@ def test_bf16_mode_index_exact_vs_oracle_b_on_fixture_with_verified_margins():
     from oracle import match as om
     arch = ARCHS["vitl14-reg"]
     batch, templates = 8, 200
-    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, batch, 518, 1, templates, seed=17, crop_seed=9, noise=(0.05, 0.10, 0.15, 0.20, 0.25),
                                          patch_frac=(1.0, 1.0, 1.0, 1.0, 1.0))
     del ex32
     bank = DeviceBank(wl.repres)
-    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    exbf = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="bf16").to("cuda")
     res = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj, keep_debug=True)
     got = [res.corresp_list(b) for b in range(batch)]
     counts = [int(wl.masks[b, 7::14, 7::14].sum()) for b in range(batch)]
@@ -204,14 +204,14 @@ def test_default_backbone_dinov2_vitl14_vs_oracle_a():
     (fp32 CPU features -> oracle/match.py, the reference's tie order) index for index on a sample, f16x3 == fp32 mode on every slot."""
     name, batch, templates = "dinov2_vitl14", 32, 800
     arch = ARCHS["vitl14"]
-    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to("cuda")
     assert ex32.layer == 9 and ex32.arch.registers == 0
     wl = workload.build_planted_workload(ex32, batch, 518, 1, templates, seed=13, crop_seed=6)
     bank = DeviceBank(wl.repres)
     runs = {"fp32": _run(fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order="torch"), wl, 32)}
     del ex32
     for prec in ("f16x3", "bf16"):
-        ex = feature_util.make_feature_extractor(name, seed=1234, precision=prec).to("cuda")
+        ex = feature_util.make_feature_extractor(name, random_init_seed=1234, precision=prec).to("cuda")
         assert ex.supports_token_selection
         runs[prec] = _run(fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch"), wl, batch)
         del ex
@@ -245,7 +245,7 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
     block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark
     geometry (ViT-L/14-reg layer 18, 518 px) with masks of different sizes in one batch (one of them empty: an image
     without a selected token), in the bf16 mode and in the f16x3 mode."""
-    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, 8, 518, 1, 200, seed=5, crop_seed=1)
     del ex32
     bank = DeviceBank(wl.repres)
@@ -255,7 +255,7 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
     masks[2, 200:260, 100:400] = 1  # a bar
     masks[3] = 1                    # everything
     masks[5] = 0                    # no query point at all: the detection selects no token
-    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision=precision).to("cuda")
+    exbf = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision=precision).to("cuda")
     eng = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
     assert exbf.supports_token_selection
     monkeypatch.setenv("FP_TOKEN_SELECT", "1")
@@ -270,11 +270,11 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
 def test_overlap_matching_same_results():
     """overlap_matching=True runs the matching stage on the engine's side stream beside the next batch's backbone: two
     back-to-back batches give the tensors of the plain engine, once `ready` has fired."""
-    ex32 = feature_util.make_feature_extractor(NAME, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, 8, 518, 1, 200, seed=5, crop_seed=1)
     del ex32
     bank = DeviceBank(wl.repres)
-    exbf = feature_util.make_feature_extractor(NAME, seed=1234, precision="bf16").to("cuda")
+    exbf = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="bf16").to("cuda")
     plain = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
     over = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch", overlap_matching=True)
     want = [plain.infer_batch(wl.crops[i:i + 4], wl.masks[i:i + 4], wl.det_obj[i:i + 4]) for i in (0, 4)]

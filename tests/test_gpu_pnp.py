@@ -120,10 +120,10 @@ def test_engine_to_pose_on_planted_workload(precision):
     from foundpose_amd import feature_util, workload
     from foundpose_amd.bank import DeviceBank
     name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1"
-    ex32 = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    ex32 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex32, 16, 224, 2, 400, seed=3, crop_seed=1)
     bank = DeviceBank(wl.repres)
-    ex = ex32 if precision == "fp32" else feature_util.make_feature_extractor(name, seed=1234, precision="bf16").to("cuda")
+    ex = ex32 if precision == "fp32" else feature_util.make_feature_extractor(name, random_init_seed=1234, precision="bf16").to("cuda")
     res = fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
     poses = pnp_util.estimate_poses(res, [wl.K.numpy()] * 16, "opencv", 400, 10.0, 0.99, True)
     best = pnp_util.select_best_coarse(poses)

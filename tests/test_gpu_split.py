@@ -285,7 +285,7 @@ def test_f16x3_saturation_is_loud(where):
     ex32 = feature_util.make_feature_extractor(name, state_dict=sd, precision="fp32").to("cuda")
     assert bool(torch.isfinite(ex32(imgs)["feature_maps"]).all())
     # through the engine: the result raises when its correspondences are read
-    clean = feature_util.make_feature_extractor(name, seed=5, precision="f16x3").to("cuda")
+    clean = feature_util.make_feature_extractor(name, random_init_seed=5, precision="f16x3").to("cuda")
     wl = workload.build_planted_workload(clean, 3, 112, 1, 40, seed=3, crop_seed=2)
     bank = DeviceBank(wl.repres)
     res = fe.FoundPoseEngine(clean, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
@@ -301,12 +301,12 @@ def test_fp8_saturation_is_reported():
     from foundpose_amd import feature_util
     name = "dinov2_version=vitb14-reg_stride=14_facet=token_layer=2_norm=1"
     imgs = synthetic.make_crops(2, 112, seed=4).cuda()
-    ex = feature_util.make_feature_extractor(name, seed=7, precision="fp8").to("cuda")
+    ex = feature_util.make_feature_extractor(name, random_init_seed=7, precision="fp8").to("cuda")
     scales = ex.calibrate_fp8(imgs)
-    roomy = feature_util.make_feature_extractor(name, seed=7, precision="fp8", act_scales=scales * 0.5).to("cuda")   # 2x head room over the calibration maxima
+    roomy = feature_util.make_feature_extractor(name, random_init_seed=7, precision="fp8", act_scales=scales * 0.5).to("cuda")   # 2x head room over the calibration maxima
     roomy(imgs)
     assert roomy.saturation_counts() == (0, 0)
-    bad = feature_util.make_feature_extractor(name, seed=7, precision="fp8", act_scales=scales * 8.0).to("cuda")
+    bad = feature_util.make_feature_extractor(name, random_init_seed=7, precision="fp8", act_scales=scales * 8.0).to("cuda")
     with pytest.warns(UserWarning, match="clamped an activation at"):
         bad(imgs)
     assert bad.saturation_counts()[1] > 0 and bad.saturation_counts()[0] == 0

@@ -182,7 +182,7 @@ def test_extractor_key_query_value_facets_vs_reference_wrapper_fixture(precision
 
 def _extractor(arch, name, seed, precision):
     from foundpose_amd import feature_util
-    ex = feature_util.make_feature_extractor(name, seed=seed, precision=precision, arch=arch if arch in (TINY, TINY0) else None)
+    ex = feature_util.make_feature_extractor(name, random_init_seed=seed, precision=precision, arch=arch if arch in (TINY, TINY0) else None)
     return ex.to("cuda")
 
 
@@ -307,7 +307,7 @@ def test_extractor_stride_through_the_engine():
     from foundpose_amd import corresp_util, engine as fe, feature_util, projector_util, workload
     from foundpose_amd.bank import DeviceBank
     name = "dinov2_version=vits14-reg_stride=7_facet=token_layer=3_norm=1"
-    ex = feature_util.make_feature_extractor(name, seed=1234, precision="fp32").to("cuda")
+    ex = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to("cuda")
     wl = workload.build_planted_workload(ex, 3, 112, 1, 60, seed=2, crop_seed=1)
     repre = wl.repres[0]
     res = fe.FoundPoseEngine(ex, DeviceBank(wl.repres), 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
@@ -396,7 +396,7 @@ def test_extractor_swiglu_ffn(precision, tol):
 def test_vitg_shapes_run():
     """The real ViT-g/14-reg geometry (D=1536, 24 heads, SwiGLU hidden 4096) runs end to end (2 blocks, 1 crop)."""
     from foundpose_amd import feature_util
-    ex = feature_util.make_feature_extractor("dinov2_version=vitg14-reg_stride=14_facet=token_layer=1_norm=1", seed=3).to("cuda")
+    ex = feature_util.make_feature_extractor("dinov2_version=vitg14-reg_stride=14_facet=token_layer=1_norm=1", random_init_seed=3).to("cuda")
     fm = ex(synthetic.make_crops(1, 518, seed=0).cuda())["feature_maps"]
     assert fm.shape == (1, 1536, 37, 37) and bool(torch.isfinite(fm).all())
 
@@ -406,8 +406,8 @@ def test_extractor_hipgraph_replay_is_bit_identical():
     also on the second replay with new pixels in the static input buffer."""
     from foundpose_amd import feature_util
     name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1"
-    eager = feature_util.make_feature_extractor(name, seed=11).to("cuda")
-    graph = feature_util.make_feature_extractor(name, seed=11, use_graph=True).to("cuda")
+    eager = feature_util.make_feature_extractor(name, random_init_seed=11).to("cuda")
+    graph = feature_util.make_feature_extractor(name, random_init_seed=11, use_graph=True).to("cuda")
     for seed in (0, 1, 2):
         imgs = synthetic.make_crops(3, 224, seed=seed).cuda()
         a, b = eager(imgs), graph(imgs)
@@ -568,7 +568,7 @@ def test_extractor_fp8_mode_vs_oracle_c(ffn):
                    pretrain_grid=4, interp_antialias=True, interp_offset=0.0)
     name = f"dinov2_version={arch.name}_stride=14_facet=token_layer=2_logbin=0_norm=1"
     from foundpose_amd import feature_util
-    mk = lambda: feature_util.make_feature_extractor(name, seed=77, precision="fp8", arch=arch).to("cuda")
+    mk = lambda: feature_util.make_feature_extractor(name, random_init_seed=77, precision="fp8", arch=arch).to("cuda")
     ex = mk()
     imgs = synthetic.make_crops(3, 56, seed=5)
     with pytest.raises(_lib.FoundPoseNativeError, match="static activation scales"):
@@ -589,7 +589,7 @@ def test_extractor_fp8_mode_vs_oracle_c(ffn):
     ex2 = mk()
     ex2.calibrate_fp8(act_scales=scales)
     assert torch.equal(ex2(imgs.cuda())["feature_maps"].cpu(), fm)
-    ex3 = feature_util.make_feature_extractor(name, seed=77, precision="fp8", arch=arch, act_scales=scales).to("cuda")  # scales as part of the model
+    ex3 = feature_util.make_feature_extractor(name, random_init_seed=77, precision="fp8", arch=arch, act_scales=scales).to("cuda")  # scales as part of the model
     assert torch.equal(ex3(imgs.cuda())["feature_maps"].cpu(), fm)
     assert torch.equal(ex.act_scales, scales) and torch.isfinite(ex(synthetic.make_crops(2, 56, seed=6).cuda())["feature_maps"]).all()
 
@@ -782,7 +782,7 @@ def test_fused_norm_and_sampling_is_bit_identical(version, size, precision):
     and outside the image, where the four taps and the zero padding matter."""
     from foundpose_amd import feature_util, ops
     layer = 3
-    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision=precision).to("cuda")
+    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", random_init_seed=8, precision=precision).to("cuda")
     B = 3
     imgs = synthetic.make_crops(B, size, seed=2).cuda()
     g = torch.Generator().manual_seed(0)
@@ -806,7 +806,7 @@ def test_selected_tokens_in_hooked_block_bit_identical(version, size, layer, pre
     thin bar, a single cell, everything), points on and off the cell centres."""
     from foundpose_amd import feature_util
     from foundpose_amd.engine import FoundPoseEngine
-    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", seed=8, precision=precision).to("cuda")
+    ex = feature_util.make_feature_extractor(f"dinov2_version={version}_stride=14_facet=token_layer={layer}_norm=1", random_init_seed=8, precision=precision).to("cuda")
     assert ex.supports_token_selection
     B = 4
     imgs = synthetic.make_crops(B, size, seed=5).cuda()
@@ -851,7 +851,7 @@ def test_query_select_equals_filter_points_by_mask(dtype):
     an empty one, a full one, pixels on the canvas border."""
     from foundpose_amd import feature_util
     from foundpose_amd.engine import FoundPoseEngine
-    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=1_norm=1", seed=8, precision="bf16").to("cuda")
+    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=1_norm=1", random_init_seed=8, precision="bf16").to("cuda")
     g = torch.Generator().manual_seed(3)
     for size, cell in ((224, 14.0), (210, 10.0), (126, 7.0), ((280, 168), 14.0)):   # the last one: width != height
         B = 5

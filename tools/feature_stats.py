@@ -15,7 +15,7 @@ else:  # the planted workload's crops: 682 textures, distinct inside the mask
 masks = m.unsqueeze(0).repeat(B, 1, 1).cuda()
 f = {}
 for prec in ("fp32", "bf16"):
-    ex = feature_util.make_feature_extractor(name, seed=1234, precision=prec).to("cuda")
+    ex = feature_util.make_feature_extractor(name, random_init_seed=1234, precision=prec).to("cuda")
     f[prec], pts, counts = workload.query_features(ex, crops, masks)
     del ex
 x = f["fp32"]
