@@ -838,15 +838,18 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
     const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
     _Float16* o = reinterpret_cast<_Float16*>(a.out) + orow * a.ld_out + head * 128;
+    // a convex combination of v rows that fit their scale cannot clamp -- but a NaN / Inf born inside the attention (an overflowing score)
+    // would leave the v_med3 of the packing as a finite operand: the NaN-propagating running maximum is what reports it
+    float o_amax = 0.f;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         unsigned xh0, xl0, xh1, xl1, yh0, yl0, yh1, yl1;
-        split16_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xl0);
-        split16_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xl1);
-        split16_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yl0);
-        split16_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yl1);
+        split16_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xl0, o_amax);
+        split16_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xl1, o_amax);
+        split16_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yl0, o_amax);
+        split16_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yl1, o_amax);
         const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
         const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
         const auto l0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false);
@@ -857,6 +860,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
           *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
         }
       }
+    if (q < NQ) report_saturation(a.sat, 0, o_amax, FP_F16_MAX);
   }
 }
 

@@ -50,9 +50,13 @@ FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3) {
   int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v0), clamp448(v1), 0, false);
   return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(clamp448(v2), clamp448(v3), w, true);
 }
+// NaN-PROPAGATING maximum (v_maximum3_f32 on gfx950; fmaxf / v_max3_f32 would drop a NaN operand): the running maxima of the saturation
+// report must see a NaN activation -- the clamps below (v_med3, fminf / fmaxf) turn it into a finite operand, so the report is the only
+// place it can surface.
+FP_DEVICE float nanmax3(float a, float b, float c) { return __builtin_elementwise_maximum(a, __builtin_elementwise_maximum(b, c)); }
 // ... and the largest magnitude that went in (saturation report: a value beyond +-448 was clamped)
 FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3, float& amax) {
-  amax = fmaxf(fmaxf(amax, fmaxf(fabsf(v0), fabsf(v1))), fmaxf(fabsf(v2), fabsf(v3)));  // v_max3_f32 with |.| modifiers
+  amax = nanmax3(nanmax3(amax, fabsf(v0), fabsf(v1)), fabsf(v2), fabsf(v3));  // v_maximum3_f32 with |.| modifiers
   return pack_fp8x4(v0, v1, v2, v3);
 }
 // Sticky saturation counters (fp_vit_workspace.sat, include/foundpose_amd.h): slot 0 counts split-fp16 clamps (|s x| > 65504),
@@ -60,7 +64,7 @@ FP_DEVICE unsigned pack_fp8x4(float v0, float v1, float v2, float v3, float& ama
 // once at the end of the kernel; an atomic is issued only when something actually clamped.
 constexpr float FP_F16_MAX = 65504.f, FP_E4M3_MAX = 448.f;
 FP_DEVICE void report_saturation(int* sat, int slot, float amax, float limit) {
-  if (sat != nullptr && amax > limit) atomicAdd(sat + slot, 1);
+  if (sat != nullptr && !(amax <= limit)) atomicAdd(sat + slot, 1);  // amax comes from nanmax3: a NaN among the packed values reports too
 }
 
 FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
@@ -87,7 +91,7 @@ FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsign
 }
 // ... and the running maximum of |s x| the caller reports at the end of the kernel (report_saturation)
 FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsigned& lo, float& amax) {
-  amax = fmaxf(amax, fmaxf(fabsf(a * scale), fabsf(b * scale)));  // v_max3_f32 with |.| modifiers
+  amax = nanmax3(amax, fabsf(a * scale), fabsf(b * scale));  // v_maximum3_f32 with |.| modifiers
   split16_pack2(a, b, scale, hi, lo);
 }
 // position (in halves) of logical column c inside a split row; its lo half sits 32 halves further

@@ -514,7 +514,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
         }
       if constexpr (SPOUT || F8OUT) {
-        if (m < a.M_valid) sat_amax = fmaxf(sat_amax, band_amax);  // padding rows (computed, never stored) do not report
+        if (m < a.M_valid) sat_amax = nanmax3(sat_amax, band_amax, 0.f);  // padding rows (computed, never stored) do not report
       }
       __syncthreads();
       // (b) slab -> global, whole rows

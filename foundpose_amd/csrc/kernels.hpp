@@ -173,8 +173,8 @@ struct AttnArgs {
   int variant;
   int tail_last;                 // set by the launcher (bf16 w64 kernel): the last (short) query tile of every (image, head) pair goes to the END of its XCD's block sequence
   float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
-  int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps (the split-fp16
-                                 // output is a convex combination of v rows that already fit their scale: it cannot clamp)
+  int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps; the split-fp16
+                                 // output (a convex combination of v rows that already fit their scale) cannot clamp and reports non-finite values only
 };
 int attn_launch(const AttnArgs& a, int dtype, hipStream_t st);
 

@@ -420,12 +420,20 @@ class DinoFeatureExtractor(torch.nn.Module):
     def check_saturation(self) -> None:
         """Raises FoundPoseSaturationError if the f16x3 mode clamped an activation since the last reset (sticky: it keeps raising until
         reset_saturation()); warns once if the fp8 mode clamped beyond its calibration scales (expected now and then with static
-        scales, but never silent).  Synchronises.  forward() calls it; the batched engine's results call it when they are read."""
-        n16, n8 = self.saturation_counts()
+        scales, but never silent).  Synchronises.  forward() calls it; the batched engine attributes clamps to the batch that caused them
+        instead (saturation_snapshot / report_saturation: a result raises for its own batch only)."""
+        self.report_saturation(*self.saturation_counts())
+
+    def saturation_snapshot(self) -> Optional[torch.Tensor]:
+        """Device-side copy of the two counters, enqueued on the current stream (no sync); None before the first workspace exists (= zeros)."""
+        return None if self._sat is None else self._sat.clone()
+
+    def report_saturation(self, n16: int, n8: int) -> None:
+        """The verdict for a pair of counts (split-fp16 clamps, e4m3 clamps): raises in the f16x3 mode, warns once in the fp8 mode."""
         if n16 and self.precision == "f16x3":
             raise _lib.FoundPoseSaturationError(
                 f"precision='f16x3': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
-                f"LayerNorm outputs / q / k / v, > {65504 / _lib.SPLIT_SCALE_HID:.0f} for hidden activations): the features are not the fp32 "
+                f"LayerNorm outputs / q / k / v, > {65504 / _lib.SPLIT_SCALE_HID:.0f} for hidden activations) or met a NaN: the features are not the fp32 "
                 "arithmetic's.  Use precision='fp32' for this checkpoint (or reset_saturation() to acknowledge).")
         if n8 and self.precision == "fp8" and not self._fp8_sat_warned:
             import warnings

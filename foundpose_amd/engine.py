@@ -138,6 +138,10 @@ class FoundPoseEngine:
         select = fused and self.extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0"
         self._stage_events = []
         self._mark("start")
+        # f16x3 / fp8: clamped activations are reported per BATCH -- the sticky device counters are snapshotted before and after the backbone
+        # of this batch (two 8-byte device copies, no sync); the result raises / warns for what ITS batch clamped, whatever happened before
+        track_sat = self.extractor.precision in ("f16x3", "fp8")
+        sat0 = self.extractor.saturation_snapshot() if track_sat else None
         pending = self._query_points_begin(masks, select_tokens=select)
         if select:
             self.extractor.forward_hidden(images, prefix_only=True)  # ~115 launches enqueued before the host waits for the counts
@@ -159,13 +163,17 @@ class FoundPoseEngine:
             D = fmap.shape[-1]
             raw = ops.sample_bilinear(fmap.reshape(B, gh, gw, D).permute(0, 3, 1, 2), q_pts, q_img, (W, H))
         self._mark("grid_sample")
+        sat_delta = None
+        if track_sat:
+            sat1 = self.extractor.saturation_snapshot()
+            sat_delta = sat1 if sat0 is None else sat1 - sat0
         if not self.overlap_matching:
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")
             res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
             self._mark("corresp")
-            if self.extractor.precision in ("f16x3", "fp8"):
-                res.extractor = self.extractor   # corresp_list() checks the sticky saturation counters of the backbone
+            if track_sat:
+                res.extractor, res.sat_delta = self.extractor, sat_delta   # corresp_list() reads the verdict of this batch
             return res
         main, side = torch.cuda.current_stream(), self.side_stream
         produced = torch.cuda.Event()
@@ -180,8 +188,8 @@ class FoundPoseEngine:
             self._mark("corresp")
             res.ready = torch.cuda.Event()
             res.ready.record(side)
-        if self.extractor.precision in ("f16x3", "fp8"):
-            res.extractor = self.extractor
+        if track_sat:
+            res.extractor, res.sat_delta = self.extractor, sat_delta
         return res
 
     @property

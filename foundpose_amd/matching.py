@@ -34,6 +34,7 @@ class MatchResult:
     word_ids: Optional[torch.Tensor] = None     # [sumQ, k]
     extractor: Optional[object] = None          # set by the engine in the f16x3 / fp8 modes: corresp_list() asks it whether an activation was
                                                 # clamped on the way (sticky device-side counters, DinoFeatureExtractor.check_saturation)
+    sat_delta: Optional[torch.Tensor] = None    # [2] i32 on the device: clamps counted during this batch's backbone (f16x3, fp8)
     _sat_error: Optional[Exception] = None      # the saturation verdict of this result, once read (see corresp_list)
     ready: Optional["torch.cuda.Event"] = None  # set when the matching ran on the engine's side stream (overlap_matching): the tensors are
                                                 # complete once this event has fired; wait() makes the current stream wait for it
@@ -59,9 +60,12 @@ class MatchResult:
             # the counters are read once per result; the verdict is kept, so EVERY access of a clamped result raises (any detection index,
             # any number of times), not only the first one
             ex, self.extractor = self.extractor, None
-            torch.cuda.current_stream().synchronize()
             try:
-                ex.check_saturation()
+                if self.sat_delta is not None:       # what THIS batch clamped (engine: counters snapshotted around its backbone)
+                    ex.report_saturation(*(int(v) for v in self.sat_delta.tolist()))
+                else:
+                    torch.cuda.current_stream().synchronize()
+                    ex.check_saturation()
             except Exception as e:
                 self._sat_error = e
         if self._sat_error is not None:

@@ -254,7 +254,7 @@ def test_extractor_f16x3_with_massive_activation_channels():
     assert ex.saturation_counts() == (0, 0)          # ... and the device-side counters agree: nothing was clamped
 
 
-@pytest.mark.parametrize("where", ["layernorm", "qkv", "hidden"])
+@pytest.mark.parametrize("where", ["layernorm", "qkv", "hidden", "nan", "nan_attention"])
 def test_f16x3_saturation_is_loud(where):
     """An activation beyond the range of its split-fp16 row (+-4094 for LayerNorm outputs and q / k / v, +-16376 for the hidden
     activations) is clamped by the producer kernel -- and REPORTED: the sticky device-side counter (fp_vit_workspace.sat) goes up, the
@@ -269,10 +269,18 @@ def test_f16x3_saturation_is_loud(where):
         sd["blocks.1.norm1.bias"][7] = 5000.0          # LayerNorm output channel 7 = 5000 + ... > 4094
     elif where == "qkv":
         sd["blocks.2.attn.qkv.bias"][arch.dim + 3] = -6000.0   # a key channel at -6000
-    else:
+    elif where == "hidden":
         sd["blocks.0.mlp.fc1.bias"][11] = 20000.0      # gelu(20000) = 20000 > 16376
     imgs = synthetic.make_crops(3, 112, seed=2).cuda()
-    ex = feature_util.make_feature_extractor(name, state_dict=sd, precision="f16x3").to("cuda")
+    ex = feature_util.make_feature_extractor(name, state_dict=sd, precision="f16x3")
+    # a NaN activation: the packing clamps (v_med3) would turn it into a FINITE operand and the features would look plausible -- the running
+    # maxima of the report propagate NaN (v_maximum3_f32), so it is as loud as a clamp.  (A checkpoint with a NaN is refused at load time,
+    # weights.validate_state_dict: the NaN is planted behind the validation, into the dict the device copy is made from.)
+    if where == "nan":
+        sd["blocks.1.norm1.bias"][7] = float("nan")             # -> a LayerNorm output
+    elif where == "nan_attention":
+        sd["blocks.2.attn.qkv.bias"][2 * arch.dim + 5] = float("nan")   # -> a value channel: surfaces in qkv's packing AND in the attention output's
+    ex = ex.to("cuda")
     with pytest.raises(_lib.FoundPoseSaturationError, match="clamped an activation"):
         ex(imgs)
     n16, n8 = ex.saturation_counts()
@@ -291,8 +299,17 @@ def test_f16x3_saturation_is_loud(where):
     res = fe.FoundPoseEngine(clean, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
     assert len(res.corresp_list(0)) == 5 and clean.saturation_counts() == (0, 0)     # clean weights: nothing reported, token selection included
     res = fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
+    for b in (0, 1, 0):     # the verdict belongs to the result: every access raises, any detection index, any number of times
+        with pytest.raises(_lib.FoundPoseSaturationError):
+            res.corresp_list(b)
+    # ... and to ITS batch: clamps counted before a batch (here: planted into the sticky counters) do not make a clean batch's result raise,
+    # while the extractor's own forward stays sticky until reset_saturation()
+    clean._sat += 5
+    res = fe.FoundPoseEngine(clean, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
+    assert len(res.corresp_list(0)) == 5 and len(res.corresp_list(2)) == 5
     with pytest.raises(_lib.FoundPoseSaturationError):
-        res.corresp_list(0)
+        clean.check_saturation()
+    clean.reset_saturation()
 
 
 def test_fp8_saturation_is_reported():
