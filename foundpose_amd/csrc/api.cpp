@@ -180,7 +180,7 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   if (pairs == 0) return FP_OK;
   CyclicArgs c;
   memset(&c, 0, sizeof(c));
-  if (knn_cand_enabled() && knn_cand_supported(1, d)) {
+  if (knn_cand_enabled() && knn_cand_supported(1, d) && pairs <= KNN_CAND_MAX_PAIRS) {  // beyond the launch's grid limits: the all-pairs tile below, same keys
     // the two 1-NN searches of a pair (corresp_util.py:46-47) by candidate pass + exact re-scoring (knn_cand.hip): query patch -> nearest
     // template patch into row_best [pairs, q_max], template patch -> nearest query patch into col_best [pairs, p_max]; the same keys
     // (d2, index; ties -> lowest index) the all-pairs tile below leaves, so everything downstream is unchanged
@@ -470,8 +470,9 @@ namespace {
 enum { VIT_FULL = 0, VIT_PREFIX = 1, VIT_LAST_SELECTED = 2 };
 struct VitSelection { const int32_t* rows; const int32_t* off; int num, max_per_img; };
 
-// VIT_FULL: embedding + blocks 0..layer.  VIT_PREFIX: embedding + blocks 0..layer-1, leaving what block `layer` starts from
-// (fp32 stream, its bf16 copy, the LayerNorm row sums).  VIT_LAST_SELECTED: block `layer` alone, computed for the selected
+// VIT_FULL: embedding + blocks 0..layer.  VIT_PREFIX: embedding + blocks 0..layer-1, leaving what block `layer` starts from:
+// the fp32 stream ws->x, its bf16 copy and the LayerNorm row sums -- or, with ws->xl set (the default, FP_RESID_HILO=1) and layer > 0,
+// the (xb, xl) pair and the row sums ONLY: ws->x is then stale (it holds the token embedding) and must not be read by a caller.  VIT_LAST_SELECTED: block `layer` alone, computed for the selected
 // tokens only (queries of the attention, rows of proj / fc1 / fc2) on top of a VIT_PREFIX run -- keys and values are all tokens.
 int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer, int mode,
                      const VitSelection* sel, fp_stream_t stream) {

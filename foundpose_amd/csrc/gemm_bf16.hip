@@ -818,7 +818,10 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
     case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
     case GEMM_EPI_RESID_F32: return launch<GEMM_EPI_RESID_F32>(a, st);
     case GEMM_EPI_RESID_HILO:
-      FP_REQUIRE(a.xb && a.xl && a.stats_out && a.N % 128 == 0 && a.ld_xb >= a.N && a.ld_xb % 4 == 0, "gemm_bf16: the (hi, lo) residual epilogue needs xb, xl, stats and N %% 128 == 0");
+      FP_REQUIRE(a.xb && a.xl && a.stats_out && a.N % 128 == 0 && a.ld_xb >= a.N, "gemm_bf16: the (hi, lo) residual epilogue needs xb, xl, stats and N %% 128 == 0");
+      // a lane moves 8 bf16 (16 bytes) of xb and of xl per access
+      FP_REQUIRE(a.ld_xb % 8 == 0 && reinterpret_cast<uintptr_t>(a.xb) % 16 == 0 && reinterpret_cast<uintptr_t>(a.xl) % 16 == 0,
+                 "gemm_bf16: the (hi, lo) residual epilogue needs 16-byte aligned xb / xl and a row stride that is a multiple of 8 elements (ld_xb = %d)", a.ld_xb);
       return launch<GEMM_EPI_RESID_HILO>(a, st);
     case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
     case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);

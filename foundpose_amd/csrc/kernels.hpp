@@ -56,6 +56,7 @@ struct KnnCandArgs {
   float* out_d2; int* out_idx;              // [pairs * row_stride, k]; may be null
 };
 size_t knn_cand_scratch_bytes(int k, long long rows);   // rows = pairs * row_stride
+constexpr int KNN_CAND_MAX_PAIRS = 65535;   // gridDim.y of the candidate pass; callers with more (detection, slot) pairs use the all-pairs tile
 bool knn_cand_supported(int k, int K);
 int knn_cand_launch(const KnnCandArgs& a, int max_rows, int max_db, void* scratch, hipStream_t st);   // max_db: the longest database segment (sizes the split)
 

@@ -417,6 +417,9 @@ int knn_cand_launch(const KnnCandArgs& a_in, int max_rows, int max_db, void* scr
   FP_REQUIRE(knn_cand_supported(a.k, a.K), "knn_cand: k (%d) must be 1..4 and the dimension (%d) 64, 128 or 256", a.k, a.K);
   FP_REQUIRE(a.ld % 4 == 0 && a.pairs >= 1 && a.row_stride >= 1 && max_rows >= 1 && scratch, "knn_cand: bad arguments");
   const long long rows = (long long)a.pairs * a.row_stride;
+  // stage 1 puts the pairs on gridDim.y (<= 65535), stage 2 one wave per row on gridDim.x (16 waves per block)
+  FP_REQUIRE(a.pairs <= KNN_CAND_MAX_PAIRS && (rows + 15) / 16 <= 0x7fffffffLL, "knn_cand: %d pairs x %d rows exceed the launch grid (at most %d pairs)",
+             a.pairs, a.row_stride, KNN_CAND_MAX_PAIRS);
   a.lists = reinterpret_cast<unsigned long long*>(scratch);
   a.counts = reinterpret_cast<int*>(a.lists + (size_t)rows * KC_LISTS * kc_cap(a.k));
   switch (a.k) {

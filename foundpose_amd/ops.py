@@ -156,6 +156,8 @@ def gemm_bf16_resid_hilo(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x
     N = w.shape[0]
     if xb.dtype != torch.bfloat16 or xl.dtype != torch.bfloat16 or xb.stride(0) != xl.stride(0):
         raise ValueError("xb / xl are bf16 arrays with one row stride")
+    if xb.stride(0) % 8 or xb.data_ptr() % 16 or xl.data_ptr() % 16 or xb.stride(1) != 1 or xl.stride(1) != 1:
+        raise ValueError("xb / xl: 16-byte aligned rows (row stride a multiple of 8 elements, unit column stride) -- the epilogue moves 8 bf16 per access")
     stats = torch.zeros(N // 128, M, 2, dtype=torch.float32, device=a.device)
     call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(xl), xl.stride(0),
          8 | (tile << 8), None, None, ptr(xb), xb.stride(0), ptr(stats), stream())

@@ -296,7 +296,10 @@ int fp_vit_sample_features(const fp_vit_model* model, const fp_vit_workspace* ws
  * for no other token, while its keys and values still come from all tokens.  Three calls replace fp_vit_forward +
  * fp_vit_sample_features with identical sampled features (bit for bit: a token's row never depends on which rows share its
  * GEMM tile or attention block):
- *   fp_vit_forward_prefix   embedding + blocks 0..layer-1 (what block `layer` starts from stays in the workspace);
+ *   fp_vit_forward_prefix   embedding + blocks 0..layer-1 (what block `layer` starts from stays in the workspace).  The workspace
+ *                           state between the calls is PRIVATE to them: with ws->xl set (the (hi, lo) residual stream) and layer > 0 the
+ *                           stream lives in the (ws->xb, ws->xl) pair only and ws->x is UNDEFINED (it still holds the token
+ *                           embedding); do not read ws->x after a prefix run -- fp_vit_block_selected rebuilds the rows it needs;
  *   fp_vit_block_selected   block `layer`: LayerNorm constants and the qkv projection for all tokens, then attention
  *                           queries, proj, fc1 and fc2 for the selected tokens only.  sel_rows [num_sel] = global token
  *                           rows (b * n_tok + token), ascending, grouped by image; sel_off [B + 1] = offsets of the images

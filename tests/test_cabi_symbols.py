@@ -69,7 +69,8 @@ def test_infer_driver_refuses_options_it_would_otherwise_ignore():
 
 
 def test_oracle_topn_is_clamped_to_the_template_count():
-    """torch.topk raises when there are fewer templates than top_n; the oracle (like the device path) returns what exists."""
+    """torch.topk raises when there are fewer templates than top_n -- and so do the drop-in establish_correspondences / tfidf_matching
+    (tests/test_gpu_matching.py::test_random_sweep_vs_oracle_both_tie_orders); the oracle, like the batched match_batch / engine, returns what exists."""
     import numpy as np
     from oracle import clib, match as om
     from oracle.make_golden import build_match_inputs
