@@ -544,12 +544,21 @@ class DinoFeatureExtractor(torch.nn.Module):
         return tok[:, 1:].contiguous(), tok[:, 0].contiguous()
 
     # ---- fp8 mode
-    def calibrate_fp8(self, images: Optional[torch.Tensor] = None, act_scales: Optional[torch.Tensor] = None) -> torch.Tensor:
+    FP8_CALIBRATION_HEADROOM = 1.5
+
+    def calibrate_fp8(self, images: Optional[torch.Tensor] = None, act_scales: Optional[torch.Tensor] = None,
+                      headroom: Optional[float] = None) -> torch.Tensor:
         """Fixes the static activation scales of the fp8 mode and quantises the block matrices.
 
         Either pass `act_scales` [depth, 4] (scale = 448 / amax of the inputs of qkv, proj, fc1, fc2 of each block) or a
         calibration batch `images`: the blocks are then run once in bf16, op by op, and the largest magnitude of each
-        GEMM input is recorded.  -> the scales in use."""
+        GEMM input is recorded; the scales are 448 / (headroom x that maximum).  The maximum over a calibration sample
+        underestimates the maximum over everything the model will see, and e4m3 is a FLOATING format: room above the sample
+        maximum costs no relative precision (only the smallest binade), so the default keeps 1.5x (a sample-maximum scale,
+        headroom=1.0, clamped tens of thousands of values when 32 calibration crops served 128).  -> the scales in use."""
+        headroom = self.FP8_CALIBRATION_HEADROOM if headroom is None else float(headroom)
+        if headroom < 1.0:
+            raise ValueError("headroom < 1 would clamp the calibration batch itself")
         from . import ops
         if self.precision != "fp8" or self._model is None:
             raise _lib.FoundPoseNativeError("calibrate_fp8 needs precision='fp8' and extractor.to('cuda')")
@@ -580,7 +589,7 @@ class DinoFeatureExtractor(torch.nn.Module):
                 ops.gemm_bf16(h, w[p + fc2 + ".weight"], w[p + fc2 + ".bias"], gamma=w[p + "ls2.gamma"], out=x, epilogue=3, m_valid=mv)
                 amax[i] = torch.stack([t[:mv].float().abs().max() for t in (y, o, y2, h)]).cpu()
             amax[self.layer + 1:] = 1.0
-            act_scales = 448.0 / amax.clamp_min(1e-12)
+            act_scales = 448.0 / (headroom * amax).clamp_min(1e-12)
         self.act_scales = act_scales.float().cpu().clone()
         self._to_fp8()
         return self.act_scales

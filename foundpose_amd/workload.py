@@ -30,6 +30,13 @@ from . import bank_builder, feature_util, ops, projector_util, repre_util, synth
 PLANT_NOISE = (0.05, 0.15, 0.25, 0.35, 0.45)  # feature noise of templates t_b + r, in units of the feature std
 PLANT_PATCHES = (0.87, 0.81, 0.75, 0.69, 0.63)  # their patch counts as fractions of the detection's query patches (nested subsets)
 WORDS_PER_TEXTURE = 3   # = tfidf_knn_k of the shipped options: a patch's k nearest words are the instances of its texture
+# The HARD variant (bench.py `parity.hard`): only the best view is planted -- template t_b holds the detection's features at the noise / patch
+# fraction below -- and the other four retrieved templates are whatever the tf-idf retrieval finds among the UNRELATED ones (random texture
+# sets: "wrong views", as the templates 2..5 of a real detection mostly are).  Nothing behind slot 1 has an engineered margin: a query patch
+# whose texture a wrong view does not contain has no counterpart there, its nearest neighbour is decided among unrelated features, and the
+# top-k cut falls among cycle distances of such patches -- the regime in which reduced-precision features move indices.
+HARD_NOISE = (0.35,)
+HARD_PATCHES = (0.69,)
 
 
 @dataclass
@@ -90,8 +97,14 @@ def query_features(extractor, crops: torch.Tensor, masks: torch.Tensor, cell: fl
 def build_planted_workload(extractor, batch: int, size: int, num_objects: int, templates_per_object: int, feat_dim: int = 256,
                            num_words: int = 2048, seed: int = 0, crop_seed: int = 0, noise: Sequence[float] = PLANT_NOISE,
                            patch_frac: Sequence[float] = PLANT_PATCHES, mask: Optional[torch.Tensor] = None,
-                           words_per_texture: int = WORDS_PER_TEXTURE) -> PlantedWorkload:
-    """`extractor`: the extractor whose features are planted (use precision="fp32": the reference's arithmetic)."""
+                           words_per_texture: int = WORDS_PER_TEXTURE, hard: bool = False) -> PlantedWorkload:
+    """`extractor`: the extractor whose features are planted (use precision="fp32": the reference's arithmetic).
+    hard=True: the margin-free variant (HARD_NOISE / HARD_PATCHES above) -- same crops, masks, words, projector and poses as the planted
+    workload of the same seeds, only template t_b planted; `targets` then names the expected BEST template only."""
+    if hard:
+        noise, patch_frac = HARD_NOISE, HARD_PATCHES
+    if len(noise) != len(patch_frac):
+        raise ValueError("noise and patch_frac describe the same planted templates")
     dev = torch.device("cuda", torch.cuda.current_device())
     m = synthetic.make_disc_mask(size) if mask is None else mask
     n_tex = num_words // words_per_texture   # (a mask with more patches than num_words / 3 needs fewer instance words per texture)
