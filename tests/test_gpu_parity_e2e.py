@@ -20,6 +20,7 @@ from foundpose_amd import feature_util, synthetic, workload
 from foundpose_amd.bank import DeviceBank
 from foundpose_amd.vit_config import ARCHS
 from oracle import baseline
+from tests.helpers import check_bar
 
 pytestmark = pytest.mark.gpu
 NAME = "dinov2_version=vitl14-reg_stride=14_facet=token_layer=18_norm=1"
@@ -86,7 +87,9 @@ def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, temp
     assert pbf["templates_equal"] == n
     assert full["templates_equal"] == batch and plbf["planted_top5_in_order"] == batch and pl32["planted_top5_in_order"] == batch
     # correspondences: the same patch-to-feature pairs up to the few nearest neighbours the bf16 feature error moves
-    assert pbf["corresp_overlap"] >= 0.9 and full["corresp_overlap"] >= 0.9
+    # (held to 2.5 x the measured 1 - overlap of this very case, tests/golden/measured_bars.json; round 4 asserted a generic >= 0.9)
+    check_bar(f"e2e_{config}_{version}/bf16/1-overlap_vs_oracle_a", 1.0 - pbf["corresp_overlap"], 0.1, floor=5e-3)
+    check_bar(f"e2e_{config}_{version}/bf16/1-overlap_vs_fp32_mode", 1.0 - full["corresp_overlap"], 0.1, floor=5e-3)
 
 
 def test_config1_lmo_geometry_vs_oracle_a():
@@ -120,7 +123,8 @@ def test_config1_lmo_geometry_vs_oracle_a():
     assert [int(c["template_id"]) for c in ora[0]] == [t0 + r for r in range(5)]        # the oracle itself finds the planted answer
     for k in ("fp32", "f16x3"):
         assert stats[k]["templates_equal"] == 1 and stats[k]["corresp_equal"] == stats[k]["slots_compared"] == 5, (k, stats[k])
-    assert stats["bf16"]["templates_equal"] == 1 and stats["bf16"]["corresp_overlap"] >= 0.9
+    assert stats["bf16"]["templates_equal"] == 1
+    check_bar("e2e_config1/bf16/1-overlap_vs_oracle_a", 1.0 - stats["bf16"]["corresp_overlap"], 0.1, floor=5e-3)
 
 
 def test_bf16_mode_index_exact_vs_oracle_b_on_fixture_with_verified_margins():
@@ -234,7 +238,8 @@ def test_default_backbone_dinov2_vitl14_vs_oracle_a():
     for k in ("fp32", "f16x3"):
         assert stats[k]["templates_equal"] == n and stats[k]["corresp_equal"] == stats[k]["slots_compared"] == 5 * n, (k, stats[k])
     assert full3["templates_equal"] == batch and full3["corresp_equal"] == full3["slots_compared"] == 5 * batch
-    assert stats["bf16"]["templates_equal"] == n and fullbf["templates_equal"] == batch and fullbf["corresp_overlap"] >= 0.9
+    assert stats["bf16"]["templates_equal"] == n and fullbf["templates_equal"] == batch
+    check_bar("e2e_dinov2_vitl14/bf16/1-overlap_vs_fp32_mode", 1.0 - fullbf["corresp_overlap"], 0.1, floor=5e-3)
     for k in runs:
         assert workload.planted_stats(runs[k], wl.targets.tolist())["planted_top5_in_order"] == batch
 
