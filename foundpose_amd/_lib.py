@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libfoundpose_amd.so")
+# FOUNDPOSE_AMD_LIB: another build of the SAME library (a measurement variant from tools/build_variant.sh, for same-box A/B runs); it must
+# export the same ABI version.  Never a different implementation: there is one product path.
+LIB_PATH = os.environ.get("FOUNDPOSE_AMD_LIB") or os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
 FP_F32, FP_BF16, FP_FP8, FP_F16X3 = 0, 1, 2, 3
 SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header

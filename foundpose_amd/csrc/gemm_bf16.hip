@@ -275,6 +275,58 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           }
         } else if constexpr (SP) {
+#ifdef FP_SP_FP8CROSS
+          // MEASUREMENT BUILD (profiles/EXPERIMENTS.md round 5; never in the shipped library): the two cross terms of a split
+          // product on the fp8 pipe.  Rows are [hi16 x 64 | hi8 x 64 | lo8 x 64] per 64 logical k (tools/sp_fp8cross.py packs them): an even
+          // 128-B K-tile holds the fp16 high halves (four 16-wide hi*hi steps), the odd one e4m3(hi 2^-7) and e4m3(lo 2^4) (two 64-wide fp8
+          // MFMAs: lo_w * hi_a and hi_w * lo_a, the block scale 2^3 on one operand undoes the two pre-scales).  Same bytes per k as the
+          // shipped rows, 8 instead of 12 fp16-MFMA units per 64 k.
+          if ((t & 1) == 0) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              if (more) {
+#pragma unroll
+                for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + 1, nxt);
+              }
+              const int chunk = ks * 2 + kh;
+              __builtin_amdgcn_iglp_opt(1);
+              f16x8 ah[TM], wh[TN];
+#pragma unroll
+              for (int i = 0; i < TM; ++i) ah[i] = __builtin_bit_cast(f16x8, read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk));
+#pragma unroll
+              for (int j = 0; j < TN; ++j) wh[j] = __builtin_bit_cast(f16x8, read_frag(Ws, wn * (BN / WN) + j * 32 + l31, chunk));
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
+            }
+          } else {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {  // s = 0: lo_w * hi_a, s = 1: hi_w * lo_a
+              if (more) {
+#pragma unroll
+                for (int q = 0; q < PIECES / 2; ++q) stage_piece(s * (PIECES / 2) + q, t + 1, nxt);
+              }
+              const int ca = (s == 0 ? 0 : 4) + kh * 2, cw = (s == 0 ? 4 : 0) + kh * 2;
+              __builtin_amdgcn_iglp_opt(1);
+              i32x8 af[TM], wf[TN];
+              auto frag8 = [&](const char* base, int row, int chunk) {
+                const i32x4 lo = __builtin_bit_cast(i32x4, read_frag(base, row, chunk));
+                const i32x4 hi = __builtin_bit_cast(i32x4, read_frag(base, row, chunk + 1));
+                return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+              };
+#pragma unroll
+              for (int i = 0; i < TM; ++i) af[i] = frag8(As, wm * (BM / WM) + i * 32 + l31, ca);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) wf[j] = frag8(Ws, wn * (BN / WN) + j * 32 + l31, cw);
+#pragma unroll
+              for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x82828282, 0, 0x7f7f7f7f);
+            }
+          }
+#else
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {  // two 16-wide k-steps of the 32 k-values of this tile
             if (more) {
@@ -297,19 +349,26 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               wl[j] = __builtin_bit_cast(f16x8, read_frag(Ws, row, ch + 4));
             }
             // the two cross terms first (small), then hi*hi; TM*TN independent accumulators between two MFMAs of one chain
+            // (FP_SP_ABLATE = 1 / 2: measurement builds that DROP one / both cross terms -- wrong results, same operand bytes -- to bound what
+            //  cross terms on the half-cost fp8 pipe could buy: tools/build_variant.sh, profiles/EXPERIMENTS.md round 5; never in the shipped library)
+#if !defined(FP_SP_ABLATE)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl[j], ah[i], acc[i][j], 0, 0, 0);
+#endif
+#if !defined(FP_SP_ABLATE) || FP_SP_ABLATE < 2
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], al[i], acc[i][j], 0, 0, 0);
+#endif
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
           }
+#endif
         } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {

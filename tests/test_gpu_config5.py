@@ -14,6 +14,7 @@ from foundpose_amd import feature_util, synthetic, workload
 from foundpose_amd.bank import DeviceBank
 from foundpose_amd.vit_config import ARCHS
 from oracle import vit as ov
+from tests.helpers import check_bar
 
 pytestmark = pytest.mark.gpu
 
@@ -50,8 +51,11 @@ def test_vitg14_fp8_batch32_vs_oracle_c(vitg_sd, version):
     e_c, e_32 = float((got - ref_c).abs().max()) / scale, float((got - ref_32).abs().max()) / scale
     rms_32 = float((got - ref_32).pow(2).mean().sqrt()) / scale
     print(f"\n{version} fp8, layer {layer}, crop {b} of 32: vs oracle C {e_c:.4f}, vs fp32 oracle max {e_32:.4f} rms {rms_32:.4f} (of the feature scale)")
-    assert e_c < 5e-2       # same quantisation points: bf16-level agreement
-    assert e_32 < 0.3 and rms_32 < 4e-2   # fp8 noise against the exact model
+    # same quantisation points: bf16-level agreement up to the elements that land on the other side of an e4m3 rounding boundary; then the
+    # fp8 noise against the exact model -- both held to 2.5 x the measured values (tests/golden/measured_bars.json)
+    check_bar(f"config5_{version}_l4_b32/fp8/vs_oracle_c_max", e_c, 8e-2)
+    check_bar(f"config5_{version}_l4_b32/fp8/vs_fp32_max", e_32, 0.3)
+    check_bar(f"config5_{version}_l4_b32/fp8/vs_fp32_rms", rms_32, 4e-2)
     # batch invariance with static scales: the crop alone == the crop inside the batch
     ex1 = feature_util.make_feature_extractor(name, state_dict=vitg_sd, precision="fp8", act_scales=scales).to("cuda")
     assert torch.equal(ex1(imgs[b:b + 1].cuda())["feature_maps"][0].cpu(), got)

@@ -98,7 +98,7 @@ def test_engine_from_uncropped_image():
     g = load_golden("hot_section_tiny")
     S = int(g["image_size"])
     ex = feature_util.make_feature_extractor("dinov2_version=tiny-reg_stride=14_facet=token_layer=2_logbin=0_norm=1",
-                                             seed=int(g["weights_seed"]), precision="fp32", arch=TINY).to("cuda")
+                                             random_init_seed=int(g["weights_seed"]), precision="fp32", arch=TINY).to("cuda")
     proj = projector_util.projector_from_tensordict({"pca_projector": {
         "components": torch.from_numpy(g["pca_components"]), "mean": torch.from_numpy(g["pca_mean"]), "whiten": torch.tensor(False)}})
     repre = repre_util.FeatureBasedObjectRepre(
