@@ -280,14 +280,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           // product on the fp8 pipe.  Rows are [hi16 x 64 | hi8 x 64 | lo8 x 64] per 64 logical k (tools/sp_fp8cross.py packs them): an even
           // 128-B K-tile holds the fp16 high halves (four 16-wide hi*hi steps), the odd one e4m3(hi 2^-7) and e4m3(lo 2^4) (two 64-wide fp8
           // MFMAs: lo_w * hi_a and hi_w * lo_a, the block scale 2^3 on one operand undoes the two pre-scales).  Same bytes per k as the
-          // shipped rows, 8 instead of 12 fp16-MFMA units per 64 k.
-          if ((t & 1) == 0) {
+          // shipped rows, 8 instead of 12 fp16-MFMA units per 64 k.  Two tiles per loop iteration, straight-line (a run-time branch on the tile
+          // parity made the allocator spill 420 VGPRs): t is even here, its tile sits in stage 0, the fp8 tile t + 1 in stage 1.
+          {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-              if (more) {
 #pragma unroll
-                for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + 1, nxt);
-              }
+              for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + 1, nxt);
               const int chunk = ks * 2 + kh;
               __builtin_amdgcn_iglp_opt(1);
               f16x8 ah[TM], wh[TN];
@@ -300,12 +299,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
             }
-          } else {
+          }
+          {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const char* As1 = smem + STAGE;
+            const char* Ws1 = As1 + A_BYTES;
+            const bool more1 = t + 2 < ke;
 #pragma unroll
             for (int s = 0; s < 2; ++s) {  // s = 0: lo_w * hi_a, s = 1: hi_w * lo_a
-              if (more) {
+              if (more1) {
 #pragma unroll
-                for (int q = 0; q < PIECES / 2; ++q) stage_piece(s * (PIECES / 2) + q, t + 1, nxt);
+                for (int q = 0; q < PIECES / 2; ++q) stage_piece(s * (PIECES / 2) + q, t + 2, smem);
               }
               const int ca = (s == 0 ? 0 : 4) + kh * 2, cw = (s == 0 ? 4 : 0) + kh * 2;
               __builtin_amdgcn_iglp_opt(1);
@@ -316,15 +321,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
                 return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
               };
 #pragma unroll
-              for (int i = 0; i < TM; ++i) af[i] = frag8(As, wm * (BM / WM) + i * 32 + l31, ca);
+              for (int i = 0; i < TM; ++i) af[i] = frag8(As1, wm * (BM / WM) + i * 32 + l31, ca);
 #pragma unroll
-              for (int j = 0; j < TN; ++j) wf[j] = frag8(Ws, wn * (BN / WN) + j * 32 + l31, cw);
+              for (int j = 0; j < TN; ++j) wf[j] = frag8(Ws1, wn * (BN / WN) + j * 32 + l31, cw);
 #pragma unroll
               for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                   acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x82828282, 0, 0x7f7f7f7f);
             }
+            ++t;
           }
 #else
 #pragma unroll
