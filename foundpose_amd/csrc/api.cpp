@@ -292,7 +292,7 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   FP_REQUIRE(A && W && out, "fp_gemm_bf16: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;  // tuning bits: force the 128 or 256 block tile
   epilogue &= 0xff;
-  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16: bad tile override %d", tile);
+  FP_REQUIRE(tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16: bad tile override %d", tile);
 
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
                  epilogue == GEMM_EPI_BIAS_F32 || epilogue == GEMM_EPI_SWIGLU_BF16,
@@ -311,7 +311,7 @@ int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N
   FP_REQUIRE(A && W && out && bias, "fp_gemm_bf16_ln: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;
   epilogue &= 0xff;
-  FP_REQUIRE(tile == 0 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16_ln: bad tile override %d", tile);
+  FP_REQUIRE(tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16_ln: bad tile override %d", tile);
   GemmBf16Args a;
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;

@@ -392,7 +392,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const int chunk = ks * 2 + kh;
           // the compiler's MFMA / LDS-read interleaving strategy 1 for this scheduling region: +0.75 % on the pipeline in same-box A/B
           // runs on two boxes (strategy 0: -0.4 %, 2 and 3: -1.3 %; its other list-scheduling strategies: 0...-1 %)
-          __builtin_amdgcn_iglp_opt(1);
+          if constexpr (TM * TN >= 4) __builtin_amdgcn_iglp_opt(1);   // (the 64 x 128 tile's two MFMAs per k-step: the strategy's search does not terminate in reasonable memory)
           bf16x8 af[TM], wf[TN];
 #pragma unroll
           for (int i = 0; i < TM; ++i) af[i] = read_frag(As, wm * (BM / WM) + i * 32 + l31, chunk);
@@ -814,11 +814,27 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
       return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   }
   if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+  // Small M (a batch of one or two crops -- the reference loop's shape, one detection at a time, scripts/infer.py:368): the N = D outputs (proj,
+  // fc2) are 12 x 8 = 96 tiles of 128^2 at B = 1 and leave 160 of the 256 CUs idle through fc2's 64 K-tiles (43 us per launch, the largest
+  // bucket of a B = 1 forward).  64 x 128 tiles double the count; same k order per output element -> the same bits.
+  if constexpr (!SP && (EPI == GEMM_EPI_RESID_HILO || EPI == GEMM_EPI_RESID_F32 || EPI == GEMM_EPI_LS_RESID_F32)) {
+    const int tiles_128 = (a.M_valid > 0 ? (a.M_valid + 127) / 128 : a.M / 128) * (a.N / 128);
+    if ((force == 64 && a.M % 64 == 0) || (force == 0 && a.M % 64 == 0 && tiles_128 <= cus / 2))
+      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT>(a, st);
+  }
   return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
 }
 
 }  // namespace
 
+// The kernel template above is instantiated by three translation units so that no single compile holds every instantiation (the one-file build
+// ran out of memory): gemm_bf16.hip (bf16 operands), gemm_fp8.hip (-> FP_GEMM_TU == 2), gemm_split.hip (-> FP_GEMM_TU == 3); the latter two
+// are one-line files that define FP_GEMM_TU and include this one.
+#ifndef FP_GEMM_TU
+#define FP_GEMM_TU 1
+#endif
+
+#if FP_GEMM_TU == 2
 // fp8 (e4m3) operands: A [M, K] and W [N, K] one byte per element, K a multiple of 128, M and N multiples of 256;
 // a.gamma = dequantisation scale per output column (x LayerScale for LS_RESID), a.bias already divided by it.
 int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
@@ -846,6 +862,9 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   return FP_ERR_UNSUPPORTED;
 }
 
+#endif  // FP_GEMM_TU == 2
+
+#if FP_GEMM_TU == 3
 // split-fp16 operands (f16x3 mode): a.K is the LOGICAL K; the kernel walks rows of 2K halves
 int gemm_split_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
@@ -871,6 +890,9 @@ int gemm_split_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   return FP_ERR_UNSUPPORTED;
 }
 
+#endif  // FP_GEMM_TU == 3
+
+#if FP_GEMM_TU == 1
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
   FP_REQUIRE(a.M > 0 && a.M % 128 == 0, "gemm_bf16: M (%d) must be a positive multiple of 128 (pad the activation buffer)", a.M);
   FP_REQUIRE(a.N > 0 && a.N % 128 == 0, "gemm_bf16: N (%d) must be a multiple of 128", a.N);
@@ -895,3 +917,4 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
   fp_set_error("gemm_bf16: unknown epilogue %d", epi);
   return FP_ERR_INVALID;
 }
+#endif  // FP_GEMM_TU == 1

@@ -647,6 +647,31 @@ def test_gemm_320_row_tile_equals_256_row_tile(M, N, K, m_valid):
         assert torch.equal(f256[:m_valid], f320[:m_valid])
 
 
+@pytest.mark.parametrize("M,N,K,m_valid", [(1536, 1024, 1024, 1374), (1536, 1024, 4096, 1374), (256, 384, 1536, 200), (2816, 1024, 1024, 2748)])
+def test_gemm_64_row_tile_equals_128_row_tile(M, N, K, m_valid):
+    """The 64 x 128 block tile the residual GEMMs (proj, fc2) of a batch of one or two crops launch -- the reference loop's shape, one detection
+    at a time -- walks k in the same order per output element as the 128^2 tile: the fp32 LayerScale-residual stream (epilogue 3), the fp32
+    stream with its bf16 copy and LayerNorm row sums (7) and the (hi, lo) bf16 stream (8) come out bit-identical; rows past m_valid untouched."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(M + N + K)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(N, K, generator=g) * 0.05).to(torch.bfloat16).cuda()
+    bias, gamma = torch.randn(N, generator=g).cuda(), torch.randn(N, generator=g).cuda()
+    x0 = (torch.randn(M, N, generator=g) * 3 + 0.7).cuda()
+    outs = []
+    for tile in (128, 64):
+        x3 = x0.clone()
+        ops.gemm_bf16(a, w, bias, gamma=gamma, out=x3, epilogue=3 | (tile << 8), m_valid=m_valid)
+        x7 = x0.clone()
+        xb7, st7 = ops.gemm_bf16_resid_ln(a, w, bias, x7, tile=tile, m_valid=m_valid)
+        xb8, xl8 = x0.to(torch.bfloat16), (x0 - x0.to(torch.bfloat16).float()).to(torch.bfloat16)
+        st8 = ops.gemm_bf16_resid_hilo(a, w, bias, xb8, xl8, tile=tile, m_valid=m_valid)
+        outs.append((x3, x7, xb7[:m_valid].clone(), st7[:, :m_valid].clone(), xb8, xl8, st8[:, :m_valid].clone()))
+    for t128, t64 in zip(*outs):
+        assert torch.equal(t128, t64)
+    assert torch.equal(outs[1][0][m_valid:], x0[m_valid:]) and not torch.equal(outs[1][0][:m_valid], x0[:m_valid])
+
+
 @pytest.mark.parametrize("tile,M,D,N2", [(128, 256, 256, 512), (256, 512, 1024, 1024), (128, 384, 384, 1152)])
 def test_folded_layernorm_gemm_pair(tile, M, D, N2):
     """The two halves of the LayerNorm fold at op level: the residual GEMM (epilogue 7) emits bf16(x) and the row's partial
