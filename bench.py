@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--words", type=int, default=0, help="visual words of the bank (default 2048 = configs/gen_repre/lmo.json; with --mask full 4224, so that the 1369 "
                                                         "distinct textures of a full crop still get three instance words each, like the headline workload)")
     ap.add_argument("--overlap", action="store_true", help="matching of batch i on a second stream beside the backbone of batch i+1 (engine overlap_matching; measured +0.3...0.8 %%, not the default)")
-    ap.add_argument("--parity-precision", default="f16x3", choices=["f16x3", "fp32", "none"],
+    ap.add_argument("--parity-precision", default="f16x3", choices=["f16x3", "f16f8", "fp32", "none"],
                     help="the near-exact mode timed next to the headline as `parity_mode` (f16x3: split-fp16 operands, three fp16 MFMAs per product; "
                          "fp32: the exact-fp32 MFMA mode) with its index agreement against oracle A and the fp32 mode")
     ap.add_argument("--parity-steps", type=int, default=5)
@@ -272,6 +272,8 @@ def main():
               "ms_per_step": round(1e3 * el_pm / args.parity_steps, 3), "steps": args.parity_steps, "n_gpus": world,
               "what": ("split-fp16 operands (hi + lo: 22 mantissa bits), every product = three fp16 MFMAs with fp32 accumulation, fp32 residual stream / "
                        "LayerNorm / softmax / exact-erf GELU; the hooked block on the sampled tokens only, like the headline (bit-identical features)" if args.parity_precision == "f16x3"
+                       else "as f16x3 with the two cross terms of every GEMM product (hi lo + lo hi, ~2^-11 of the product) on the fp8 MFMA: rows carry fp16 high halves + e4m3 copies of "
+                            "hi and lo, 8 instead of 12 fp16-MFMA units per 64 k; q / k / v and the attention's own products stay three-fp16-MFMA" if args.parity_precision == "f16f8"
                        else "exact-fp32 MFMA GEMMs (k-ascending fmaf chains) + fp32 attention")}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
@@ -479,8 +481,8 @@ def main():
         if world == 1 and not args.no_hard:
             # ---- the margin-free workload: same crops / words / projector, only the best view planted, slots 2..5 = wrong views
             exs = {"fp32": ex32, args.precision: extractor}
-            if ex_pm is not None and args.parity_precision == "f16x3":
-                exs["f16x3"] = ex_pm
+            if ex_pm is not None and args.parity_precision in ("f16x3", "f16f8"):
+                exs[args.parity_precision] = ex_pm
             parity["hard"] = hard_parity(args, wl, exs, oracle_feats, dict(batch=B, full_mask=full_mask, W_words=W_words, wpt=wpt, rank=rank, dev=dev))
         if pm is not None:  # north_star's index bar, stated as booleans next to the mode's throughput
             pm["index_exact_vs_oracle_a"] = ("vs_oracle_a" in pm and pm["vs_oracle_a"]["corresp_equal"] == pm["vs_oracle_a"]["slots_compared"]

@@ -270,7 +270,7 @@ int fp_pnp_ransac(const float* coord_2d, const float* coord_3d, const int32_t* c
 int fp_patchify(const float* images, int B, int H, int W, int patch, void* out, int ld_out, int out_dtype,
                 fp_stream_t stream) {
   FP_REQUIRE(images && out, "fp_patchify: null pointer");
-  return patchify_launch(images, B, H, W, patch, out, ld_out, out_dtype, ST(stream), out_dtype == FP_DTYPE_F16X3 ? FP_SPLIT_SCALE_ACT : 1.f);
+  return patchify_launch(images, B, H, W, patch, out, ld_out, out_dtype, ST(stream), (out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8) ? FP_SPLIT_SCALE_ACT : 1.f);
 }
 
 int fp_layernorm(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out,
@@ -379,6 +379,7 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_split: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;
+  const bool f16f8 = (epilogue >> 20) & 1;   // FP_GEMM_SPLIT_F16F8: the operands (and a GELU / SwiGLU output) are f16f8 rows
   epilogue &= 0xff;
   FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_split: bad tile override %d", tile);
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
@@ -389,7 +390,7 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
   a.tile_override = tile; a.acc_scale = acc_scale; a.out_scale = out_scale;
-  return gemm_split_launch(epilogue, a, ST(stream));
+  return f16f8 ? gemm_splitx_launch(epilogue, a, ST(stream)) : gemm_split_launch(epilogue, a, ST(stream));
 }
 
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
@@ -398,14 +399,15 @@ int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
-  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = out_scale;
+  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = fabsf(out_scale);
+  a.out_fmt = out_scale < 0.f ? 1 : 0;   // a NEGATIVE out_scale asks for an f16f8 output row (scaled by its magnitude)
   return attn_launch(a, FP_DTYPE_F16X3, ST(stream));
 }
 
 int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out, int out_dtype, float out_scale,
                         int dim, int out_rows, fp_stream_t stream) {
   FP_REQUIRE(x && weight && bias && out, "fp_layernorm_scaled: null pointer");
-  FP_REQUIRE(out_dtype == FP_DTYPE_FP8 || out_dtype == FP_DTYPE_F16X3, "fp_layernorm_scaled: the scaled outputs are fp8 bytes and split-fp16 rows");
+  FP_REQUIRE(out_dtype == FP_DTYPE_FP8 || out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8, "fp_layernorm_scaled: the scaled outputs are fp8 bytes, split-fp16 rows and f16f8 rows");
   LayerNormArgs a;
   memset(&a, 0, sizeof(a));
   a.x = x; a.ld_x = ld_x; a.weight = weight; a.bias = bias; a.eps = eps; a.out = out; a.ld_out = ld_out;
@@ -488,9 +490,11 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   FP_REQUIRE(ws->patches && ws->x && ws->y && ws->qkv && ws->h, "fp_vit_forward: workspace buffer missing");
   hipStream_t st = ST(stream);
   const bool f8 = m->weight_dtype == FP_DTYPE_FP8;  // e4m3 block matrices; activations and patch embed stay bf16
-  const bool sp = m->weight_dtype == FP_DTYPE_F16X3;  // split-fp16 operands everywhere (near-exact mode): rows of 2 x halves
+  const bool sx = m->weight_dtype == FP_DTYPE_F16F8;  // f16f8 rows (common.hpp): the split mode with the cross terms on the fp8 pipe
+  const bool sp = m->weight_dtype == FP_DTYPE_F16X3 || sx;  // split-fp16 operands everywhere (near-exact modes): rows of 2 x halves
   const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
-  const int adt = sp ? FP_DTYPE_F16X3 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32);
+  const int adt = sx ? FP_DTYPE_F16F8 : (sp ? FP_DTYPE_F16X3 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32));
+  FP_REQUIRE(!sx || (D % 64 == 0 && m->hidden % 64 == 0 && m->patch_k_pad % 64 == 0), "fp_vit_forward: the f16f8 mode needs dim, hidden and patch_k_pad to be multiples of 64");
   const int em = sp ? 2 : 1;                          // stored elements per logical element of an operand row
   FP_REQUIRE(!sp || m->patch_acc_scale > 0.f, "fp_vit_forward: the f16x3 mode needs patch_acc_scale");
   FP_REQUIRE(!f8 || (ws->a8 && ws->m_pad % 256 == 0), "fp_vit_forward: the fp8 mode needs workspace a8 and m_pad %% 256 == 0");
@@ -511,7 +515,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     g.M = ws->m_patch_pad; g.N = D; g.K = m->patch_k_pad; g.M_valid = Mp; g.bias = m->patch_b;
     g.out = ws->x; g.ldo = D; g.pos = m->pos_patch; g.tok_np = np; g.tok_n = ntok; g.tok_skip = 1 + m->registers;
     g.acc_scale = m->patch_acc_scale;
-    TRY(gemm_split_launch(GEMM_EPI_TOKENS_F32, g, st));
+    TRY(sx ? gemm_splitx_launch(GEMM_EPI_TOKENS_F32, g, st) : gemm_split_launch(GEMM_EPI_TOKENS_F32, g, st));
   } else if (bf) {
     GemmBf16Args g;
     memset(&g, 0, sizeof(g));
@@ -645,13 +649,14 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
         g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
         g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
         g.acc_scale = acc_scale; g.out_scale = out_scale; g.sat = ws->sat;
-        return gemm_split_launch(epi, g, st);
+        return sx ? gemm_splitx_launch(epi, g, st) : gemm_split_launch(epi, g, st);
       };
       ln.out_scale = FP_SPLIT_SCALE_ACT;
       TRY(layernorm_launch(ln, st));
       TRY(sgemm(ws->y, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.act_scale[0], FP_SPLIT_SCALE_QKV));
       AttnArgs as = at;
       as.in_scale = FP_SPLIT_SCALE_QKV; as.out_scale = FP_SPLIT_SCALE_ACT;
+      as.out_fmt = sx ? 1 : 0;   // f16f8: q | k | v stay split-fp16 rows (the attention's own three-MFMA products), its output is proj's f16f8 operand
       float* xr = ws->x;  // the residual rows the rest of the block updates
       if (selected) {
         as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;

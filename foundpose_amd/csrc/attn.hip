@@ -841,6 +841,31 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     // a convex combination of v rows that fit their scale cannot clamp -- but a NaN / Inf born inside the attention (an overflowing score)
     // would leave the v_med3 of the packing as a finite operand: the NaN-propagating running maximum is what reports it
     float o_amax = 0.f;
+    if (a.out_fmt == 1) {
+      // f16f8 row (common.hpp): a head's 64 output dims are one 64-column group -- fp16 high halves (128 B), then e4m3(hi) and e4m3(lo) (64 B
+      // each).  Same lane exchange as below; the word that travels in the lo slot is [hi8_a, hi8_b, lo8_a, lo8_b] of a column pair.
+      char* ob = reinterpret_cast<char*>(o);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned xh0, xp0, xh1, xp1, yh0, yp0, yh1, yp1;
+          splitx_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xp0, o_amax);
+          splitx_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xp1, o_amax);
+          splitx_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yp0, o_amax);
+          splitx_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yp1, o_amax);
+          const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
+          const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
+          const auto p0 = __builtin_amdgcn_permlane32_swap(xp0, yp0, false, false);
+          const auto p1 = __builtin_amdgcn_permlane32_swap(xp1, yp1, false, false);
+          const int d = dt * 32 + 16 * j + 8 * kh;   // this lane's 8 consecutive dims
+          if (q < NQ) {
+            *reinterpret_cast<uint4*>(ob + d * 2) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+            *reinterpret_cast<uint2*>(ob + 128 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x05040100u), __builtin_amdgcn_perm(p1[1], p0[1], 0x05040100u));
+            *reinterpret_cast<uint2*>(ob + 192 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x07060302u), __builtin_amdgcn_perm(p1[1], p0[1], 0x07060302u));
+          }
+        }
+    } else {
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt)
 #pragma unroll
@@ -860,6 +885,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
           *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
         }
       }
+    }
     if (q < NQ) report_saturation(a.sat, 0, o_amax, FP_F16_MAX);
   }
 }

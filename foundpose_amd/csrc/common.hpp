@@ -97,6 +97,46 @@ FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsign
 // position (in halves) of logical column c inside a split row; its lo half sits 32 halves further
 FP_DEVICE int split16_pos(int c) { return ((c >> 5) << 6) + (c & 31); }
 
+// ---- "f16f8" rows (the f16f8 mode: fp16 high halves, the two cross terms of a split product on the fp8 pipe).
+// The same 4 bytes per logical element as a split-fp16 row, in groups of 64 columns (K % 64 == 0): group g = k / 64 holds
+//   bytes [256 g,       256 g + 128)  hi = f16(s x)                      64 halves  -> hi * hi on v_mfma_f32_32x32x16_f16, as before
+//   bytes [256 g + 128, 256 g + 192)  e4m3(hi 2^-7)                      64 bytes   \ the cross terms hi_a lo_w + lo_a hi_w as two
+//   bytes [256 g + 192, 256 g + 256)  e4m3((s x - hi) 2^4)               64 bytes   / v_mfma_scale_f32_32x32x64_f8f6f4 (block scale 2^3)
+// The e4m3 copies carry 4 significant bits of hi and of lo: a cross term is good to 2^-3 of 2^-11 of the product, so a product
+// carries ~14 mantissa bits at the worst and the sum over K far more on average (measured on fc2, K = 4096: max error 1.3e-5 of the
+// output scale, rms 2.5e-6 -- tools/sp_fp8cross.py) at 8 instead of 12 fp16-MFMA units per 64 k: 1.34x the three-fp16-MFMA form.
+constexpr float FP_SX_HI_SCALE = 0.0078125f, FP_SX_LO_SCALE = 16.f;     // 2^-7 and 2^4: hi (<= 65504) and lo (<= 16) into e4m3's range (<= 448)
+constexpr unsigned FP_SX_MFMA_SCALE = 0x82828282u;                       // E8M0 127 + 3 in every byte: the block scale 2^3 that undoes 2^-7 x 2^4
+FP_DEVICE int splitx_pos(int c) { return ((c >> 6) << 7) + (c & 63); }   // halves index of hi(column c), the row viewed as halves
+FP_DEVICE int splitx_hi8(int c) { return ((c >> 6) << 8) + 128 + (c & 63); }  // byte offset of e4m3(hi) of column c; its e4m3(lo) sits 64 bytes further
+// two columns -> hi = (f16, f16) and p8 = the bytes [e4m3(hi_a), e4m3(hi_b), e4m3(lo_a), e4m3(lo_b)]
+FP_DEVICE void splitx_pack2(float a, float b, float scale, unsigned& hi, unsigned& p8) {
+  a = __builtin_amdgcn_fmed3f(a * scale, -65504.f, 65504.f);
+  b = __builtin_amdgcn_fmed3f(b * scale, -65504.f, 65504.f);
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(clamp448(hf[0] * FP_SX_HI_SCALE), clamp448(hf[1] * FP_SX_HI_SCALE), 0, false);
+  p8 = (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(clamp448((a - hf[0]) * FP_SX_LO_SCALE), clamp448((b - hf[1]) * FP_SX_LO_SCALE), w, true);
+}
+FP_DEVICE void splitx_pack2(float a, float b, float scale, unsigned& hi, unsigned& p8, float& amax) {
+  amax = nanmax3(amax, fabsf(a * scale), fabsf(b * scale));
+  splitx_pack2(a, b, scale, hi, p8);
+}
+// stores of a lane's packed columns into a row image (`row` = first byte of the row, or of a tile's 64-column-aligned part of it):
+// two adjacent columns c, c + 1 (c even) ...
+FP_DEVICE void splitx_store2(char* row, int c, unsigned hi, unsigned p8) {
+  *reinterpret_cast<unsigned*>(row + splitx_pos(c) * 2) = hi;
+  *reinterpret_cast<unsigned short*>(row + splitx_hi8(c)) = (unsigned short)p8;
+  *reinterpret_cast<unsigned short*>(row + splitx_hi8(c) + 64) = (unsigned short)(p8 >> 16);
+}
+// ... and four adjacent columns c .. c + 3 (c % 4 == 0) from two packed pairs
+FP_DEVICE void splitx_store4(char* row, int c, unsigned hi01, unsigned p01, unsigned hi23, unsigned p23) {
+  *reinterpret_cast<uint2*>(row + splitx_pos(c) * 2) = make_uint2(hi01, hi23);
+  *reinterpret_cast<unsigned*>(row + splitx_hi8(c)) = __builtin_amdgcn_perm(p23, p01, 0x05040100u);        // hi8 of the four columns
+  *reinterpret_cast<unsigned*>(row + splitx_hi8(c) + 64) = __builtin_amdgcn_perm(p23, p01, 0x07060302u);   // lo8 of the four columns
+}
+
 // ---- wave-level reductions (64 lanes)
 FP_DEVICE float wave_sum(float v) {
 #pragma unroll

@@ -138,8 +138,13 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // v_mfma_f32_32x32x16_f16 per accumulator and 16-wide k-step -- hi*hi, hi*lo, lo*hi -- i.e. 3x the MFMAs and 2x the operand
 // bytes of the bf16 kernel for products that carry 22 mantissa bits.  SPOUT: the BIAS / GELU / SwiGLU result is the next
 // GEMM's (or the attention's) operand and leaves as a split-fp16 row scaled by a.out_scale; GELU is the exact erf form here.
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
+// SX (f16f8 mode, with SP): the operands are f16f8 rows (common.hpp): per 64 logical k a 128-B tile of fp16 high halves (four 16-wide hi*hi steps)
+// and a 128-B tile [e4m3(hi 2^-7) x 64 | e4m3(lo 2^4) x 64] consumed by two 64-wide fp8 MFMAs (lo_w * hi_a, hi_w * lo_a; block scale 2^3 on one
+// operand) -- 8 instead of 12 fp16-MFMA units per 64 k at the same operand bytes.  The GELU / SwiGLU outputs (the next GEMM's A operand) leave as
+// f16f8 rows; the BIAS output (q | k | v for the attention kernel) stays a split-fp16 row.
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
+  static_assert(!SX || SP, "f16f8 rows are a form of the split operands");
   static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
   static_assert(!(SP && F8) && (!SPOUT || SP), "split-fp16 and fp8 operands exclude each other; a split output needs split operands");
   static_assert(SPOUT == (SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "f16x3: the half-precision epilogues write split rows");
@@ -274,14 +279,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               for (int j = 0; j < TN; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
           }
-        } else if constexpr (SP) {
-#ifdef FP_SP_FP8CROSS
-          // MEASUREMENT BUILD (profiles/EXPERIMENTS.md round 5; never in the shipped library): the two cross terms of a split
-          // product on the fp8 pipe.  Rows are [hi16 x 64 | hi8 x 64 | lo8 x 64] per 64 logical k (tools/sp_fp8cross.py packs them): an even
-          // 128-B K-tile holds the fp16 high halves (four 16-wide hi*hi steps), the odd one e4m3(hi 2^-7) and e4m3(lo 2^4) (two 64-wide fp8
-          // MFMAs: lo_w * hi_a and hi_w * lo_a, the block scale 2^3 on one operand undoes the two pre-scales).  Same bytes per k as the
-          // shipped rows, 8 instead of 12 fp16-MFMA units per 64 k.  Two tiles per loop iteration, straight-line (a run-time branch on the tile
-          // parity made the allocator spill 420 VGPRs): t is even here, its tile sits in stage 0, the fp8 tile t + 1 in stage 1.
+        } else if constexpr (SP && SX) {
+          // f16f8 rows: an even 128-B K-tile holds the fp16 high halves of 64 k (four 16-wide hi*hi steps), the odd one their e4m3 copies
+          // [hi8 x 64 | lo8 x 64] (two 64-wide fp8 MFMAs: lo_w * hi_a and hi_w * lo_a).  Two tiles per loop iteration, straight-line (a run-time
+          // branch on the tile parity made the allocator spill 420 VGPRs): t is even here, its tile sits in stage 0, the fp8 tile t + 1 in stage 1.
           {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
@@ -328,11 +329,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, 0x82828282, 0, 0x7f7f7f7f);
+                  acc[i][j] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(wf[j], af[i], acc[i][j], 0, 0, 0, (int)FP_SX_MFMA_SCALE, 0, 0x7f7f7f7f);
             }
             ++t;
           }
-#else
+        } else if constexpr (SP) {
 #pragma unroll
           for (int s2 = 0; s2 < 2; ++s2) {  // two 16-wide k-steps of the 32 k-values of this tile
             if (more) {
@@ -374,7 +375,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 #pragma unroll
               for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh[j], ah[i], acc[i][j], 0, 0, 0);
           }
-#endif
         } else {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -559,7 +559,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               h0 = v0 / (1.f + __builtin_amdgcn_exp2f(-v0 * 1.44269504088896340736f)) * v1;  // silu(x1) * x2
               h1 = v2 / (1.f + __builtin_amdgcn_exp2f(-v2 * 1.44269504088896340736f)) * v3;
             }
-            if constexpr (SPOUT) {
+            if constexpr (SPOUT && SX) {
+              unsigned hi, p8;
+              splitx_pack2(h0, h1, a.out_scale, hi, p8, band_amax);
+              splitx_store2(srow, col >> 1, hi, p8);
+            } else if constexpr (SPOUT) {
               unsigned hi, lo;
               split16_pack2(h0, h1, a.out_scale, hi, lo, band_amax);
               char* sp = srow + split16_pos(col >> 1) * 2;
@@ -567,6 +571,11 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               *reinterpret_cast<unsigned*>(sp + 64) = lo;
             } else if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f, band_amax);
             else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
+          } else if constexpr (SPOUT && SX && EPI != GEMM_EPI_BIAS_BF16) {
+            unsigned h01, p01, h23, p23;
+            splitx_pack2(v0, v1, a.out_scale, h01, p01, band_amax);
+            splitx_pack2(v2, v3, a.out_scale, h23, p23, band_amax);
+            splitx_store4(srow, col, h01, p01, h23, p23);
           } else if constexpr (SPOUT) {
             unsigned h01, l01, h23, l23;
             split16_pack2(v0, v1, a.out_scale, h01, l01, band_amax);
@@ -748,7 +757,7 @@ static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
   return {0, 0};
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   // M is padded to whole tiles of every shape in use; tiles of padding rows only are not launched (they would all sit at the end of the
@@ -769,8 +778,8 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;
-  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT>, (int)lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX>, (int)lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
@@ -799,7 +808,7 @@ static bool tall_tile_wins(const GemmBf16Args& a) {
 
 // Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
 // otherwise 128x128 (4 waves, 2 blocks/CU).
-template <int EPI, bool SP = false, bool SPOUT = false>
+template <int EPI, bool SP = false, bool SPOUT = false, bool SX = false>
 int launch(const GemmBf16Args& a, hipStream_t st) {
   const int force = a.tile_override;
   const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
@@ -813,7 +822,7 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
     if ((force == 320 && a.M % 320 == 0 && a.N % 256 == 0) || (force == 0 && use_big && tall_tile_wins(a)))
       return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
   }
-  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT, SX>(a, st);
   // Small M (a batch of one or two crops -- the reference loop's shape, one detection at a time, scripts/infer.py:368): the N = D outputs (proj,
   // fc2) are 12 x 8 = 96 tiles of 128^2 at B = 1 and leave 160 of the 256 CUs idle through fc2's 64 K-tiles (43 us per launch, the largest
   // bucket of a B = 1 forward).  64 x 128 tiles double the count; same k order per output element -> the same bits.
@@ -822,13 +831,13 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
     if ((force == 64 && a.M % 64 == 0) || (force == 0 && a.M % 64 == 0 && tiles_128 <= cus / 2))
       return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT>(a, st);
   }
-  return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT>(a, st);
+  return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT, SX>(a, st);
 }
 
 }  // namespace
 
-// The kernel template above is instantiated by three translation units so that no single compile holds every instantiation (the one-file build
-// ran out of memory): gemm_bf16.hip (bf16 operands), gemm_fp8.hip (-> FP_GEMM_TU == 2), gemm_split.hip (-> FP_GEMM_TU == 3); the latter two
+// The kernel template above is instantiated by four translation units so that no single compile holds every instantiation (the one-file build
+// ran out of memory): gemm_bf16.hip (bf16 operands), gemm_fp8.hip (-> FP_GEMM_TU == 2), gemm_split.hip (-> 3), gemm_splitx.hip (-> 4); the latter three
 // are one-line files that define FP_GEMM_TU and include this one.
 #ifndef FP_GEMM_TU
 #define FP_GEMM_TU 1
@@ -864,12 +873,18 @@ int gemm_fp8_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
 
 #endif  // FP_GEMM_TU == 2
 
+#if FP_GEMM_TU == 3 || FP_GEMM_TU == 4
+// split-fp16 operands (f16x3 mode, TU 3) / f16f8 rows (f16f8 mode, TU 4): a.K is the LOGICAL K; the kernel walks rows of 2K halves
 #if FP_GEMM_TU == 3
-// split-fp16 operands (f16x3 mode): a.K is the LOGICAL K; the kernel walks rows of 2K halves
 int gemm_split_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
+  constexpr bool SX = false;
+#else
+int gemm_splitx_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
+  constexpr bool SX = true;
+#endif
   GemmBf16Args a = a_in;
   FP_REQUIRE(a.M > 0 && a.M % 128 == 0 && a.N > 0 && a.N % 128 == 0, "gemm_split: M (%d) and N (%d) must be positive multiples of 128", a.M, a.N);
-  FP_REQUIRE(a.K > 0 && a.K % 32 == 0, "gemm_split: K (%d) must be a multiple of 32", a.K);
+  FP_REQUIRE(a.K > 0 && a.K % (SX ? 64 : 32) == 0, "gemm_split: K (%d) must be a multiple of %d", a.K, SX ? 64 : 32);
   FP_REQUIRE(a.bias != nullptr, "gemm_split: bias is required (pass zeros)");
   FP_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.lda >= 2 * a.K && a.ldw >= 2 * a.K, "gemm_split: operand rows are 2K halves, 16-byte aligned");
   FP_REQUIRE(a.acc_scale > 0.f, "gemm_split: acc_scale must be positive");
@@ -877,20 +892,19 @@ int gemm_split_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   FP_REQUIRE(!half_out || (a.out_scale > 0.f && a.ldo % 8 == 0), "gemm_split: a split-fp16 output needs out_scale > 0 and ldo %% 8 == 0");
   FP_REQUIRE(half_out || a.ldo % 4 == 0, "gemm_split: ldo must keep 16-byte alignment");
   FP_REQUIRE(epi != GEMM_EPI_LS_RESID_F32 || a.gamma, "gemm_split: gamma required");
-  a.K *= 2;  // halves per row (hi + lo): one 64-half K-tile = 32 logical k
+  a.K *= 2;  // halves per row: one 64-half K-tile = 32 logical k (f16f8: a pair of tiles = 64 logical k)
   switch (epi) {
-    case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16, true, true>(a, st);
-    case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16, true, true>(a, st);
-    case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16, true, true>(a, st);
-    case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32, true, false>(a, st);
-    case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32, true, false>(a, st);
-    case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32, true, false>(a, st);
+    case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16, true, true, SX>(a, st);
+    case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16, true, true, SX>(a, st);
+    case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16, true, true, SX>(a, st);
+    case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32, true, false, SX>(a, st);
+    case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32, true, false, SX>(a, st);
+    case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32, true, false, SX>(a, st);
   }
   fp_set_error("gemm_split: epilogue %d is not available for split-fp16 operands", epi);
   return FP_ERR_UNSUPPORTED;
 }
-
-#endif  // FP_GEMM_TU == 3
+#endif  // FP_GEMM_TU == 3 || 4
 
 #if FP_GEMM_TU == 1
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {

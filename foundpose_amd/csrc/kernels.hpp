@@ -154,10 +154,13 @@ int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 // lda / ldw in halves; out = epi(acc * a.acc_scale + bias); the BIAS / GELU (exact erf) / SwiGLU epilogues write split-fp16 rows
 // again ([M, 2N] halves, values scaled by a.out_scale), LS_RESID / TOKENS / BIAS_F32 write fp32
 int gemm_split_launch(int epi, const GemmBf16Args& a, hipStream_t st);
+// f16f8 mode: the same with A and W as f16f8 rows (common.hpp; K a multiple of 64): hi*hi on the fp16 MFMA, the two cross terms on the fp8 MFMA;
+// the GELU / SwiGLU outputs are f16f8 rows, the BIAS output (q | k | v) stays a split-fp16 row for the attention kernel
+int gemm_splitx_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
 
 // ---------------------------------------------------------------- dtypes of the C ABI
-enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2, FP_DTYPE_F16X3 = 3 };
+enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2, FP_DTYPE_F16X3 = 3, FP_DTYPE_F16F8 = 4 };   // F16F8: common.hpp "f16f8 rows"
 
 // ---------------------------------------------------------------- attn.hip
 struct AttnArgs {
@@ -174,6 +177,7 @@ struct AttnArgs {
   int variant;
   int tail_last;                 // set by the launcher (bf16 w64 kernel): the last (short) query tile of every (image, head) pair goes to the END of its XCD's block sequence
   float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
+  int out_fmt;                   // f16x3 kernel: 0 = the output is a split-fp16 row, 1 = an f16f8 row (common.hpp; the f16f8 mode's proj operand)
   int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps; the split-fp16
                                  // output (a convex combination of v rows that already fit their scale) cannot clamp and reports non-finite values only
 };

@@ -88,6 +88,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
             *reinterpret_cast<unsigned*>(o) = h01;
             *reinterpret_cast<unsigned*>(o + 32) = l01;
           }
+        } else if (a.out_dtype == FP_DTYPE_F16F8) {  // f16f8 row (common.hpp): fp16 high halves + the e4m3 copies of hi and lo
+          char* orow = reinterpret_cast<char*>(a.out) + (size_t)row * a.ld_out * 2;   // ld_out in halves
+          unsigned h01, p01;
+          splitx_pack2(y[0], y[1], a.out_scale, h01, p01, amax);
+          if constexpr (VEC == 4) {
+            unsigned h23, p23;
+            splitx_pack2(y[2], y[3], a.out_scale, h23, p23, amax);
+            splitx_store4(orow, c, h01, p01, h23, p23);
+          } else {
+            splitx_store2(orow, c, h01, p01);
+          }
         } else if (a.out_dtype == FP_DTYPE_BF16) {
           __bf16* o = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c;
           if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
@@ -97,7 +108,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
         }
       }
   }
-  if (a.out_dtype == FP_DTYPE_F16X3) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8) report_saturation(a.sat, 0, amax, FP_F16_MAX);
   else if (a.out_dtype == FP_DTYPE_FP8) report_saturation(a.sat, 1, amax, FP_E4M3_MAX);
 }
 
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
 //  both phases 92 us.)
 // SPLIT (f16x3 mode): T = _Float16 and a row is the split-fp16 image (common.hpp) of the normalised pixels times `scale`; ld = 2 x
 // the padded column count.
-template <typename T, bool SPLIT = false>
+template <typename T, int SPLIT = 0>   // SPLIT: 0 plain rows of T, 1 split-fp16 rows, 2 f16f8 rows (common.hpp)
 __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__ img, int B, int H, int W, int P, T* __restrict__ out, int ld, float scale) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   constexpr int V = 16 / sizeof(T);  // elements per 16-byte chunk
@@ -304,7 +315,15 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
           if (x < W) {
             const unsigned t = xtab[x];
             const float nv = (v[h][i] - mean) / stdv;  // T.Normalize: sub then div
-            if constexpr (SPLIT) {
+            if constexpr (SPLIT == 2) {
+              unsigned h, p8;
+              splitx_pack2(nv, 0.f, scale, h, p8);
+              const int col = r * P + (int)(t & 255u);
+              char* rowb = reinterpret_cast<char*>(tile + (size_t)(t >> 8) * lds_ld);
+              *reinterpret_cast<unsigned short*>(rowb + splitx_pos(col) * 2) = (unsigned short)h;
+              rowb[splitx_hi8(col)] = (char)p8;
+              rowb[splitx_hi8(col) + 64] = (char)(p8 >> 16);
+            } else if constexpr (SPLIT == 1) {
               const float sv = nv * scale;
               const _Float16 hi = (_Float16)sv;
               T* d = tile + (size_t)(t >> 8) * lds_ld + split16_pos(r * P + (int)(t & 255u));
@@ -328,7 +347,7 @@ __global__ __launch_bounds__(256) void patchify_kernel(const float* __restrict__
 
 // stride != patch size (the reference's patch_vit_resolution, dinov2_utils.py:364-389: the conv of the patch embedding runs with a
 // smaller stride, patches overlap): row = b * gh * gw + gy * gw + gx with gh = 1 + (H - P) / stride, same column order.  One thread per
-// output element -- a rarely used configuration, not a hot kernel.  OUT: 0 fp32, 1 bf16, 2 split-fp16 (ld in halves).
+// output element -- a rarely used configuration, not a hot kernel.  OUT: 0 fp32, 1 bf16, 2 split-fp16, 3 f16f8 rows (ld in halves).
 template <int OUT>
 __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __restrict__ img, int B, int H, int W, int P, int stride, int gh, int gw,
                                                                void* __restrict__ out, int ld, int cols_pad, float scale) {
@@ -347,7 +366,14 @@ __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __re
   }
   if constexpr (OUT == 0) reinterpret_cast<float*>(out)[(size_t)row * ld + col] = v;
   else if constexpr (OUT == 1) reinterpret_cast<__bf16*>(out)[(size_t)row * ld + col] = (__bf16)v;
-  else {
+  else if constexpr (OUT == 3) {
+    unsigned h, p8;
+    splitx_pack2(v, 0.f, scale, h, p8);
+    char* rowb = reinterpret_cast<char*>(out) + (size_t)row * ld * 2;
+    *reinterpret_cast<unsigned short*>(rowb + splitx_pos(col) * 2) = (unsigned short)h;
+    rowb[splitx_hi8(col)] = (char)p8;
+    rowb[splitx_hi8(col) + 64] = (char)(p8 >> 16);
+  } else {
     const float sv = v * scale;
     const _Float16 hi = (_Float16)sv;
     _Float16* d = reinterpret_cast<_Float16*>(out) + (size_t)row * ld + split16_pos(col);
@@ -549,8 +575,8 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   const int grid = wgs < 2048 ? wgs : 2048;  // 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
   FP_REQUIRE(a.out_dtype != FP_DTYPE_FP8 || (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0 && a.out_scale > 0.f),
              "layernorm: fp8 output needs dim %% 256 == 0 and a positive scale");
-  FP_REQUIRE(a.out_dtype != FP_DTYPE_F16X3 || (a.ld_out >= 2 * a.dim && a.ld_out % 4 == 0 && a.out_scale > 0.f),
-             "layernorm: a split-fp16 output row is 2 * dim halves and needs a positive scale");
+  FP_REQUIRE((a.out_dtype != FP_DTYPE_F16X3 && a.out_dtype != FP_DTYPE_F16F8) || (a.ld_out >= 2 * a.dim && a.ld_out % 4 == 0 && a.out_scale > 0.f),
+             "layernorm: a split-fp16 / f16f8 output row is 2 * dim halves and needs a positive scale");
   if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0)
     hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, st, a);
   else
@@ -603,13 +629,14 @@ int patchify_strided_launch(const float* images, int batch, int height, int widt
                             hipStream_t st, float out_scale) {
   FP_REQUIRE(stride >= 1 && height >= patch && width >= patch, "patchify: stride %d / image %dx%d / patch %d", stride, height, width, patch);
   const int gh = 1 + (height - patch) / stride, gw = 1 + (width - patch) / stride;
-  const bool split = out_dtype == FP_DTYPE_F16X3;
+  const bool split = out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8;
   const int cols_pad = split ? ld_out / 2 : ld_out;   // logical columns of a row (zero beyond 3 P^2)
-  FP_REQUIRE(cols_pad >= 3 * patch * patch && (!split || ld_out % 64 == 0), "patchify: ld_out too small");
+  FP_REQUIRE(cols_pad >= 3 * patch * patch && (!split || ld_out % 64 == 0) && (out_dtype != FP_DTYPE_F16F8 || ld_out % 128 == 0), "patchify: ld_out too small");
   const long long total = (long long)batch * gh * gw * cols_pad;
   if (total == 0) return FP_OK;
   const unsigned grid = (unsigned)((total + 255) / 256);
-  if (split) hipLaunchKernelGGL(patchify_strided_kernel<2>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
+  if (out_dtype == FP_DTYPE_F16F8) hipLaunchKernelGGL(patchify_strided_kernel<3>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
+  else if (split) hipLaunchKernelGGL(patchify_strided_kernel<2>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
   else if (out_dtype == FP_DTYPE_BF16) hipLaunchKernelGGL(patchify_strided_kernel<1>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
   else hipLaunchKernelGGL(patchify_strided_kernel<0>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
   FP_CHECK_LAUNCH("patchify_strided");
@@ -622,18 +649,22 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
   FP_REQUIRE(ld_out >= 3 * patch * patch, "patchify: ld_out too small");
   const unsigned grid = (unsigned)(batch * (height / patch));  // one workgroup per row of patches
   if (grid == 0) return FP_OK;
-  const bool split = out_dtype == FP_DTYPE_F16X3;  // ld_out = halves per row = 2 x the padded column count (a multiple of 32)
+  const bool split = out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8;  // ld_out = halves per row = 2 x the padded column count (a multiple of 32; f16f8: of 64)
   FP_REQUIRE(!split || (ld_out % 64 == 0 && ld_out >= 2 * ((3 * patch * patch + 31) / 32 * 32)), "patchify: a split-fp16 row is 2 x the columns padded to 32");
+  FP_REQUIRE(out_dtype != FP_DTYPE_F16F8 || (ld_out % 128 == 0 && ld_out >= 2 * ((3 * patch * patch + 63) / 64 * 64)), "patchify: an f16f8 row is 2 x the columns padded to 64");
   const size_t esz = out_dtype == FP_DTYPE_F32 ? 4 : 2;
   FP_REQUIRE(ld_out % (16 / esz) == 0, "patchify: ld_out must keep 16-byte rows");
   const size_t lds = (size_t)(width / patch) * (ld_out + 16 / esz) * esz + (size_t)width * 2;  // the row of patches in output layout + the x table
   FP_REQUIRE(lds <= 160 * 1024 && patch <= 255 && width / patch <= 255, "patchify: a row of patches (%d x %d columns) does not fit LDS", width / patch, ld_out);
-  static FpDeviceOnce attr_b, attr_f, attr_s;
+  static FpDeviceOnce attr_b, attr_f, attr_s, attr_x;
+  fp_allow_dynamic_lds(attr_x, &patchify_kernel<_Float16, 2>, 160 * 1024);
   fp_allow_dynamic_lds(attr_b, &patchify_kernel<__bf16>, 160 * 1024);
   fp_allow_dynamic_lds(attr_f, &patchify_kernel<float>, 160 * 1024);
-  fp_allow_dynamic_lds(attr_s, &patchify_kernel<_Float16, true>, 160 * 1024);
-  if (split)
-    hipLaunchKernelGGL((patchify_kernel<_Float16, true>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, out_scale);
+  fp_allow_dynamic_lds(attr_s, &patchify_kernel<_Float16, 1>, 160 * 1024);
+  if (out_dtype == FP_DTYPE_F16F8)
+    hipLaunchKernelGGL((patchify_kernel<_Float16, 2>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, out_scale);
+  else if (split)
+    hipLaunchKernelGGL((patchify_kernel<_Float16, 1>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, out_scale);
   else if (out_dtype == FP_DTYPE_BF16)
     hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out, 1.f);
   else

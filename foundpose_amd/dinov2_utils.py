@@ -89,14 +89,18 @@ class DinoFeatureExtractor(torch.nn.Module):
             raise NotImplementedError("use_graph replays the token path only")
         if not 0 <= self.layer < self.arch.depth:
             raise ValueError(f"layer {self.layer} out of range for {self.version}")
-        if precision not in ("bf16", "fp32", "fp8", "f16x3"):
-            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3' or 'fp8'")
+        if precision not in ("bf16", "fp32", "fp8", "f16x3", "f16f8"):
+            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3', 'f16f8' or 'fp8'")
         # "f16x3": the near-exact mode.  The reference computes in fp32 (scripts/infer.py:468-473); the fp32-input MFMA runs at 1/16
         # of the fp16 rate, so this mode carries every GEMM / attention operand as a (hi, lo) pair of fp16 numbers (22 mantissa
         # bits) and builds each product from three fp16 MFMAs with fp32 accumulation (include/foundpose_amd.h "split-fp16 rows").
         # Residual stream, LayerNorm, softmax, GELU (exact erf) stay fp32: features at the fp32 path's own noise level, ~3.5x its speed.
-        if precision == "f16x3" and (self.arch.dim % 128 or self.arch.hidden % 128):
-            raise NotImplementedError(f"precision='f16x3' needs dim and hidden to be multiples of 128 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
+        # "f16f8": the same split products with the two cross terms (hi lo, lo hi: ~2^-11 of a product) on the fp8 pipe -- rows carry the fp16 high
+        # halves plus e4m3 copies of hi and lo (include/foundpose_amd.h "f16f8 rows"), 8 instead of 12 fp16-MFMA units per 64 k: GEMMs 1.3x
+        # faster, a product good to ~14 bits at the worst (fc2: 1.3e-5 of the output scale against f16x3's 1.9e-6); q / k / v and the
+        # attention's own products stay three-fp16-MFMA.  Same scales, same saturation report.
+        if precision in ("f16x3", "f16f8") and (self.arch.dim % 128 or self.arch.hidden % 128):
+            raise NotImplementedError(f"precision='{precision}' needs dim and hidden to be multiples of 128 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
         if precision == "fp8" and (self.arch.dim % 256 or self.arch.hidden % 256):
             raise NotImplementedError(f"precision='fp8' needs dim and hidden to be multiples of 256 ({self.version}: {self.arch.dim}, {self.arch.hidden})")
         # fp8 mode (BASELINE config 5): e4m3 block matrices quantised per output channel, GEMM inputs quantised per tensor
@@ -139,7 +143,7 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def _prepare(self, dev: torch.device) -> None:
         a, sd = self.arch, self._sd
-        if self.precision == "f16x3":
+        if self.precision in ("f16x3", "f16f8"):
             return self._prepare_split(dev)
         wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
         w: Dict[str, torch.Tensor] = {}
@@ -275,9 +279,12 @@ class DinoFeatureExtractor(torch.nn.Module):
             w[key] = f32(key).reshape(-1).contiguous()
             return w[key]
 
+        sx = self.precision == "f16f8"
+        pack = ops.splitx_pack if sx else ops.split16_pack
+
         def mat(name, W):  # -> (split rows, scale)
             sw = ops.pow2_scale(W)
-            w[name] = ops.split16_pack(W, sw, pad)
+            w[name] = pack(W, sw, pad)
             return w[name], sw
 
         kp = 3 * a.patch * a.patch
@@ -285,7 +292,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         pw = torch.zeros(a.dim, kpad, dtype=torch.float32, device=dev)
         pw[:, :kp] = f32("patch_embed.proj.weight").reshape(a.dim, kp)
         spw = ops.pow2_scale(pw)
-        w["patch_w"] = ops.split16_pack(pw, spw)
+        w["patch_w"] = pack(pw, spw)
         vec("patch_embed.proj.bias")
         vec("norm.weight")
         vec("norm.bias")
@@ -317,7 +324,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")
         m.patch_stride = 0 if self.stride == self.patch_size else self.stride
-        m.weight_dtype = _lib.FP_F16X3
+        m.weight_dtype = _lib.FP_F16F8 if sx else _lib.FP_F16X3
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.patch_acc_scale = 1.0 / (S_ACT * spw)
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
@@ -367,7 +374,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         key = (B, gh, gw, torch.cuda.current_stream().cuda_stream)  # one workspace per stream: concurrent sub-batches
         if key not in self._ws:
             a, dev = self.arch, self._device
-            sp = self.precision == "f16x3"
+            sp = self.precision in ("f16x3", "f16f8")
             adt = torch.float32 if self.precision == "fp32" else (torch.float16 if sp else torch.bfloat16)
             em = 2 if sp else 1  # stored elements per logical element of an operand row (split rows: hi + lo halves)
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
@@ -430,9 +437,9 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def report_saturation(self, n16: int, n8: int) -> None:
         """The verdict for a pair of counts (split-fp16 clamps, e4m3 clamps): raises in the f16x3 mode, warns once in the fp8 mode."""
-        if n16 and self.precision == "f16x3":
+        if n16 and self.precision in ("f16x3", "f16f8"):
             raise _lib.FoundPoseSaturationError(
-                f"precision='f16x3': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
+                f"precision='{self.precision}': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
                 f"LayerNorm outputs / q / k / v, > {65504 / _lib.SPLIT_SCALE_HID:.0f} for hidden activations) or met a NaN: the features are not the fp32 "
                 "arithmetic's.  Use precision='fp32' for this checkpoint (or reset_saturation() to acknowledge).")
         if n8 and self.precision == "fp8" and not self._fp8_sat_warned:
@@ -472,7 +479,7 @@ class DinoFeatureExtractor(torch.nn.Module):
     @property
     def supports_token_selection(self) -> bool:
         """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms, fp8, or f16x3."""
-        mode_ok = (self.precision == "bf16" and self.fold_layernorm) or self.precision in ("f16x3", "fp8")
+        mode_ok = (self.precision == "bf16" and self.fold_layernorm) or self.precision in ("f16x3", "f16f8", "fp8")
         return (self.facet == "token" and not self.use_graph and mode_ok and self.layer >= 0
                 and self.stride == self.patch_size)   # the selection maps query points to 14-px cells
 
@@ -533,7 +540,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, bufs = self._workspace(B, gh, gw)
         call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
         ntok, fi = 1 + a.registers + gh * gw, {"query": 0, "key": 1, "value": 2}[self.facet]
-        if self.precision == "f16x3":  # split rows (hi + lo halves, scale FP_SPLIT_SCALE_QKV) -> fp32
+        if self.precision in ("f16x3", "f16f8"):  # q | k | v are split-fp16 rows in both modes (hi + lo halves, scale FP_SPLIT_SCALE_QKV) -> fp32
             f = ops.split16_unpack(bufs[3][:B * ntok, fi * 2 * a.dim:(fi + 1) * 2 * a.dim].contiguous(), _lib.SPLIT_SCALE_QKV)
         else:
             f = bufs[3][:B * ntok, fi * a.dim:(fi + 1) * a.dim].float()
@@ -663,7 +670,7 @@ class DinoFeatureExtractor(torch.nn.Module):
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
         B, _, H, W = images.shape
         fmap, cls = self.forward_tokens(images)
-        if self.precision in ("f16x3", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
+        if self.precision in ("f16x3", "f16f8", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
             self.check_saturation()   # one host sync; the reference's forward is synchronous too (CPU tensors)
         gh, gw = self._grid(H, W)
         # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output

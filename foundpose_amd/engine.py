@@ -140,7 +140,7 @@ class FoundPoseEngine:
         self._mark("start")
         # f16x3 / fp8: clamped activations are reported per BATCH -- the sticky device counters are snapshotted before and after the backbone
         # of this batch (two 8-byte device copies, no sync); the result raises / warns for what ITS batch clamped, whatever happened before
-        track_sat = self.extractor.precision in ("f16x3", "fp8")
+        track_sat = self.extractor.precision in ("f16x3", "f16f8", "fp8")
         sat0 = self.extractor.saturation_snapshot() if track_sat else None
         pending = self._query_points_begin(masks, select_tokens=select)
         if select:

@@ -261,6 +261,34 @@ def split16_pack(x: torch.Tensor, scale: float = 1.0, pad: int = 0) -> torch.Ten
     return buf[:, :2 * K]
 
 
+def splitx_pack(x: torch.Tensor, scale: float = 1.0, pad: int = 0) -> torch.Tensor:
+    """fp32 [rows, K] (K % 64 == 0) -> fp16-typed [rows, 2K] f16f8 rows of scale * x (include/foundpose_amd.h "f16f8 rows"): per 64 columns the
+    fp16 high halves (128 B), e4m3(hi 2^-7) (64 B) and e4m3((s x - hi) 2^4) (64 B).  Host-side preparation of weights and test operands, the
+    same arithmetic as the device's splitx_pack2 (common.hpp)."""
+    rows, K = x.shape
+    if K % 64:
+        raise ValueError("splitx_pack: the row length must be a multiple of 64")
+    xs = (x.float() * scale).clamp(-65504.0, 65504.0)
+    hi = xs.half()
+    hi8 = (hi.float() * 2.0 ** -7).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    lo8 = ((xs - hi.float()) * 2.0 ** 4).clamp(-448.0, 448.0).to(torch.float8_e4m3fn).view(torch.uint8)
+    buf = torch.zeros(rows, 2 * K + pad, dtype=torch.float16, device=x.device)
+    by = buf.view(torch.uint8)[:, :4 * K].unflatten(1, (K // 64, 256))
+    by[:, :, :128] = hi.contiguous().view(torch.uint8).unflatten(1, (K // 64, 128))
+    by[:, :, 128:192] = hi8.unflatten(1, (K // 64, 64))
+    by[:, :, 192:256] = lo8.unflatten(1, (K // 64, 64))
+    return buf[:, :2 * K] if pad else buf
+
+
+def splitx_unpack(xs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """What an f16f8 row represents in the products it enters: fp16 [rows, 2K] -> fp32 [rows, K] = (hi + e4m3-lo 2^-4) / scale (summed in fp64)."""
+    rows, K2 = xs.shape
+    by = xs.contiguous().view(torch.uint8).unflatten(1, (K2 // 128, 256))
+    hi = by[:, :, :128].contiguous().view(torch.float16).double()
+    lo = by[:, :, 192:256].contiguous().view(torch.float8_e4m3fn).double() * 2.0 ** -4
+    return ((hi + lo) / scale).reshape(rows, K2 // 2).float()
+
+
 def split16_unpack(xs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
     """Inverse of split16_pack (up to its 2^-22 rounding): fp16 [rows, 2K] -> fp32 [rows, K] = (hi + lo) / scale (summed in fp64)."""
     rows, K2 = xs.shape
@@ -269,8 +297,9 @@ def split16_unpack(xs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: float, gamma=None, out=None, epilogue: int = 0,
-               out_scale: float = 1.0, m_valid: Optional[int] = None, tile: int = 0) -> torch.Tensor:
-    """a [M, 2K], w [N, 2K] split rows (fp16); -> epilogue 0 / 1 / 6: split rows [M, 2N] (6: [M, N]) scaled by out_scale; 3 / 5: fp32 [M, N]."""
+               out_scale: float = 1.0, m_valid: Optional[int] = None, tile: int = 0, f16f8: bool = False) -> torch.Tensor:
+    """a [M, 2K], w [N, 2K] split rows (fp16); -> epilogue 0 / 1 / 6: split rows [M, 2N] (6: [M, N]) scaled by out_scale; 3 / 5: fp32 [M, N].
+    f16f8: a and w (and the output of epilogues 1 / 6) are f16f8 rows (splitx_pack); the output of epilogue 0 stays a split-fp16 row."""
     require_cuda(a, w, bias)
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise ValueError("gemm_split operands are fp16 split rows")
@@ -282,21 +311,22 @@ def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: 
         else:
             out = torch.zeros(M, N if epilogue == 6 else 2 * N, dtype=torch.float16, device=a.device)
     call("fp_gemm_split", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(gamma),
-         ptr(out), out.stride(0), epilogue | (tile << 8), float(acc_scale), float(out_scale), stream())
+         ptr(out), out.stride(0), epilogue | (tile << 8) | (_lib.GEMM_SPLIT_F16F8 if f16f8 else 0), float(acc_scale), float(out_scale), stream())
     return out
 
 
-def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float) -> torch.Tensor:
-    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows."""
+def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float, f16f8_out: bool = False) -> torch.Tensor:
+    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows)."""
     require_cuda(qkv)
     out = torch.zeros(qkv.shape[0], 2 * dim, dtype=torch.float16, device=qkv.device)
-    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale), float(out_scale), stream())
+    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale),
+         -float(out_scale) if f16f8_out else float(out_scale), stream())
     return out
 
 
-def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_scale: float, eps: float = 1e-6) -> torch.Tensor:
+def layernorm_split(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_scale: float, eps: float = 1e-6, f16f8: bool = False) -> torch.Tensor:
     require_cuda(x, weight, bias)
     rows, D = x.shape
     out = torch.empty(rows, 2 * D, dtype=torch.float16, device=x.device)
-    call("fp_layernorm_scaled", ptr(x), x.stride(0), ptr(weight), ptr(bias), eps, ptr(out), 2 * D, _lib.FP_F16X3, float(out_scale), D, rows, stream())
+    call("fp_layernorm_scaled", ptr(x), x.stride(0), ptr(weight), ptr(bias), eps, ptr(out), 2 * D, _lib.FP_F16F8 if f16f8 else _lib.FP_F16X3, float(out_scale), D, rows, stream())
     return out

@@ -24,8 +24,8 @@ extern "C" {
 
 typedef void* fp_stream_t; /* hipStream_t */
 
-enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights, fp_vit_model only;
-                                                               FP_F16X3: split-fp16 rows, see below) */
+enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights,
+                                                               fp_vit_model only; FP_F16X3: split-fp16 rows, FP_F16F8: f16f8 rows, see below) */
 
 /* ---- split-fp16 rows (the "f16x3" near-exact mode) --------------------------------------------------------------------
  * The reference computes the backbone in fp32 (scripts/infer.py:468-473).  The fp32-input MFMA runs at 1/16 of the fp16 /
@@ -42,7 +42,18 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3 }; /* element types of 
  *  multiplies like any other number, so a modest scale costs nothing on O(1) activations and leaves three decades of head room for
  *  the outlier channels of real checkpoints.) */
 
-#define FP_ABI_VERSION 14
+/* ---- f16f8 rows (the "f16f8" mode: the split product with its two cross terms on the fp8 pipe) ---------------------------------
+ * a b = hi_a hi_b + (hi_a lo_b + lo_a hi_b): the cross terms are ~2^-11 of the product, so they do not need fp16 operands.  An f16f8
+ * row keeps the fp16 high halves and carries e4m3 copies of hi and lo for the cross terms, which run as two 64-wide
+ * v_mfma_scale_f32_32x32x64_f8f6f4 (twice the fp16 rate): 8 instead of 12 fp16-MFMA units per 64 k at the same 4 bytes per element.
+ * Storage: a logical row of K values (K % 64 == 0) is 4K bytes; group g = k / 64 holds  bytes [256g, 256g + 128): hi = f16(s x) (64 halves);
+ * [256g + 128, 256g + 192): e4m3(hi 2^-7); [256g + 192, 256g + 256): e4m3((s x - hi) 2^4).  Same scales s and saturation report as the
+ * split-fp16 rows.  A product carries ~14 mantissa bits at the worst (measured on fc2, K = 4096: max error 1.3e-5 of the output scale
+ * against 1.9e-6 for f16x3); fp_vit_forward with weight_dtype FP_F16F8 uses these rows for every GEMM operand, while q | k | v and the
+ * attention's own products stay split-fp16 (three fp16 MFMAs). */
+#define FP_GEMM_SPLIT_F16F8 (1 << 20) /* OR-ed into fp_gemm_split's `epilogue`: A, W (and a GELU / SwiGLU output) are f16f8 rows, K % 64 == 0 */
+
+#define FP_ABI_VERSION 15
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -205,7 +216,7 @@ typedef struct {
    * act_scale[0..3] quantise the inputs of qkv, proj, fc1, fc2 (static per-tensor scales from a calibration batch) */
   const float *qkv_s, *proj_s, *fc1_s, *fc2_s;
   float act_scale[4];
-  /* weight_dtype == FP_F16X3: the four matrices are split-fp16 rows ([N, 2K] halves) of s_w W with a power-of-two s_w per
+  /* weight_dtype == FP_F16X3 (FP_F16F8: the same with f16f8 rows): the four matrices are split-fp16 rows ([N, 2K] halves) of s_w W with a power-of-two s_w per
    * matrix, and act_scale[0..3] = 1 / (scale of the GEMM's input rows x s_w) for qkv, proj, fc1, fc2: the epilogue computes
    * acc * act_scale + bias.  ls1 / ls2 are applied as usual. */
   /* fp_vit_model.ln_fold only: fp32 [N] sums of the rows of the (gain-folded, bf16-rounded) qkv_w / fc1_w */
@@ -372,10 +383,11 @@ int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, in
  * halves, values x out_scale, ldo in halves); 3 (out += gamma v) and 5 (bias) write fp32. */
 int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
-/* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, scale in_scale) -> out [B*N, 2D] halves (scale out_scale) */
+/* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, scale in_scale) -> out [B*N, 2D] halves (scale out_scale).
+ * A NEGATIVE out_scale writes the output as an f16f8 row scaled by |out_scale| (the f16f8 mode's proj operand). */
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
                        fp_stream_t stream);
-/* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes) or FP_F16X3 (split row of y * out_scale) */
+/* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes), FP_F16X3 (split row of y * out_scale) or FP_F16F8 (f16f8 row) */
 int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out, int out_dtype, float out_scale,
                         int dim, int out_rows, fp_stream_t stream);
 int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* out, fp_stream_t stream);
