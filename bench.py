@@ -102,6 +102,7 @@ def main():
                     help="the near-exact mode timed next to the headline as `parity_mode` (f16x3: split-fp16 operands, three fp16 MFMAs per product; "
                          "fp32: the exact-fp32 MFMA mode) with its index agreement against oracle A and the fp32 mode")
     ap.add_argument("--parity-steps", type=int, default=5)
+    ap.add_argument("--no-parity-fast", action="store_true", help="skip `parity_mode_fast` (the f16f8 mode timed next to the f16x3 parity mode)")
     ap.add_argument("--skip-probes", action="store_true", help="time the steps and stop: no roofline probe launches, no parity passes (tools/pmc_bench.sh: every "
                                                                 "launch the counters see then belongs to a step of the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -275,6 +276,18 @@ def main():
                        else "as f16x3 with the two cross terms of every GEMM product (hi lo + lo hi, ~2^-11 of the product) on the fp8 MFMA: rows carry fp16 high halves + e4m3 copies of "
                             "hi and lo, 8 instead of 12 fp16-MFMA units per 64 k; q / k / v and the attention's own products stay three-fp16-MFMA" if args.parity_precision == "f16f8"
                        else "exact-fp32 MFMA GEMMs (k-ascending fmaf chains) + fp32 attention")}
+    # ... and its faster variant (f16f8: the cross terms of every GEMM product on the fp8 pipe), driver-timed the same way -> `parity_mode_fast`
+    pmf, ex_pmf = None, None
+    if args.parity_precision == "f16x3" and args.precision not in ("f16x3", "f16f8") and not args.no_parity_fast:
+        ex_pmf = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="f16f8").to(dev)
+        eng_pmf = fe.FoundPoseEngine(ex_pmf, bank, 14.0, 5, 300, tie_order=args.tie_order)
+        step(eng_pmf)
+        el_f, (_, last_pmf) = timed(eng_pmf, args.parity_steps)
+        pmf = {"precision": "f16f8", "value": round(world * B * args.parity_steps / el_f, 2), "unit": "detections/s",
+               "ms_per_step": round(1e3 * el_f / args.parity_steps, 3), "steps": args.parity_steps, "n_gpus": world,
+               "what": "as f16x3 with the two cross terms of every GEMM product (hi lo + lo hi, ~2^-11 of the product) on the fp8 MFMA: rows carry the fp16 high halves + e4m3 "
+                       "copies of hi and lo, 8 instead of 12 fp16-MFMA units per 64 k (a product good to ~14 bits at the worst); q / k / v and the attention's own products stay "
+                       "three-fp16-MFMA"}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
         mv = B * n_tok
@@ -458,6 +471,9 @@ def main():
         lists_pm = [last_pm.corresp_list(b) for b in range(B)] if pm is not None else None
         if pm is not None:
             pm["planted"] = workload.planted_stats(lists_pm, wl.targets.tolist())
+        lists_pmf = [last_pmf.corresp_list(b) for b in range(B)] if pmf is not None else None
+        if pmf is not None:
+            pmf["planted"] = workload.planted_stats(lists_pmf, wl.targets.tolist())
         if not args.no_parity:  # the library's fp32 mode on every detection of the batch (same bank, same tie order)
             eng32 = fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order=args.tie_order)
             res32 = eng32.infer_batch(images, masks, det_obj)
@@ -465,6 +481,8 @@ def main():
             parity["vs_fp32_mode"] = workload.parity_stats(lists, lists32)
             if pm is not None and args.parity_precision != "fp32":
                 pm["vs_fp32_mode"] = workload.parity_stats(lists_pm, lists32)
+            if pmf is not None:
+                pmf["vs_fp32_mode"] = workload.parity_stats(lists_pmf, lists32)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             dbg = eng.infer_batch(images, masks, det_obj, keep_debug=True)   # one untimed step that keeps the visual-word ids (stage attribution)
             q_cnt = [int(masks[b, 7::14, 7::14].sum()) for b in range(B)]
@@ -476,6 +494,8 @@ def main():
             parity.update(extra)
             if pm is not None:
                 pm["vs_oracle_a"] = workload.parity_stats(lists_pm[:len(ora)], ora)
+            if pmf is not None:
+                pmf["vs_oracle_a"] = workload.parity_stats(lists_pmf[:len(ora)], ora)
         else:
             oracle_feats = None
         if world == 1 and not args.no_hard:
@@ -483,12 +503,19 @@ def main():
             exs = {"fp32": ex32, args.precision: extractor}
             if ex_pm is not None and args.parity_precision in ("f16x3", "f16f8"):
                 exs[args.parity_precision] = ex_pm
+            if ex_pmf is not None:
+                exs["f16f8"] = ex_pmf
             parity["hard"] = hard_parity(args, wl, exs, oracle_feats, dict(batch=B, full_mask=full_mask, W_words=W_words, wpt=wpt, rank=rank, dev=dev))
         if pm is not None:  # north_star's index bar, stated as booleans next to the mode's throughput
             pm["index_exact_vs_oracle_a"] = ("vs_oracle_a" in pm and pm["vs_oracle_a"]["corresp_equal"] == pm["vs_oracle_a"]["slots_compared"]
                                              and pm["vs_oracle_a"]["templates_equal"] == pm["vs_oracle_a"]["detections"]) if "vs_oracle_a" in pm else None
             pm["index_exact_vs_fp32_mode"] = (pm["vs_fp32_mode"]["corresp_equal"] == pm["vs_fp32_mode"]["slots_compared"]) if "vs_fp32_mode" in pm else None
             result["parity_mode"] = pm
+        if pmf is not None:
+            for key in ("vs_oracle_a", "vs_fp32_mode"):
+                if key in pmf:
+                    pmf["index_exact_" + key] = pmf[key]["corresp_equal"] == pmf[key]["slots_compared"] and pmf[key]["templates_equal"] == pmf[key]["detections"]
+            result["parity_mode_fast"] = pmf
         result["parity"] = parity
         if world == 1 and not args.no_latency:
             result["latency_b1"], result["pipeline"] = latency_and_pipeline(args, wl, bank, extractor, eng, result.get("cpu_baseline"))
@@ -497,6 +524,8 @@ def main():
             del eng, eng_o, extractor, ex32, bank, wl, images, masks, last, gathered
             if pm is not None:
                 del eng_pm, ex_pm, last_pm
+            if pmf is not None:
+                del eng_pmf, ex_pmf, last_pmf
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -816,13 +845,17 @@ def other_config(label, args, dev, rank, steps=5, parity_steps=3):
     ex = None
     gc.collect()
     torch.cuda.empty_cache()
-    ex3 = feature_util.make_feature_extractor(name, state_dict=sd, precision="f16x3").to(dev)
-    v3, ms3, lists3 = run(ex3, parity_steps, 1)
-    st3 = workload.parity_stats(lists3, lists32)
-    out["parity_mode"] = {"precision": "f16x3", "value": v3, "unit": "detections/s", "ms_per_step": ms3, "steps": parity_steps,
-                          "planted": workload.planted_stats(lists3, wl.targets.tolist()), "vs_fp32_mode": st3,
-                          "index_exact_vs_fp32_mode": st3["corresp_equal"] == st3["slots_compared"] and st3["templates_equal"] == st3["detections"]}
-    del ex3, bank, wl, inp, sd
+    for key, prec in (("parity_mode", "f16x3"), ("parity_mode_fast", "f16f8")):
+        ex3 = feature_util.make_feature_extractor(name, state_dict=sd, precision=prec).to(dev)
+        v3, ms3, lists3 = run(ex3, parity_steps, 1)
+        st3 = workload.parity_stats(lists3, lists32)
+        out[key] = {"precision": prec, "value": v3, "unit": "detections/s", "ms_per_step": ms3, "steps": parity_steps,
+                    "planted": workload.planted_stats(lists3, wl.targets.tolist()), "vs_fp32_mode": st3,
+                    "index_exact_vs_fp32_mode": st3["corresp_equal"] == st3["slots_compared"] and st3["templates_equal"] == st3["detections"]}
+        ex3 = None
+        gc.collect()
+        torch.cuda.empty_cache()
+    del bank, wl, inp, sd
     gc.collect()
     torch.cuda.empty_cache()
     return out

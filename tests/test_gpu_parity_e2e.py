@@ -50,6 +50,9 @@ def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, temp
     ex3 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="f16x3").to("cuda")   # the near-exact mode bench.py times as `parity_mode`
     got3 = _run(fe.FoundPoseEngine(ex3, bank, 14.0, 5, 300, tie_order="torch"), wl, 32)
     del ex3
+    ex8 = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="f16f8").to("cuda")   # f16x3 with the cross terms on the fp8 pipe: bench.py's `parity_mode_fast`
+    got8 = _run(fe.FoundPoseEngine(ex8, bank, 14.0, 5, 300, tie_order="torch"), wl, batch)
+    del ex8
 
     # ---- oracle A on a sample: first detection of the batch, and the last ones (another object in config 3)
     sd = synthetic.make_vit_state_dict(arch, seed=1234)
@@ -83,6 +86,14 @@ def test_benchmarked_mode_vs_oracle_a_and_fp32_mode(config, batch, objects, temp
     assert p3["templates_equal"] == n and p3["corresp_equal"] == p3["slots_compared"] == 5 * n
     assert full3["templates_equal"] == batch and pl3["planted_top5_in_order"] == batch
     assert full3["corresp_equal"] == full3["slots_compared"] == 5 * batch, full3   # every slot of every detection (r3 allowed 3 % of them to differ; none does)
+    # the f16f8 mode (a product good to ~14 bits instead of 22): the same templates for every detection, the planted ones, and correspondences
+    # held to the index agreement MEASURED for this case (tests/golden/measured_bars.json; a recorded 0 makes this an equality)
+    full8 = workload.parity_stats(got8, got32)
+    p8 = workload.parity_stats([got8[b] for b in sample], ora)
+    print(f"[{config}] f16f8 mode vs oracle A: {p8}\n[{config}] f16f8 vs fp32 mode, all {batch}: {full8}")
+    assert full8["templates_equal"] == batch and p8["templates_equal"] == n and workload.planted_stats(got8, wl.targets.tolist())["planted_top5_in_order"] == batch
+    check_bar(f"e2e_{config}_{version}/f16f8/slots_differing_vs_fp32_mode", 1.0 - full8["corresp_equal"] / full8["slots_compared"], 0.03)
+    check_bar(f"e2e_{config}_{version}/f16f8/slots_differing_vs_oracle_a", 1.0 - p8["corresp_equal"] / p8["slots_compared"], 0.2)
     # the benchmarked bf16 mode: the same five templates in the same order for every detection, the planted ones
     assert pbf["templates_equal"] == n
     assert full["templates_equal"] == batch and plbf["planted_top5_in_order"] == batch and pl32["planted_top5_in_order"] == batch
@@ -244,7 +255,7 @@ def test_default_backbone_dinov2_vitl14_vs_oracle_a():
         assert workload.planted_stats(runs[k], wl.targets.tolist())["planted_top5_in_order"] == batch
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f16x3"])
+@pytest.mark.parametrize("precision", ["bf16", "f16x3", "f16f8"])
 def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
     """The engine's default path computes the hooked block for the sampled tokens only; with FP_TOKEN_SELECT=0 it runs the
     block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark
