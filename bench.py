@@ -304,10 +304,11 @@ def main():
             w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
             bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
             out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
-            if args.precision == "f16x3":   # split-fp16 operands: the algorithmic FLOPs are those of the fp32 product (3 MFMAs each)
-                a3, w3 = ops.split16_pack(a.float(), 128.0, 64), ops.split16_pack(w.float(), ops.pow2_scale(w.float()), 64)
+            if args.precision in ("f16x3", "f16f8"):   # split operands: the algorithmic FLOPs are those of the fp32 product
+                pack = ops.splitx_pack if args.precision == "f16f8" else ops.split16_pack
+                a3, w3 = pack(a.float(), 128.0, 64), pack(w.float(), ops.pow2_scale(w.float()), 64)
                 o3 = torch.zeros(M, n, dtype=torch.float32, device=dev) if epi == 3 else torch.zeros(M, n if epi == 6 else 2 * n, dtype=torch.float16, device=dev)
-                return time_kernel(lambda: ops.gemm_split(a3, w3, bias, 1e-6, gamma=gamma, out=o3, epilogue=epi, out_scale=64.0, m_valid=mv))
+                return time_kernel(lambda: ops.gemm_split(a3, w3, bias, 1e-6, gamma=gamma, out=o3, epilogue=epi, out_scale=64.0, m_valid=mv, f16f8=args.precision == "f16f8"))
             if args.precision == "fp8":
                 a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
                 col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
@@ -332,16 +333,16 @@ def main():
         fl = lambda n, k: 2.0 * mv * n * k     # algorithmic: valid rows only
         # attention of one block at the step's shape (all tokens as queries; the precision's own kernel), 4 N^2 d per (image, head)
         attn_info = None
-        if args.precision in ("bf16", "fp8", "f16x3"):
+        if args.precision in ("bf16", "fp8", "f16x3", "f16f8"):
             xq = torch.randn(M, 3 * arch.dim, device=dev)
-            if args.precision == "f16x3":
+            if args.precision in ("f16x3", "f16f8"):
                 pk = torch.cat([ops.split16_pack(xq[:, i * arch.dim:(i + 1) * arch.dim].contiguous(), 16.0) for i in range(3)], dim=1)
                 ms_attn = time_kernel(lambda: ops.attention_split(pk, B, n_tok, arch.dim, arch.heads, 16.0, 16.0))
             else:
                 xq16 = xq.to(torch.bfloat16)
                 ms_attn = time_kernel(lambda: ops.attention(xq16, B, n_tok, arch.dim, arch.heads))
             attn_flops = 4.0 * B * n_tok * n_tok * arch.dim
-            attn_info = {"kernel": "attn_split_kernel (three fp16 MFMAs per product; FLOPs of the fp32 product)" if args.precision == "f16x3" else "attn_bf16_w64_kernel",
+            attn_info = {"kernel": "attn_split_kernel (three fp16 MFMAs per product; FLOPs of the fp32 product)" if args.precision in ("f16x3", "f16f8") else "attn_bf16_w64_kernel",
                          "bound": "mfma", "launch_ms": round(ms_attn, 4), "achieved": round(attn_flops / (ms_attn * 1e-3) / 1e12, 1), "peak": PEAK_BF16_TFLOPS,
                          "unit": "TFLOP/s", "frac": round(attn_flops / (ms_attn * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4), "flops_per_launch": attn_flops,
                          "note": "back-to-back launches on random scores (inside the pipeline, behind the qkv GEMM, the same kernel measures 5-10 % faster: profiles/*_per_step_kernels.csv)"}

@@ -186,28 +186,6 @@ def test_f16f8_saturation_and_nan_are_loud():
             ex(imgs)
 
 
-def test_engine_f16f8_token_selection_and_planted_answer(monkeypatch):
-    """Through the engine: the hooked block on the sampled tokens only == on every token, tensor for tensor; every detection retrieves its planted
-    templates in order; agreement with the library's fp32 mode is recorded (and held to the measured rate)."""
-    from foundpose_amd import engine as fe, feature_util, workload
-    from foundpose_amd.bank import DeviceBank
-    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=9_norm=1"
-    ex32 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="fp32").to("cuda")
-    wl = workload.build_planted_workload(ex32, 6, 224, 1, 120, seed=4, crop_seed=2)
-    bank = DeviceBank(wl.repres)
-    run = lambda ex: fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj)
-    r32 = run(ex32)
-    ex8 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="f16f8").to("cuda")
-    assert ex8.supports_token_selection
-    sel = run(ex8)
-    monkeypatch.setenv("FP_TOKEN_SELECT", "0")
-    full = run(ex8)
-    monkeypatch.delenv("FP_TOKEN_SELECT")
-    for f in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_3d"):
-        assert torch.equal(getattr(sel, f), getattr(full, f)), f
-    lists8, lists32 = [sel.corresp_list(b) for b in range(6)], [r32.corresp_list(b) for b in range(6)]
-    assert workload.planted_stats(lists8, wl.targets.tolist())["planted_top5_in_order"] == 6
-    st = workload.parity_stats(lists8, lists32)
-    print(f"\n[f16f8 engine, vits14-reg 224] vs fp32 mode: {st}")
-    assert st["templates_equal"] == 6
-    check_bar("f16f8_engine_vits14reg_224/1-overlap_vs_fp32_mode", 1.0 - st["corresp_overlap"], 0.02, floor=2e-3)
+# Through the engine: tests/test_gpu_parity_e2e.py::test_token_selection_changes_nothing_end_to_end[f16f8] (the hooked block on the sampled tokens only ==
+# on every token, tensor for tensor) and ::test_benchmarked_mode_vs_oracle_a_and_fp32_mode (configs 2 and 3: planted templates in order for every
+# detection, index agreement with oracle A and with the fp32 mode held to the measured rate); bench.py times the mode as `parity_mode_fast`.

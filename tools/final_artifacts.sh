@@ -5,9 +5,10 @@ tag=${1:-rX}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/${tag}_pytest_gpu.log
-python bench.py 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_final.json
+python bench.py < /dev/null 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_final.json
 bash tools/profile_bench.sh ${tag}_final > /dev/null 2>&1
 bash tools/profile_bench.sh ${tag}_f16x3 --precision f16x3 --parity-precision none > /dev/null 2>&1
+bash tools/profile_bench.sh ${tag}_f16f8 --precision f16f8 --parity-precision none > /dev/null 2>&1
 bash tools/pmc_bench.sh ${tag} > /dev/null 2>&1
 bash tools/pmc_mfma.sh ${tag}_bf16 > /dev/null 2>&1
 bash tools/pmc_mfma.sh ${tag}_f16x3 --precision f16x3 > /dev/null 2>&1
