@@ -380,7 +380,6 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
   FP_REQUIRE(A && W && out, "fp_gemm_split: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;
   const bool f16f8 = (epilogue >> 20) & 1;   // FP_GEMM_SPLIT_F16F8: the operands (and a GELU / SwiGLU output) are f16f8 rows
-  const int sx_cols = ((epilogue >> 21) & 0x3ff) * 256;   // FP_GEMM_SPLIT_QK_COLS(n): the first n output columns of a BIAS epilogue leave as f16f8 rows
   epilogue &= 0xff;
   FP_REQUIRE(tile == 0 || tile == 128 || tile == 256, "fp_gemm_split: bad tile override %d", tile);
   FP_REQUIRE(epilogue == GEMM_EPI_BIAS_BF16 || epilogue == GEMM_EPI_GELU_BF16 || epilogue == GEMM_EPI_LS_RESID_F32 ||
@@ -390,7 +389,7 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
-  a.tile_override = tile; a.acc_scale = acc_scale; a.out_scale = out_scale; a.sx_cols = sx_cols;
+  a.tile_override = tile; a.acc_scale = acc_scale; a.out_scale = out_scale;
   return f16f8 ? gemm_splitx_launch(epilogue, a, ST(stream)) : gemm_split_launch(epilogue, a, ST(stream));
 }
 
@@ -400,9 +399,8 @@ int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
-  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = fabsf(in_scale); a.out_scale = fabsf(out_scale);
+  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = fabsf(out_scale);
   a.out_fmt = out_scale < 0.f ? 1 : 0;   // a NEGATIVE out_scale asks for an f16f8 output row (scaled by its magnitude)
-  a.in_fmt = in_scale < 0.f ? 1 : 0;     // a NEGATIVE in_scale says q and k are f16f8 rows (v stays split-fp16)
   return attn_launch(a, FP_DTYPE_F16X3, ST(stream));
 }
 
@@ -645,10 +643,9 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       // LayerNorm 2 / fc1 / fc2 run on them.  Per-row arithmetic does not depend on where a row sits: the same bits as the full block.
       const bool selected = mode == VIT_LAST_SELECTED;
       auto sgemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
-                       float acc_scale, float out_scale, int sx_cols = 0) -> int {
+                       float acc_scale, float out_scale) -> int {
         GemmBf16Args g;
         memset(&g, 0, sizeof(g));
-        g.sx_cols = sx_cols;
         g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
         g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
         g.acc_scale = acc_scale; g.out_scale = out_scale; g.sat = ws->sat;
@@ -656,11 +653,10 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       };
       ln.out_scale = FP_SPLIT_SCALE_ACT;
       TRY(layernorm_launch(ln, st));
-      TRY(sgemm(ws->y, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.act_scale[0], FP_SPLIT_SCALE_QKV, sx ? 2 * D : 0));
+      TRY(sgemm(ws->y, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.act_scale[0], FP_SPLIT_SCALE_QKV));
       AttnArgs as = at;
       as.in_scale = FP_SPLIT_SCALE_QKV; as.out_scale = FP_SPLIT_SCALE_ACT;
-      as.out_fmt = sx ? 1 : 0;   // f16f8: the attention's output is proj's f16f8 operand ...
-      as.in_fmt = sx ? 1 : 0;    // ... and q | k arrive as f16f8 rows (the cross terms of K Q^T on the fp8 pipe); v, P and P V stay split-fp16
+      as.out_fmt = sx ? 1 : 0;   // f16f8: q | k | v stay split-fp16 rows (the attention's own three-MFMA products), its output is proj's f16f8 operand
       float* xr = ws->x;  // the residual rows the rest of the block updates
       if (selected) {
         as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;

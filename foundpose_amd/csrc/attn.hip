@@ -613,10 +613,6 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 constexpr float SPLIT_P_SCALE = 16384.f;
 constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);  // 1 in the exponent, in score units
 
-// QK8 (the f16f8 mode): q and k arrive as f16f8 rows (common.hpp: a head's 64 dims = fp16 high halves 128 B | e4m3(hi 2^-7) 64 B | e4m3(lo 2^4) 64 B --
-// the same 256 B per key, so the staging and the K image are unchanged) and S^T = K Q^T is four fp16 MFMAs (hi*hi) + two 64-wide fp8 MFMAs (lo_k hi_q,
-// hi_k lo_q; block scale 2^3) instead of twelve fp16 MFMAs per 32 keys; v, P and the P V product are the split-fp16 form in both modes.
-template <bool QK8>
 __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][16384];  // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -677,30 +673,17 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   // exp2 argument = score * head_dim^-0.5 * log2(e); the accumulated scores carry the operand scales in_scale^2
   const float c = 0.125f * 1.44269504088896340736f / (a.in_scale * a.in_scale);
   // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d] as (hi, lo)
-  typedef __attribute__((ext_vector_type(8))) int qi32x8;
-  typedef __attribute__((ext_vector_type(4))) int qi32x4;
-  f16x8 qh[4], ql[4];      // QK8: ql is unused, q8h / q8l carry the e4m3 copies (lane (query, kh): dims 32 kh .. 32 kh + 31)
-  qi32x8 q8h = {}, q8l = {};
+  f16x8 qh[4], ql[4];
   {
     const int q = q0 + l31;
     int qc = q < NQ ? q : NQ - 1;
     if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;  // the selected query's token
     const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
-    if constexpr (QK8) {
 #pragma unroll
-      for (int ds = 0; ds < 4; ++ds) qh[ds] = *reinterpret_cast<const f16x8*>(qp + ds * 16 + kh * 8);
-      const char* qb = reinterpret_cast<const char*>(qp);
-      const qi32x4 h0 = *reinterpret_cast<const qi32x4*>(qb + 128 + kh * 32), h1 = *reinterpret_cast<const qi32x4*>(qb + 144 + kh * 32);
-      const qi32x4 l0 = *reinterpret_cast<const qi32x4*>(qb + 192 + kh * 32), l1 = *reinterpret_cast<const qi32x4*>(qb + 208 + kh * 32);
-      q8h = __builtin_shufflevector(h0, h1, 0, 1, 2, 3, 4, 5, 6, 7);
-      q8l = __builtin_shufflevector(l0, l1, 0, 1, 2, 3, 4, 5, 6, 7);
-    } else {
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
-        qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
-        ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
-      }
+    for (int ds = 0; ds < 4; ++ds) {
+      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
+      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
+      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
     }
   }
   f32x16 oacc[2];
@@ -731,32 +714,6 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
-      if constexpr (QK8) {
-        // f16f8 k rows: chunks 0..7 = hi16 (dims 8 c .. 8 c + 7), 8..11 = e4m3(hi), 12..15 = e4m3(lo) (dims 16 (c - 8 | 12) ...)
-#pragma unroll
-        for (int ds = 0; ds < 4; ++ds) {
-          const int ch = ds * 2 + kh;
-#pragma unroll
-          for (int ks = 0; ks < KS; ++ks) {
-            const int row = ks * 32 + l31;
-            const f16x8 kf = *reinterpret_cast<const f16x8*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4));
-            sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qh[ds], sacc[ks], 0, 0, 0);
-          }
-        }
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int row = ks * 32 + l31;
-          const char* kr = Ks + row * 256;
-          auto frag8 = [&](int c0) {
-            const qi32x4 lo = *reinterpret_cast<const qi32x4*>(kr + ((c0 ^ (row & 15)) << 4));
-            const qi32x4 hi = *reinterpret_cast<const qi32x4*>(kr + (((c0 + 1) ^ (row & 15)) << 4));
-            return __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-          };
-          const qi32x8 k8l = frag8(12 + 2 * kh), k8h = frag8(8 + 2 * kh);
-          sacc[ks] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k8l, q8h, sacc[ks], 0, 0, 0, (int)FP_SX_MFMA_SCALE, 0, 0x7f7f7f7f);
-          sacc[ks] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(k8h, q8l, sacc[ks], 0, 0, 0, (int)FP_SX_MFMA_SCALE, 0, 0x7f7f7f7f);
-        }
-      } else
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
         const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
@@ -1169,9 +1126,7 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 8 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
     FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
     FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
-    const dim3 sgrid((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch));
-    if (a.in_fmt == 1) hipLaunchKernelGGL(attn_split_kernel<true>, sgrid, dim3(512), 0, st, a);
-    else hipLaunchKernelGGL(attn_split_kernel<false>, sgrid, dim3(512), 0, st, a);
+    hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection exists in the bf16 and f16x3 kernels");
     if (a.variant == 1) {  // the thread-per-query VALU kernel (one fma chain per score, keys in order): the cross-check of the MFMA kernel

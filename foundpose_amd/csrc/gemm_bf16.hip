@@ -576,11 +576,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             splitx_pack2(v0, v1, a.out_scale, h01, p01, band_amax);
             splitx_pack2(v2, v3, a.out_scale, h23, p23, band_amax);
             splitx_store4(srow, col, h01, p01, h23, p23);
-          } else if (SPOUT && SX && EPI == GEMM_EPI_BIAS_BF16 && n0 < a.sx_cols) {   // q | k of the qkv GEMM (block-uniform: sx_cols is a multiple of the tile width)
-            unsigned h01, p01, h23, p23;
-            splitx_pack2(v0, v1, a.out_scale, h01, p01, band_amax);
-            splitx_pack2(v2, v3, a.out_scale, h23, p23, band_amax);
-            splitx_store4(srow, col, h01, p01, h23, p23);
           } else if constexpr (SPOUT) {
             unsigned h01, l01, h23, l23;
             split16_pack2(v0, v1, a.out_scale, h01, l01, band_amax);
@@ -897,8 +892,6 @@ int gemm_splitx_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
   FP_REQUIRE(!half_out || (a.out_scale > 0.f && a.ldo % 8 == 0), "gemm_split: a split-fp16 output needs out_scale > 0 and ldo %% 8 == 0");
   FP_REQUIRE(half_out || a.ldo % 4 == 0, "gemm_split: ldo must keep 16-byte alignment");
   FP_REQUIRE(epi != GEMM_EPI_LS_RESID_F32 || a.gamma, "gemm_split: gamma required");
-  FP_REQUIRE(a.sx_cols == 0 || (SX && epi == GEMM_EPI_BIAS_BF16 && a.sx_cols % 256 == 0),
-             "gemm_split: sx_cols is an option of the f16f8 BIAS epilogue and must be a multiple of 256 (whole tiles of either width)");
   a.K *= 2;  // halves per row: one 64-half K-tile = 32 logical k (f16f8: a pair of tiles = 64 logical k)
   switch (epi) {
     case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16, true, true, SX>(a, st);

@@ -146,7 +146,6 @@ struct GemmBf16Args {
   //   out = epi(rstd_r * (acc - mean_r * colsum_n) + bias_n);  ln_stats [M] = (rstd_r, mean_r * rstd_r) from ln_finalize_launch
   const float2* ln_stats; int ln_parts; float ln_eps;
   const float* colsum;        // [N] fp32 sums of the rows of W
-  int sx_cols;                // f16f8 kernels, BIAS epilogue: output columns below this bound leave as f16f8 rows (q | k of the qkv GEMM), the others as split-fp16 rows (v); 0: all split-fp16
   int* sat;                   // may be null; else [2] sticky saturation counters (common.hpp report_saturation): the split-fp16 / e4m3 epilogues report clamped outputs
 };
 
@@ -179,7 +178,6 @@ struct AttnArgs {
   int tail_last;                 // set by the launcher (bf16 w64 kernel): the last (short) query tile of every (image, head) pair goes to the END of its XCD's block sequence
   float in_scale, out_scale;     // f16x3 kernel: power-of-two scale the split-fp16 q / k / v rows carry, and the one the output row gets
   int out_fmt;                   // f16x3 kernel: 0 = the output is a split-fp16 row, 1 = an f16f8 row (common.hpp; the f16f8 mode's proj operand)
-  int in_fmt;                    // f16x3 kernel: 0 = q, k, v are split-fp16 rows; 1 = q and k are f16f8 rows (the cross terms of K Q^T on the fp8 pipe), v split-fp16
   int* sat;                      // may be null; else [2] sticky saturation counters: the e4m3 output of the bf16 kernel reports clamps; the split-fp16
                                  // output (a convex combination of v rows that already fit their scale) cannot clamp and reports non-finite values only
 };

@@ -540,9 +540,8 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, bufs = self._workspace(B, gh, gw)
         call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
         ntok, fi = 1 + a.registers + gh * gw, {"query": 0, "key": 1, "value": 2}[self.facet]
-        if self.precision in ("f16x3", "f16f8"):  # split rows (scale FP_SPLIT_SCALE_QKV) -> fp32; f16f8: q and k are f16f8 rows, v a split-fp16 row
-            unpack = ops.splitx_unpack if (self.precision == "f16f8" and fi < 2) else ops.split16_unpack
-            f = unpack(bufs[3][:B * ntok, fi * 2 * a.dim:(fi + 1) * 2 * a.dim].contiguous(), _lib.SPLIT_SCALE_QKV)
+        if self.precision in ("f16x3", "f16f8"):  # q | k | v are split-fp16 rows in both modes (hi + lo halves, scale FP_SPLIT_SCALE_QKV) -> fp32
+            f = ops.split16_unpack(bufs[3][:B * ntok, fi * 2 * a.dim:(fi + 1) * 2 * a.dim].contiguous(), _lib.SPLIT_SCALE_QKV)
         else:
             f = bufs[3][:B * ntok, fi * a.dim:(fi + 1) * a.dim].float()
         f = f.reshape(B, ntok, a.heads, a.head_dim).permute(0, 1, 3, 2).reshape(B, ntok, a.dim)

@@ -297,10 +297,9 @@ def split16_unpack(xs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
 
 
 def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: float, gamma=None, out=None, epilogue: int = 0,
-               out_scale: float = 1.0, m_valid: Optional[int] = None, tile: int = 0, f16f8: bool = False, qk_cols: int = 0) -> torch.Tensor:
+               out_scale: float = 1.0, m_valid: Optional[int] = None, tile: int = 0, f16f8: bool = False) -> torch.Tensor:
     """a [M, 2K], w [N, 2K] split rows (fp16); -> epilogue 0 / 1 / 6: split rows [M, 2N] (6: [M, N]) scaled by out_scale; 3 / 5: fp32 [M, N].
-    f16f8: a and w (and the output of epilogues 1 / 6) are f16f8 rows (splitx_pack); the output of epilogue 0 is a split-fp16 row except for its
-    first qk_cols columns (a multiple of 256: q | k of a qkv GEMM), which leave as f16f8 rows."""
+    f16f8: a and w (and the output of epilogues 1 / 6) are f16f8 rows (splitx_pack); the output of epilogue 0 stays a split-fp16 row."""
     require_cuda(a, w, bias)
     if a.dtype != torch.float16 or w.dtype != torch.float16:
         raise ValueError("gemm_split operands are fp16 split rows")
@@ -312,16 +311,15 @@ def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: 
         else:
             out = torch.zeros(M, N if epilogue == 6 else 2 * N, dtype=torch.float16, device=a.device)
     call("fp_gemm_split", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(gamma),
-         ptr(out), out.stride(0), epilogue | (tile << 8) | (_lib.GEMM_SPLIT_F16F8 if f16f8 else 0) | ((qk_cols // 256) << 21), float(acc_scale), float(out_scale), stream())
+         ptr(out), out.stride(0), epilogue | (tile << 8) | (_lib.GEMM_SPLIT_F16F8 if f16f8 else 0), float(acc_scale), float(out_scale), stream())
     return out
 
 
-def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float, f16f8_out: bool = False,
-                    f16f8_qk: bool = False) -> torch.Tensor:
-    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows).  f16f8_qk: q and k are f16f8 rows, v split-fp16."""
+def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float, f16f8_out: bool = False) -> torch.Tensor:
+    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows)."""
     require_cuda(qkv)
     out = torch.zeros(qkv.shape[0], 2 * dim, dtype=torch.float16, device=qkv.device)
-    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, -float(in_scale) if f16f8_qk else float(in_scale),
+    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale),
          -float(out_scale) if f16f8_out else float(out_scale), stream())
     return out
 

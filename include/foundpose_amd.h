@@ -49,11 +49,9 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4 }; /* ele
  * Storage: a logical row of K values (K % 64 == 0) is 4K bytes; group g = k / 64 holds  bytes [256g, 256g + 128): hi = f16(s x) (64 halves);
  * [256g + 128, 256g + 192): e4m3(hi 2^-7); [256g + 192, 256g + 256): e4m3((s x - hi) 2^4).  Same scales s and saturation report as the
  * split-fp16 rows.  A product carries ~14 mantissa bits at the worst (measured on fc2, K = 4096: max error 1.3e-5 of the output scale
- * against 1.9e-6 for f16x3); fp_vit_forward with weight_dtype FP_F16F8 uses these rows for every GEMM operand and for q and k (the
- * attention's K Q^T: four fp16 + two fp8 MFMAs per 32 keys); v, the probabilities and P V stay split-fp16 (three fp16 MFMAs). */
+ * against 1.9e-6 for f16x3); fp_vit_forward with weight_dtype FP_F16F8 uses these rows for every GEMM operand, while q | k | v and the
+ * attention's own products stay split-fp16 (three fp16 MFMAs). */
 #define FP_GEMM_SPLIT_F16F8 (1 << 20) /* OR-ed into fp_gemm_split's `epilogue`: A, W (and a GELU / SwiGLU output) are f16f8 rows, K % 64 == 0 */
-#define FP_GEMM_SPLIT_QK_COLS(n) (((n) / 256) << 21) /* ... with epilogue 0: the first n (a multiple of 256) output columns leave as f16f8 rows (q | k of a qkv
-                                                        GEMM for fp_attention_split with a negative in_scale), the others as split-fp16 rows (v) */
 
 #define FP_ABI_VERSION 15
 int fp_abi_version(void);
@@ -386,8 +384,7 @@ int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, in
 int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
 /* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, scale in_scale) -> out [B*N, 2D] halves (scale out_scale).
- * A NEGATIVE out_scale writes the output as an f16f8 row scaled by |out_scale| (the f16f8 mode's proj operand); a NEGATIVE in_scale says q and k
- * are f16f8 rows (scale |in_scale|; v stays split-fp16): K Q^T then runs its two cross terms on the fp8 MFMA. */
+ * A NEGATIVE out_scale writes the output as an f16f8 row scaled by |out_scale| (the f16f8 mode's proj operand). */
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
                        fp_stream_t stream);
 /* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes), FP_F16X3 (split row of y * out_scale) or FP_F16F8 (f16f8 row) */

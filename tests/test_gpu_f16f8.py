@@ -118,8 +118,8 @@ def test_gemm_f16f8_epilogues(tile):
 
 @pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 4), (2, 257, 3)])
 def test_attention_split_f16f8_output_rows(B, N, heads):
-    """With split-fp16 q / k / v the attention kernel's products are the three-fp16-MFMA ones; only its OUTPUT row format differs: the f16f8 output is
-    the host packing of the values the split-fp16 output carries."""
+    """The attention kernel's products are unchanged (three fp16 MFMAs); only its OUTPUT row format differs: the f16f8 output is the host packing of
+    the values the split-fp16 output carries."""
     D = heads * 64
     g = torch.Generator(device="cuda").manual_seed(N + heads)
     qkv = torch.randn(B * N, 3 * D, generator=g, device="cuda") * 1.5
@@ -189,49 +189,3 @@ def test_f16f8_saturation_and_nan_are_loud():
 # Through the engine: tests/test_gpu_parity_e2e.py::test_token_selection_changes_nothing_end_to_end[f16f8] (the hooked block on the sampled tokens only ==
 # on every token, tensor for tensor) and ::test_benchmarked_mode_vs_oracle_a_and_fp32_mode (configs 2 and 3: planted templates in order for every
 # detection, index agreement with oracle A and with the fp32 mode held to the measured rate); bench.py times the mode as `parity_mode_fast`.
-
-
-def _ref_attention(q, k, v, B, N, heads):
-    D = q.shape[1]
-    sh = lambda t: t.reshape(B, N, heads, 64).permute(0, 2, 1, 3)
-    p = torch.softmax(sh(q) @ sh(k).transpose(-1, -2) * 0.125, dim=-1)
-    return (p @ sh(v)).permute(0, 2, 1, 3).reshape(B * N, D)
-
-
-@pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 4), (3, 905, 2), (1, 256, 1), (2, 257, 3), (1, 64, 16)])
-def test_attention_with_f16f8_q_and_k_rows_vs_fp64(B, N, heads):
-    """q and k as f16f8 rows (K Q^T = four fp16 + two fp8 MFMAs per 32 keys), v split-fp16: against the fp64 attention of the same fp32 operands and
-    against the all-split-fp16 kernel."""
-    D = heads * 64
-    g = torch.Generator(device="cuda").manual_seed(N + heads)
-    qkv = torch.randn(B * N, 3 * D, generator=g, device="cuda") * 1.5
-    qkv[:, 5] *= 6.0   # a dominant q dimension: peaked softmax rows
-    parts = [qkv[:, i * D:(i + 1) * D].contiguous() for i in range(3)]
-    pk3 = torch.cat([ops.split16_pack(p, 16.0) for p in parts], dim=1)
-    pk8 = torch.cat([ops.splitx_pack(parts[0], 16.0), ops.splitx_pack(parts[1], 16.0), ops.split16_pack(parts[2], 16.0)], dim=1)
-    ref = _ref_attention(parts[0].double(), parts[1].double(), parts[2].double(), B, N, heads)
-    o3 = ops.split16_unpack(ops.attention_split(pk3, B, N, D, heads, 16.0, 16.0), 16.0)
-    o8 = ops.split16_unpack(ops.attention_split(pk8, B, N, D, heads, 16.0, 16.0, f16f8_qk=True), 16.0)
-    e3, e8 = rel_err(o3, ref), rel_err(o8, ref)
-    check_bar(f"f16f8_attention_{B}x{N}x{heads}/vs_fp64", e8, 2e-4)
-    print(f"\nattention {B}x{N}x{heads}: f16f8 q/k {e8:.2e}, split-fp16 {e3:.2e}")
-    assert e8 < 2e-4
-
-
-def test_qkv_gemm_writes_q_and_k_as_f16f8_rows_and_v_as_split_rows():
-    g = torch.Generator(device="cuda").manual_seed(11)
-    M, D = 512, 256
-    a = torch.randn(M, D, generator=g, device="cuda")
-    w = torch.randn(3 * D, D, generator=g, device="cuda") * 0.05
-    bias = torch.randn(3 * D, generator=g, device="cuda") * 0.3
-    sa, sw = 128.0, ops.pow2_scale(w)
-    lin = (a.double() @ w.double().T + bias.double()).float()
-    for tile in (128, 256):
-        o = ops.gemm_split(ops.splitx_pack(a, sa), ops.splitx_pack(w, sw), bias, 1.0 / (sa * sw), epilogue=0, out_scale=16.0, tile=tile, f16f8=True, qk_cols=2 * D)
-        q, k, v = (o[:, i * 2 * D:(i + 1) * 2 * D].contiguous() for i in range(3))
-        assert rel_err(ops.splitx_unpack(q, 16.0), lin[:, :D]) < 2.0 ** -12 and rel_err(ops.splitx_unpack(k, 16.0), lin[:, D:2 * D]) < 2.0 ** -12
-        assert rel_err(ops.split16_unpack(v, 16.0), lin[:, 2 * D:]) < 1e-4
-        # the q part is the host packing of the values its fp16 high halves came from
-        by = q.view(torch.uint8).unflatten(1, (D // 64, 256))
-        hi = by[:, :, :128].contiguous().view(torch.float16)
-        assert torch.equal(by[:, :, 128:192].contiguous(), (hi.float() * 2.0 ** -7).clamp(-448, 448).to(torch.float8_e4m3fn).view(torch.uint8))
