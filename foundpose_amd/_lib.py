@@ -74,7 +74,7 @@ _PROTOS = {
     "fp_gemm_fp8": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, vp],
     "fp_quantize_fp8": [vp, i32, i64, f32, vp, vp],
     "fp_gemm_split": [vp, i32, vp, i32, i32, i32, i32, i32, vp, vp, vp, i32, i32, f32, f32, vp],
-    "fp_attention_split": [vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, vp],
+    "fp_attention_split": [vp, i32, vp, i32, i32, i32, i32, i32, f32, f32, i32, vp],
     "fp_layernorm_scaled": [vp, i32, vp, vp, f32, vp, i32, i32, f32, i32, i32, vp],
     "fp_gemm_f32": [vp, i32, vp, i32, i32, i32, i32, vp, vp, vp, i32, i32, vp],
     "fp_attention": [vp, i32, vp, i32, i32, i32, i32, i32, i32, vp],

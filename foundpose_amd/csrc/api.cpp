@@ -394,13 +394,15 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
 }
 
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
-                       fp_stream_t stream) {
+                       int out_dtype, fp_stream_t stream) {
   FP_REQUIRE(qkv && out, "fp_attention_split: null pointer");
+  FP_REQUIRE(out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8, "fp_attention_split: the output is a split-fp16 row (FP_F16X3) or an f16f8 row (FP_F16F8)");
+  FP_REQUIRE(in_scale > 0.f && out_scale > 0.f, "fp_attention_split: scales must be positive");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
-  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = fabsf(out_scale);
-  a.out_fmt = out_scale < 0.f ? 1 : 0;   // a NEGATIVE out_scale asks for an f16f8 output row (scaled by its magnitude)
+  a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = out_scale;
+  a.out_fmt = out_dtype == FP_DTYPE_F16F8 ? 1 : 0;
   return attn_launch(a, FP_DTYPE_F16X3, ST(stream));
 }
 

@@ -319,8 +319,8 @@ def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: 
     """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows)."""
     require_cuda(qkv)
     out = torch.zeros(qkv.shape[0], 2 * dim, dtype=torch.float16, device=qkv.device)
-    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale),
-         -float(out_scale) if f16f8_out else float(out_scale), stream())
+    call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale), float(out_scale),
+         _lib.FP_F16F8 if f16f8_out else _lib.FP_F16X3, stream())
     return out
 
 

@@ -383,10 +383,10 @@ int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, in
  * halves, values x out_scale, ldo in halves); 3 (out += gamma v) and 5 (bias) write fp32. */
 int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
-/* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, scale in_scale) -> out [B*N, 2D] halves (scale out_scale).
- * A NEGATIVE out_scale writes the output as an f16f8 row scaled by |out_scale| (the f16f8 mode's proj operand). */
+/* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, split-fp16 rows of scale in_scale) -> out [B*N, 2D] halves (scale out_scale);
+ * out_dtype FP_F16X3: a split-fp16 row, FP_F16F8: an f16f8 row (the f16f8 mode's proj operand). */
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
-                       fp_stream_t stream);
+                       int out_dtype, fp_stream_t stream);
 /* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes), FP_F16X3 (split row of y * out_scale) or FP_F16F8 (f16f8 row) */
 int fp_layernorm_scaled(const float* x, int ld_x, const float* weight, const float* bias, float eps, void* out, int ld_out, int out_dtype, float out_scale,
                         int dim, int out_rows, fp_stream_t stream);

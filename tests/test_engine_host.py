@@ -55,3 +55,29 @@ def test_activation_rows_are_padded_to_whole_tiles_of_both_heights():
     assert f32.padded_rows(32 * 1374) == 44032                                              # no taller tile in the fp32 mode
     plain = feature_util.make_feature_extractor(name, random_init_seed=1, precision="bf16", fold_layernorm=False)
     assert plain.padded_rows(32 * 1374) == 44032
+
+
+def test_f16f8_row_packing_host_side():
+    """ops.splitx_pack / splitx_unpack (host-side preparation of the f16f8 mode's weights, include/foundpose_amd.h "f16f8 rows"): layout and what a row
+    represents, on CPU tensors -- the device producers write the same bytes (tests/test_gpu_f16f8.py)."""
+    from foundpose_amd import ops
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(6, 192, generator=g) * torch.logspace(-1, 2, 192)[None, :]
+    s = 8.0
+    p = ops.splitx_pack(x, s)
+    assert p.shape == (6, 384) and p.dtype == torch.float16
+    by = p.view(torch.uint8).unflatten(1, (3, 256))
+    hi = (x * s).half()
+    assert torch.equal(by[:, :, :128].contiguous().view(torch.float16).reshape(6, 192), hi)
+    assert torch.equal(by[:, :, 128:192].reshape(6, 192), (hi.float() * 2.0 ** -7).to(torch.float8_e4m3fn).view(torch.uint8))
+    assert torch.equal(by[:, :, 192:256].reshape(6, 192), ((x * s - hi.float()) * 16.0).to(torch.float8_e4m3fn).view(torch.uint8))
+    back = ops.splitx_unpack(p, s)
+    big = x.abs() * s > 1.0
+    assert float(((back - x).abs() / x.abs())[big].max()) < 2.0 ** -14
+    padded = ops.splitx_pack(x, s, pad=64)
+    assert padded.stride(0) == 384 + 64 and torch.equal(padded.contiguous(), p)
+    with pytest.raises(ValueError):
+        ops.splitx_pack(x[:, :96], s)
+    # values beyond the fp16 range saturate in the high half and in its e4m3 copy (the device reports them: saturation counters)
+    sat = ops.splitx_pack(torch.full((1, 64), 1.0e6), 1.0)
+    assert float(sat[0, 0]) == 65504.0 and int(sat.view(torch.uint8)[0, 128]) == int(torch.tensor(448.0).to(torch.float8_e4m3fn).view(torch.uint8))
