@@ -752,7 +752,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
         mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
       }
       // lazy rescale, per query (attn_bf16_w64_kernel): here the reference may trail the maximum by at most 1 in the exponent --
-      // p <= 2, and 2 * SPLIT_P_SCALE = 2^15 still splits into fp16 (max 65504)
+      // p <= 2, and 2 * SPLIT_P_SCALE = 2^15 still splits into fp16 (max 65504): the split below needs no clamp (split16_pack2_inrange)
       const bool moves = mx - m_run > SPLIT_LAZY_TH;
       const bool grow = __any(moves);
       float alpha = 1.f;
@@ -776,10 +776,10 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
         for (int kk = 0; kk < 2; ++kk) {
           const int r0 = 8 * kk;
           unsigned a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l;
-          split16_pack2(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
-          split16_pack2(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
-          split16_pack2(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
-          split16_pack2(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
+          split16_pack2_inrange(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
+          split16_pack2_inrange(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
+          split16_pack2_inrange(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
+          split16_pack2_inrange(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
           auto h0 = __builtin_amdgcn_permlane32_swap(a0h, b0h, false, false);
           auto h1 = __builtin_amdgcn_permlane32_swap(a1h, b1h, false, false);
           auto l0 = __builtin_amdgcn_permlane32_swap(a0l, b0l, false, false);

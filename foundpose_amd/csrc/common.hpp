@@ -89,6 +89,16 @@ FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsign
   hi = __builtin_bit_cast(unsigned, h);
   lo = __builtin_bit_cast(unsigned, l);
 }
+// ... for values known to fit (|s x| <= 65504: the attention's probabilities, p <= 2 at scale 2^14): the same bits without the two clamps
+FP_DEVICE void split16_pack2_inrange(float a, float b, float scale, unsigned& hi, unsigned& lo) {
+  a *= scale;
+  b *= scale;
+  const f16x2 h = __builtin_convertvector(f32x2{a, b}, f16x2);
+  const f32x2 hf = __builtin_convertvector(h, f32x2);
+  const f16x2 l = __builtin_convertvector(f32x2{a - hf[0], b - hf[1]}, f16x2);
+  hi = __builtin_bit_cast(unsigned, h);
+  lo = __builtin_bit_cast(unsigned, l);
+}
 // ... and the running maximum of |s x| the caller reports at the end of the kernel (report_saturation)
 FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsigned& lo, float& amax) {
   amax = nanmax3(amax, fabsf(a * scale), fabsf(b * scale));  // v_maximum3_f32 with |.| modifiers
