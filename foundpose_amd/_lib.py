@@ -168,3 +168,14 @@ def require_cuda(*tensors) -> None:
         if t is not None and not t.is_cuda:
             raise FoundPoseNativeError(
                 "foundpose_amd runs on the MI355X only: got a CPU tensor (move inputs to 'cuda'; no CPU fallback exists)")
+
+
+def upload_async(host: torch.Tensor, device) -> torch.Tensor:
+    """A small host table -> device through pinned staging, asynchronously on the current stream.  A pageable upload (torch.tensor(..., device=),
+    .to(device) of a pageable tensor) blocks the host until everything queued on the stream before it has drained -- a whole batch of the backbone --
+    and the launches behind it then reach an idle GPU one launch latency at a time; the caching host allocator keeps the pinned block alive
+    until the copy has run."""
+    host = host.contiguous()
+    staged = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
+    staged.copy_(host)
+    return staged.to(device, non_blocking=True)

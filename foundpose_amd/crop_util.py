@@ -19,7 +19,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import call, ptr, require_cuda, stream
+from ._lib import call, ptr, require_cuda, stream, upload_async
 
 INTER_NEAREST, INTER_LINEAR, INTER_AREA = 0, 1, 3
 
@@ -136,7 +136,7 @@ def _warp(src: torch.Tensor, mode: int, src_index: Optional[torch.Tensor], param
     require_cuda(src)
     B = params.shape[0]
     H, W = out_hw
-    p = torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64)).to(src.device)
+    p = upload_async(torch.from_numpy(np.ascontiguousarray(params, dtype=np.float64)), src.device)   # pinned + asynchronous: the host goes on to the next image while this batch runs
     if mode == INTER_NEAREST:
         if src.dtype != torch.uint8 or src.dim() != 3:
             raise ValueError("nearest-mode source must be uint8 [n, H, W]")
@@ -149,7 +149,7 @@ def _warp(src: torch.Tensor, mode: int, src_index: Optional[torch.Tensor], param
         out = torch.empty(B, ch, H, W, dtype=torch.float32, device=src.device)
     src = src.contiguous()
     maps = torch.empty(B, 2, H, W, dtype=torch.float32, device=src.device) if want_maps else None
-    idx = None if src_index is None else src_index.to(device=src.device, dtype=torch.int32).contiguous()
+    idx = None if src_index is None else (src_index.to(torch.int32).contiguous() if src_index.is_cuda else upload_async(src_index.to(torch.int32), src.device))
     call("fp_warp_crops", ptr(src), n, sh, sw, ch, 1 if mode == INTER_NEAREST else 0, ptr(idx), ptr(p), B, H, W,
          1 if depth_check else 0, ptr(out), ptr(maps), stream())
     return (out, maps) if want_maps else out

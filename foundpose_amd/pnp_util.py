@@ -14,7 +14,7 @@ from typing import Any, Dict, List, Optional, Sequence, Tuple
 import numpy as np
 import torch
 
-from ._lib import call, ptr, stream, require_cuda
+from ._lib import call, ptr, stream, require_cuda, upload_async
 from .matching import MatchResult
 
 MIN_CORRESP = 6  # scripts/infer.py:555-559
@@ -49,7 +49,7 @@ def solve_pnp_ransac_batch(coord_2d: torch.Tensor, coord_3d: torch.Tensor, count
     dev = coord_2d.device
     if len(cameras) != B:
         raise ValueError(f"{len(cameras)} cameras for {B} detections")
-    cam = torch.tensor([_intrinsics(c) for c in cameras], dtype=torch.float64, device=dev).reshape(B, 4)
+    cam = upload_async(torch.tensor([_intrinsics(c) for c in cameras], dtype=torch.float64).reshape(B, 4), dev)   # (a pageable upload would block until the batch has drained)
     c2, c3 = coord_2d.float().contiguous(), coord_3d.float().contiguous()
     cnt = counts.to(torch.int32).contiguous()
     P = B * n
