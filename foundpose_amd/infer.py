@@ -79,14 +79,15 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         raise ValueError(f"Unknown feature matching type ({opts.match_feat_matching_type}).")
     if opts.final_pose_type != "best_coarse":
         raise ValueError(f"Unknown final pose type {opts.final_pose_type}")
-    if not opts.crop:
-        raise NotImplementedError("crop=False (whole-image extraction) is not on the batched path")
     # scripts/infer.py:482-485 subsamples the query points with torch.randperm when a mask yields more than max_num_queries of them
     # (default 1 000 000: never for a crop).  The batched path keeps every point; an option value that could trigger the subsampling
-    # is refused instead of being ignored.
-    max_points = int(opts.crop_size[0] // opts.grid_cell_size) * int(opts.crop_size[1] // opts.grid_cell_size)
-    if opts.max_num_queries < max_points:
-        raise NotImplementedError(f"max_num_queries={opts.max_num_queries} could subsample the {max_points} grid points of a crop: not on the batched path")
+    # is refused instead of being ignored (crop=False: checked per frame against the image's own grid).
+    def check_max_queries(size_wh):
+        max_points = int(size_wh[0] // opts.grid_cell_size) * int(size_wh[1] // opts.grid_cell_size)
+        if opts.max_num_queries < max_points:
+            raise NotImplementedError(f"max_num_queries={opts.max_num_queries} could subsample the {max_points} grid points of a {size_wh[0]}x{size_wh[1]} input: not on the batched path")
+    if opts.crop:
+        check_max_queries(opts.crop_size)
     if extractor is None:  # infer.py:125-128; the checkpoint: weights=, $FOUNDPOSE_DINOV2_WEIGHTS or the torch hub cache, else this raises
         extractor = feature_util.make_feature_extractor(opts.extractor_name, precision=precision, weights=weights).to("cuda")
     bank = DeviceBank([repre])
@@ -133,7 +134,18 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         img = (img.to("cuda", torch.float32) / 255.0) if img.dtype == torch.uint8 else img.to("cuda", torch.float32)
         masks = torch.from_numpy(np.stack([i["input_mask_modal"] for _, i in kept]).astype(np.uint8)).cuda()
         boxes = [i["input_box_amodal"].tolist() for _, i in kept]
-        crops, crop_masks, cams = crop_util.crop_detections(img, masks, boxes, cam, tuple(opts.crop_size), opts.crop_rel_pad)
+        if opts.crop:
+            crops, crop_masks, cams = crop_util.crop_detections(img, masks, boxes, cam, tuple(opts.crop_size), opts.crop_rel_pad)
+        else:
+            # crop=False (infer.py:355-357, 411-416): the whole image and the modal mask of every instance go to the extractor unchanged, the
+            # original camera stays the camera the poses are solved in.  The image must tile into patches -- the backbone's patch embedding
+            # asserts it in the reference as well (every instance then shares one feature map; it is computed per instance here, like there).
+            ps = extractor.patch_size
+            if img.shape[0] % ps or img.shape[1] % ps:
+                raise AssertionError(f"Input image height {img.shape[0]} / width {img.shape[1]} is not a multiple of patch size {ps} (crop=False)")
+            check_max_queries((cam.width, cam.height))
+            crops = img.permute(2, 0, 1)[None].expand(len(kept), -1, -1, -1).contiguous()
+            crop_masks, cams = masks, [cam] * len(kept)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         res = eng.infer_batch(crops, crop_masks, [0] * len(kept))

@@ -56,11 +56,11 @@ def test_bank_builder_entry_points_refuse_cpu_tensors_and_bad_names():
 
 
 def test_infer_driver_refuses_options_it_would_otherwise_ignore():
-    """scripts/infer.py options the batched path does not implement are refused before any GPU work: whole-image extraction, a
-    max_num_queries that could trigger the reference's random subsampling (infer.py:482-485), unknown matching / pose types."""
+    """scripts/infer.py options the batched path does not implement are refused before any GPU work: a max_num_queries that could trigger the
+    reference's random subsampling (infer.py:482-485), unknown matching / pose types.  (crop=False runs: tests/test_gpu_infer_driver.py.)"""
     from foundpose_amd import infer
     base = dict(version="v", repre_version="r", object_dataset="lmo")
-    for bad, exc in ((dict(crop=False), NotImplementedError), (dict(max_num_queries=500), NotImplementedError),
+    for bad, exc in ((dict(max_num_queries=500), NotImplementedError),
                      (dict(match_template_type="sift"), ValueError), (dict(match_feat_matching_type="1nn"), ValueError),
                      (dict(final_pose_type="refined"), ValueError)):
         with pytest.raises(exc):

@@ -183,3 +183,64 @@ def test_cli_loads_an_upstream_layout_checkpoint_file(tmp_path):
     p = tmp_path / "out_other" / "1" / "estimated-poses.json"
     other = json.load(open(p)) if p.exists() else []
     assert [(e["R"], e["score"]) for e in other] != [(e["R"], e["score"]) for e in want]
+
+
+def test_infer_driver_without_cropping(tmp_path):
+    """crop=False (scripts/infer.py:355-357, 411-416): the whole image and each instance's modal mask go to the extractor as they are, the grid
+    covers the image, the original camera is the one the poses are solved in.  Planted like the cropped scene: the bank holds the image's own
+    features under each instance's mask as templates 2 and 5, their vertices come from known poses in the ORIGINAL camera."""
+    g = torch.Generator().manual_seed(1)
+    H, W = 224, 336          # multiples of the patch size, as the backbone's patch embedding demands of an uncropped input
+    image = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8).numpy()
+    cam = crop_util.PinholePlaneCameraModel(W, H, (400.0, 410.0), (168.0, 110.0), np.eye(4))
+    boxes_xywh = [[20, 30, 150, 160], [180, 20, 140, 180]]
+    masks = np.zeros((2, H, W), np.uint8)
+    for b, (x, y, w, h) in enumerate(boxes_xywh):
+        masks[b, y + 6:y + h - 6, x + 6:x + w - 6] = 1
+    dets = [{"scene_id": 2, "image_id": 7, "category_id": 1, "bbox": boxes_xywh[b], "score": 0.9 - 0.1 * b, "time": 0.1,
+             "segmentation": infer_pose_util.binary_mask_to_rle(masks[b])} for b in range(2)]
+    det_path = tmp_path / "cnos.json"
+    det_path.write_text(json.dumps(dets))
+    opts = infer.load_opts({"infer_opts": {
+        "version": "v1", "object_dataset": "synth", "repre_version": "v1", "object_lids": [1], "crop": False, "use_detections": True,
+        "extractor_name": NAME, "grid_cell_size": 14.0, "match_top_n_templates": 5, "match_top_k_buddies": 300, "pnp_ransac_iter": 400,
+        "pnp_inlier_thresh": 10.0, "num_preds_factor": 2, "vis_results": False}})
+    ex = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision="fp32").to("cuda")
+    img_f = torch.from_numpy(image).cuda().float() / 255.0
+    T = 9
+    tpl = torch.rand(T, 3, H, W, generator=g).cuda()
+    tmask = torch.zeros(T, H, W, dtype=torch.uint8).cuda()
+    tmask[:, 40:180, 60:300] = 1
+    slots = [2, 5]
+    for b, s in enumerate(slots):
+        tpl[s], tmask[s] = img_f.permute(2, 0, 1), torch.from_numpy(masks[b]).cuda()
+    feats, f2t, pts = bank_builder.extract_template_features(ex, tpl, tmask)
+    verts = torch.randn(feats.shape[0], 3, generator=g).cuda() * 50.0
+    R = workload._random_rotations(2, g)
+    t = torch.tensor([[5.0, -12.0, 800.0], [-20.0, 9.0, 950.0]], dtype=torch.float64)
+    K = torch.tensor([[cam.f[0], 0, cam.c[0]], [0, cam.f[1], cam.c[1]], [0, 0, 1.0]], dtype=torch.float64)
+    for b, s in enumerate(slots):
+        rows = f2t == s
+        verts[rows] = workload.planted_vertices(pts[rows], K, R[b], t[b]).cuda()
+    repre = bank_builder.build_object_repre(feats, f2t, verts, T, pca_components=128, cluster_num=64, cluster_iters=10)
+    frames = lambda lid: iter([{"scene_id": 2, "im_id": 7, "image": image, "camera": cam}])
+    out_dir = str(tmp_path / "inference")
+    infer.infer(opts, frames, infer_pose_util.load_detections_in_bop_format(str(det_path)), {1: repre}, out_dir, extractor=ex, num_target_insts={1: {(2, 7): 1}})
+    est = json.load(open(os.path.join(out_dir, "1", "estimated-poses.json")))
+    assert len(est) == 2
+    for e in est:
+        b = int(e["inst_id"])
+        assert np.abs(np.array(e["R"]) - R[b].numpy()).max() < 1e-4
+        assert np.linalg.norm(np.array(e["t"]).ravel() - t[b].numpy()) / np.linalg.norm(t[b].numpy()) < 1e-4
+    # an image that does not tile into patches is refused, like the backbone's patch embedding refuses it in the reference
+    H2 = 230
+    masks2 = np.zeros((2, H2, W), np.uint8)
+    masks2[:, 40:200, 30:150] = 1
+    dets2 = [{"scene_id": 2, "image_id": 7, "category_id": 1, "bbox": [30, 40, 120, 160], "score": 0.9, "time": 0.1,
+              "segmentation": infer_pose_util.binary_mask_to_rle(masks2[0])}]
+    (tmp_path / "cnos2.json").write_text(json.dumps(dets2))
+    cam2 = crop_util.PinholePlaneCameraModel(W, H2, (400.0, 410.0), (168.0, 110.0), np.eye(4))
+    frames2 = lambda lid: iter([{"scene_id": 2, "im_id": 7, "image": np.zeros((H2, W, 3), np.uint8), "camera": cam2}])
+    with pytest.raises(AssertionError, match="not a multiple of patch size"):
+        infer.infer(opts, frames2, infer_pose_util.load_detections_in_bop_format(str(tmp_path / "cnos2.json")), {1: repre}, str(tmp_path / "bad"), extractor=ex,
+                    num_target_insts={1: {(2, 7): 1}})
