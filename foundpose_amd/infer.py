@@ -130,7 +130,10 @@ def infer_object(opts: InferOpts, object_lid: int, repre: repre_util.FeatureBase
         if not kept:
             continue
         t0 = time.perf_counter()
-        img = torch.as_tensor(np.asarray(frame["image"]) if not isinstance(frame["image"], torch.Tensor) else frame["image"])
+        img = frame["image"]
+        if not isinstance(img, torch.Tensor):
+            arr = np.asarray(img)
+            img = torch.from_numpy(arr if arr.flags.writeable else arr.copy())   # (PIL hands out read-only arrays)
         img = (img.to("cuda", torch.float32) / 255.0) if img.dtype == torch.uint8 else img.to("cuda", torch.float32)
         masks = torch.from_numpy(np.stack([i["input_mask_modal"] for _, i in kept]).astype(np.uint8)).cuda()
         boxes = [i["input_box_amodal"].tolist() for _, i in kept]
