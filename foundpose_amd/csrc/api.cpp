@@ -396,10 +396,14 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
                        int out_dtype, fp_stream_t stream) {
   FP_REQUIRE(qkv && out, "fp_attention_split: null pointer");
+  const int variant = (out_dtype >> 8) & 0xff;  // test bits, as in fp_attention: 0 = the default kernel, 1 = the lock-step kernel, 2 = the role-split kernel (bit-identical)
+  out_dtype &= 0xff;
   FP_REQUIRE(out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8, "fp_attention_split: the output is a split-fp16 row (FP_F16X3) or an f16f8 row (FP_F16F8)");
+  FP_REQUIRE(variant <= 2, "fp_attention_split: unknown kernel variant %d", variant);
   FP_REQUIRE(in_scale > 0.f && out_scale > 0.f, "fp_attention_split: scales must be positive");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
+  a.variant = variant;
   a.qkv = qkv; a.ld_qkv = ld_qkv; a.out = out; a.ld_out = ld_out;
   a.batch = B; a.n_tok = n_tok; a.dim = dim; a.heads = heads; a.in_scale = in_scale; a.out_scale = out_scale;
   a.out_fmt = out_dtype == FP_DTYPE_F16F8 ? 1 : 0;

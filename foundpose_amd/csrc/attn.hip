@@ -613,6 +613,66 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 constexpr float SPLIT_P_SCALE = 16384.f;
 constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);  // 1 in the exponent, in score units
 
+// Epilogue of the split-fp16 attention kernels: O = sum(P v) / l without the scales of P and v, written as a split-fp16 row or an f16f8 row.
+FP_DEVICE void split_attn_store(const AttnArgs& a, const f32x16 (&oacc)[2], float l_run, int q0, int l31, int kh, int NQ, int sel_base, int img, int N, int head) {
+  const int q = q0 + l31;
+  const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+  const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
+  // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
+  const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
+  _Float16* o = reinterpret_cast<_Float16*>(a.out) + orow * a.ld_out + head * 128;
+  // a convex combination of v rows that fit their scale cannot clamp -- but a NaN / Inf born inside the attention (an overflowing score)
+  // would leave the v_med3 of the packing as a finite operand: the NaN-propagating running maximum is what reports it
+  float o_amax = 0.f;
+  if (a.out_fmt == 1) {
+    // f16f8 row (common.hpp): a head's 64 output dims are one 64-column group -- fp16 high halves (128 B), then e4m3(hi) and e4m3(lo) (64 B
+    // each).  Same lane exchange as below; the word that travels in the lo slot is [hi8_a, hi8_b, lo8_a, lo8_b] of a column pair.
+    char* ob = reinterpret_cast<char*>(o);
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        unsigned xh0, xp0, xh1, xp1, yh0, yp0, yh1, yp1;
+        splitx_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xp0, o_amax);
+        splitx_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xp1, o_amax);
+        splitx_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yp0, o_amax);
+        splitx_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yp1, o_amax);
+        const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
+        const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
+        const auto p0 = __builtin_amdgcn_permlane32_swap(xp0, yp0, false, false);
+        const auto p1 = __builtin_amdgcn_permlane32_swap(xp1, yp1, false, false);
+        const int d = dt * 32 + 16 * j + 8 * kh;   // this lane's 8 consecutive dims
+        if (q < NQ) {
+          *reinterpret_cast<uint4*>(ob + d * 2) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+          *reinterpret_cast<uint2*>(ob + 128 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x05040100u), __builtin_amdgcn_perm(p1[1], p0[1], 0x05040100u));
+          *reinterpret_cast<uint2*>(ob + 192 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x07060302u), __builtin_amdgcn_perm(p1[1], p0[1], 0x07060302u));
+        }
+      }
+  } else {
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      unsigned xh0, xl0, xh1, xl1, yh0, yl0, yh1, yl1;
+      split16_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xl0, o_amax);
+      split16_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xl1, o_amax);
+      split16_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yl0, o_amax);
+      split16_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yl1, o_amax);
+      const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
+      const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
+      const auto l0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false);
+      const auto l1 = __builtin_amdgcn_permlane32_swap(xl1, yl1, false, false);
+      _Float16* op = o + dt * 64 + 16 * j + 8 * kh;
+      if (q < NQ) {
+        *reinterpret_cast<uint4*>(op) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
+        *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
+      }
+    }
+  }
+  if (q < NQ) report_saturation(a.sat, 0, o_amax, FP_F16_MAX);
+}
+
+
 __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][16384];  // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -831,63 +891,320 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
     else tile(nfull, std::true_type{}, std::false_type{});
   }
 
-  if (active) {
-    const int q = q0 + l31;
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-    const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
-    // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
-    const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
-    _Float16* o = reinterpret_cast<_Float16*>(a.out) + orow * a.ld_out + head * 128;
-    // a convex combination of v rows that fit their scale cannot clamp -- but a NaN / Inf born inside the attention (an overflowing score)
-    // would leave the v_med3 of the packing as a finite operand: the NaN-propagating running maximum is what reports it
-    float o_amax = 0.f;
-    if (a.out_fmt == 1) {
-      // f16f8 row (common.hpp): a head's 64 output dims are one 64-column group -- fp16 high halves (128 B), then e4m3(hi) and e4m3(lo) (64 B
-      // each).  Same lane exchange as below; the word that travels in the lo slot is [hi8_a, hi8_b, lo8_a, lo8_b] of a column pair.
-      char* ob = reinterpret_cast<char*>(o);
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          unsigned xh0, xp0, xh1, xp1, yh0, yp0, yh1, yp1;
-          splitx_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xp0, o_amax);
-          splitx_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xp1, o_amax);
-          splitx_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yp0, o_amax);
-          splitx_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yp1, o_amax);
-          const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
-          const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
-          const auto p0 = __builtin_amdgcn_permlane32_swap(xp0, yp0, false, false);
-          const auto p1 = __builtin_amdgcn_permlane32_swap(xp1, yp1, false, false);
-          const int d = dt * 32 + 16 * j + 8 * kh;   // this lane's 8 consecutive dims
-          if (q < NQ) {
-            *reinterpret_cast<uint4*>(ob + d * 2) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
-            *reinterpret_cast<uint2*>(ob + 128 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x05040100u), __builtin_amdgcn_perm(p1[1], p0[1], 0x05040100u));
-            *reinterpret_cast<uint2*>(ob + 192 + d) = make_uint2(__builtin_amdgcn_perm(p1[0], p0[0], 0x07060302u), __builtin_amdgcn_perm(p1[1], p0[1], 0x07060302u));
-          }
-        }
+  if (active) split_attn_store(a, oacc, l_run, q0, l31, kh, NQ, sel_base, img, N, head);
+}
+
+// ---------------------------------------------------------------- split-fp16, role-split ("ping-pong") form: the default of the f16x3 / f16f8 modes
+// The same arithmetic as attn_split_kernel, instruction for instruction per query (same MFMA order per accumulator, same softmax, same
+// epilogue: bit-identical outputs), on another schedule.  In the lock-step kernel the two waves a 512-thread workgroup places on each SIMD
+// (waves w and w + 4) walk S -> softmax -> P V together behind one barrier per key tile, so the SIMD's matrix pipe idles while both waves are
+// in their softmax and its VALU while both are in their MFMAs: a tile costs the SUM of the two (measured: 48 MFMAs = 1536 cycles + ~300 VALU
+// per wave and tile, 7.0 k cycles per tile for the pair).  Here the waves of a SIMD run half a tile apart:
+//   even interval 2t:   waves 0-3: P V (t-1), S(t)         [matrix pipe]      waves 4-7: softmax(t-1)               [VALU]
+//   odd interval 2t+1:  waves 0-3: softmax(t)              [VALU]             waves 4-7: P V (t-1), S(t)           [matrix pipe]
+// with a barrier at the end of every interval (the one after the even interval orders nothing in memory, it keeps the two halves in anti-phase).
+// K / V tiles travel through a ring of three slots: every wave issues its rows of K(t+2) and V(t+1) right behind its P V (t-1) -- after its last
+// transpose read of the iteration (the compiler drains vmcnt in front of the first transpose read that follows an LDS-DMA) --, the loads of
+// iteration t have landed when iteration t + 1 ends (vmcnt(4) + barrier), one iteration ahead of their first reader.
+//   slot s: [K image 16 KiB | V image 16 KiB] (layouts as in attn_split_kernel); K(t) and V(t) live in slot t % 3
+// A short last query tile hands its 32-query blocks to waves 0, 4, 1, 5, ... so that both halves of a SIMD have work.
+constexpr int SPP_SLOT = 32768, SPP_LDS = 3 * SPP_SLOT;
+#ifdef SPP_NO_MIDBAR   // (measurement build: without the barrier that holds the two halves in anti-phase)
+#define SPP_MID_BARRIER() ((void)0)
+#else
+#define SPP_MID_BARRIER() __builtin_amdgcn_s_barrier()
+#endif
+
+__global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char KVR[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, kh = lane >> 5;
+#if defined(SPP_GRP) && SPP_GRP == 1   // (measurement builds: tools/attn_split_ablate.sh)
+  const int grp = wave & 1;
+#else
+  const int grp = wave >> 2;  // 0: matrix phase in the even intervals; 1: half a tile behind
+#endif
+  int qt, head, img;
+  {
+    const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + 255) / 256, pairs = a.heads * a.batch, i = blockIdx.x;
+    int pair;
+    if ((pairs & 7) == 0) {  // as in attn_split_kernel: a pair's query tiles on one XCD, the short last tile at the end of the XCD's sequence
+      const int j = i >> 3;
+      if (a.tail_last && nqt > 1) {
+        const int nfull = (pairs >> 3) * (nqt - 1);
+        const bool tail = j >= nfull;
+        qt = tail ? nqt - 1 : j % (nqt - 1);
+        pair = (tail ? j - nfull : j / (nqt - 1)) * 8 + (i & 7);
+      } else {
+        qt = j % nqt;
+        pair = (j / nqt) * 8 + (i & 7);
+      }
     } else {
+      qt = i % nqt;
+      pair = i / nqt;
+    }
+    head = pair % a.heads;
+    img = pair / a.heads;
+  }
+  const int N = a.n_tok, D = a.dim;
+  const _Float16* qkv = reinterpret_cast<const _Float16*>(a.qkv) + (size_t)img * N * a.ld_qkv;
+  const int sel_base = a.sel_off ? a.sel_off[img] : 0;
+  const int NQ = a.sel_off ? a.sel_off[img + 1] - sel_base : N;
+  if (qt * 256 >= NQ) return;  // block-uniform, before any barrier
+#if defined(SPP_GRP) && SPP_GRP == 1
+  const int q0 = qt * 256 + wave * 32;
+#else
+  const int q0 = qt * 256 + (((wave & 3) << 1) | grp) * 32;
+#endif
+  const bool active = q0 < NQ;  // wave-uniform; an inactive wave only stages tiles and keeps the barriers
+
+  // ---- staging (attn_split_kernel's): a DMA instruction moves 4 rows x 256 B; wave w issues row groups 2w, 2w + 1 of K and of V
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, (unsigned)((size_t)N * a.ld_qkv * 2), 0x00020000);
+  const int sr = lane >> 4, sp = lane & 15;
+  const unsigned rowoff = (unsigned)(sr * a.ld_qkv) * 2u;
+  const unsigned voff_k0 = rowoff + ((unsigned)(sp ^ (4 * ((2 * wave) & 3) + sr)) << 4);
+  const unsigned voff_k1 = rowoff + ((unsigned)(sp ^ (4 * ((2 * wave + 1) & 3) + sr)) << 4);
+  const unsigned voff_v = rowoff + ((unsigned)((((sp >> 2) ^ sr) << 2) | (sp & 3)) << 4);
+  const unsigned tile_stride = (unsigned)(64 * a.ld_qkv) * 2u, grp_stride = (unsigned)(4 * a.ld_qkv) * 2u;
+  const unsigned soff_k = (unsigned)(2 * D + head * 128) * 2u + 2u * wave * grp_stride, soff_v = soff_k + (unsigned)(2 * D) * 2u;
+  auto stage_k = [&](int kt, int slot) {
+    const unsigned t = kt * tile_stride;
+    char* kd = KVR + slot * SPP_SLOT + wave * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)kd, 16, voff_k0, soff_k + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(kd + 1024), 16, voff_k1, soff_k + t + grp_stride, 0, 0);
+  };
+  auto stage_v = [&](int kt, int slot) {
+    const unsigned t = kt * tile_stride;
+    char* vd = KVR + slot * SPP_SLOT + 16384 + wave * 2048;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)vd, 16, voff_v, soff_v + t, 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void_t*)(vd + 1024), 16, voff_v, soff_v + t + grp_stride, 0, 0);
+  };
+  const int T = (N + 63) / 64;
+  stage_k(0, 0);
+  stage_v(0, 0);
+  if (T > 1) stage_k(1, 1);
+
+  const float c = 0.125f * 1.44269504088896340736f / (a.in_scale * a.in_scale);
+  f16x8 qh[4], ql[4];
+  {
+    const int q = q0 + l31;
+    int qc = q < NQ ? q : NQ - 1;
+    if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;
+    const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
 #pragma unroll
-    for (int dt = 0; dt < 2; ++dt)
+    for (int ds = 0; ds < 4; ++ds) {
+      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
+      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
+      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
+    }
+  }
+  f32x16 oacc[2], sacc[2];
+  f16x8 ph[4], pl[4];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        unsigned xh0, xl0, xh1, xl1, yh0, yl0, yh1, yl1;
-        split16_pack2(oacc[dt][8 * j + 0] * inv, oacc[dt][8 * j + 1] * inv, a.out_scale, xh0, xl0, o_amax);
-        split16_pack2(oacc[dt][8 * j + 2] * inv, oacc[dt][8 * j + 3] * inv, a.out_scale, xh1, xl1, o_amax);
-        split16_pack2(oacc[dt][8 * j + 4] * inv, oacc[dt][8 * j + 5] * inv, a.out_scale, yh0, yl0, o_amax);
-        split16_pack2(oacc[dt][8 * j + 6] * inv, oacc[dt][8 * j + 7] * inv, a.out_scale, yh1, yl1, o_amax);
-        const auto h0 = __builtin_amdgcn_permlane32_swap(xh0, yh0, false, false);
-        const auto h1 = __builtin_amdgcn_permlane32_swap(xh1, yh1, false, false);
-        const auto l0 = __builtin_amdgcn_permlane32_swap(xl0, yl0, false, false);
-        const auto l1 = __builtin_amdgcn_permlane32_swap(xl1, yl1, false, false);
-        _Float16* op = o + dt * 64 + 16 * j + 8 * kh;
-        if (q < NQ) {
-          *reinterpret_cast<uint4*>(op) = make_uint4(h0[0], h1[0], h0[1], h1[1]);
-          *reinterpret_cast<uint4*>(op + 32) = make_uint4(l0[0], l1[0], l0[1], l1[1]);
-        }
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f, sacc[i][r] = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) ph[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, pl[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  float m_run = -INFINITY, l_run = 0.f;
+  const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
+  const int vrd0 = (kh * 8 + kq) * 256 + vb * 32 + (lane & 3) * 8;
+
+  // ---- S^T(t) = K(t) Q^T from slot `slot`: sacc[ks][r] = score(query l31, key 64 t + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
+  auto s_phase = [&](int t, int slot) {
+    const char* Ks = KVR + slot * SPP_SLOT;
+#ifdef SPP_NO_MATRIX   // measurement build: no MFMAs, scores = raw LDS words (values the compiler cannot fold)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        const float4 w = *reinterpret_cast<const float4*>(Ks + (ks * 32 + l31) * 256 + kh * 64 + r * 4);
+        sacc[ks][r] = w.x * 1e-30f; sacc[ks][r + 1] = w.y * 1e-30f; sacc[ks][r + 2] = w.z * 1e-30f; sacc[ks][r + 3] = w.w * 1e-30f;
+      }
+    return;
+#endif
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;
+      f16x8 kfh[2], kfl[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int row = ks * 32 + l31;
+        const char* kr = Ks + row * 256;
+        kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
+        kfl[ks] = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
+      }
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
+    }
+    if (t == T - 1 && (N & 63)) {  // the ragged last tile: mask the padded keys (their K rows are the DMA's out-of-range zeros)
+      const int lim = N - t * 64 - 4 * kh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
+    }
+  };
+  // ---- online softmax of the scores in sacc (fp32; attn_split_kernel's arithmetic): P leaves as the split pairs (ph, pl)
+  auto softmax_phase = [&]() {
+#ifdef SPP_NO_SOFTMAX   // measurement build: the matrix phases alone
+    return;
+#endif
+    float mx = fmaxf(sacc[0][0], sacc[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
+    {
+      const unsigned mu = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      const unsigned m0 = sw[0], m1 = sw[1];
+      mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
+    }
+    const bool moves = mx - m_run > SPLIT_LAZY_TH;
+    const bool grow = __any(moves);
+    float alpha = 1.f;
+    if (grow) {
+      const float m_new = moves ? mx : m_run;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+    }
+    float psum = 0.f;
+    const float mc = m_run * c;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
+        sacc[ks][r] = p;
+        psum += p;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        const int r0 = 8 * kk;
+        unsigned a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l;
+        split16_pack2_inrange(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
+        split16_pack2_inrange(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
+        split16_pack2_inrange(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
+        split16_pack2_inrange(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
+        auto h0 = __builtin_amdgcn_permlane32_swap(a0h, b0h, false, false);
+        auto h1 = __builtin_amdgcn_permlane32_swap(a1h, b1h, false, false);
+        auto l0 = __builtin_amdgcn_permlane32_swap(a0l, b0l, false, false);
+        auto l1 = __builtin_amdgcn_permlane32_swap(a1l, b1l, false, false);
+        ph[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(h0[0], h1[0], h0[1], h1[1]));
+        pl[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(l0[0], l1[0], l0[1], l1[1]));
       }
     }
-    if (q < NQ) report_saturation(a.sat, 0, o_amax, FP_F16_MAX);
+    if (grow) {
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    l_run += psum;
+  };
+  // ---- O^T += V^T P^T with V from slot `slot`, 4 steps of 16 keys (per accumulator: lo.hi, hi.lo, hi.hi, k-steps ascending)
+  auto pv_phase = [&](int slot) {
+    const char* Vs = KVR + slot * SPP_SLOT + 16384;
+#ifdef SPP_NO_MATRIX
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[0][r] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, ph[r & 3])[r >> 2]) * 1e-30f;
+    return;
+#endif
+#pragma unroll
+    for (int kstep = 0; kstep < 4; ++kstep) {
+      f16x8 vfh[2], vfl[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;
+        const char* vpl = Vs + vrd0 + (((2 * dt + 1) ^ kq) << 6) + kstep * 4096;
+        const s16x4 h_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph));
+        const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
+        const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
+        const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
+        vfh[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        vfl[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[0], ph[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[1], ph[kstep], oacc[1], 0, 0, 0);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], pl[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], pl[kstep], oacc[1], 0, 0, 0);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], ph[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], ph[kstep], oacc[1], 0, 0, 0);
+    }
+  };
+  // this wave's rows of K(t+2) and V(t+1): always four loads (a tile index past the end reads out of range: zeros into a slot nobody reads),
+  // so "everything but this iteration's loads has landed" is vmcnt(4) in every iteration
+  auto stage_ahead = [&](int t, int s_prev, int s_next) {
+    stage_k(t + 2 < T ? t + 2 : T, s_prev);
+    stage_v(t + 1 < T ? t + 1 : T, s_next);
+  };
+  auto end_of_iteration = [&]() {
+    __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4)
+    __builtin_amdgcn_s_barrier();
+  };
+  auto next = [](int& s_prev, int& s_cur, int& s_next) { s_prev = s_cur, s_cur = s_next, s_next = s_next == 2 ? 0 : s_next + 1; };
+
+  __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) as a builtin (see attn_bf16_w64_kernel)
+  __syncthreads();
+  int s_prev = 2, s_cur = 0, s_next = 1;
+  if (!active) {  // a wave without queries (short last query tile): its share of the staging and the barriers
+    for (int t = 0; t < T; ++t) {
+      if (grp == 0) stage_ahead(t, s_prev, s_next);
+      SPP_MID_BARRIER();
+      if (grp != 0) stage_ahead(t, s_prev, s_next);
+      end_of_iteration();
+      next(s_prev, s_cur, s_next);
+    }
+    SPP_MID_BARRIER();
+    return;
   }
+  if (grp == 0) {
+    stage_ahead(0, s_prev, s_next);
+    s_phase(0, s_cur);
+    SPP_MID_BARRIER();
+    softmax_phase();
+    end_of_iteration();
+    next(s_prev, s_cur, s_next);
+    for (int t = 1; t < T; ++t) {
+      pv_phase(s_prev);
+      stage_ahead(t, s_prev, s_next);
+      s_phase(t, s_cur);
+      SPP_MID_BARRIER();
+      softmax_phase();
+      end_of_iteration();
+      next(s_prev, s_cur, s_next);
+    }
+    pv_phase(s_prev);
+    SPP_MID_BARRIER();
+  } else {
+    SPP_MID_BARRIER();
+    stage_ahead(0, s_prev, s_next);
+    s_phase(0, s_cur);
+    end_of_iteration();
+    next(s_prev, s_cur, s_next);
+    for (int t = 1; t < T; ++t) {
+      softmax_phase();   // of tile t - 1
+      SPP_MID_BARRIER();
+      pv_phase(s_prev);
+      stage_ahead(t, s_prev, s_next);
+      s_phase(t, s_cur);
+      end_of_iteration();
+      next(s_prev, s_cur, s_next);
+    }
+    softmax_phase();
+    SPP_MID_BARRIER();
+    pv_phase(s_prev);
+  }
+  if (active) split_attn_store(a, oacc, l_run, q0, l31, kh, NQ, sel_base, img, N, head);
 }
 
 // ---------------------------------------------------------------- fp32 parity-mode attention
@@ -1126,7 +1443,18 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 8 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
     FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
     FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
-    hipLaunchKernelGGL(attn_split_kernel, dim3((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch)), dim3(512), 0, st, a);
+    static const int tail_last = getenv("FP_ATTN_TAIL_LAST") ? atoi(getenv("FP_ATTN_TAIL_LAST")) : 1;
+    a.tail_last = tail_last;
+    const dim3 grid((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch));
+    // variant 1 = the lock-step kernel, 2 = the role-split kernel (attn_split_pp_kernel's header; bit-identical), 0 = the default of the two
+    static const int pp_default = getenv("FP_ATTN_SPLIT_PP") ? atoi(getenv("FP_ATTN_SPLIT_PP")) : 0;
+    if (a.variant == 1 || (a.variant == 0 && !pp_default)) {
+      hipLaunchKernelGGL(attn_split_kernel, grid, dim3(512), 0, st, a);
+    } else {
+      static FpDeviceOnce once;
+      fp_allow_dynamic_lds(once, attn_split_pp_kernel, SPP_LDS);
+      hipLaunchKernelGGL(attn_split_pp_kernel, grid, dim3(512), SPP_LDS, st, a);
+    }
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection exists in the bf16 and f16x3 kernels");
     if (a.variant == 1) {  // the thread-per-query VALU kernel (one fma chain per score, keys in order): the cross-check of the MFMA kernel

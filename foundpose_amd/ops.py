@@ -315,12 +315,14 @@ def gemm_split(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, acc_scale: 
     return out
 
 
-def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float, f16f8_out: bool = False) -> torch.Tensor:
-    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows)."""
+def attention_split(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, in_scale: float, out_scale: float, f16f8_out: bool = False,
+                    variant: int = 0) -> torch.Tensor:
+    """qkv [B*N, 6D] split rows (q | k | v) -> [B*N, 2D] split rows (f16f8_out: f16f8 rows).  variant 0 = the kernel the pipeline runs, 1 = the lock-step
+    kernel, 2 = the role-split kernel (bit-identical)."""
     require_cuda(qkv)
     out = torch.zeros(qkv.shape[0], 2 * dim, dtype=torch.float16, device=qkv.device)
     call("fp_attention_split", ptr(qkv), qkv.stride(0), ptr(out), 2 * dim, batch, n_tok, dim, heads, float(in_scale), float(out_scale),
-         _lib.FP_F16F8 if f16f8_out else _lib.FP_F16X3, stream())
+         (_lib.FP_F16F8 if f16f8_out else _lib.FP_F16X3) | (int(variant) << 8), stream())
     return out
 
 

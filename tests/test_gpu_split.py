@@ -142,6 +142,24 @@ def test_attention_split_vs_fp64(B, N, heads):
     assert e < 5e-6 and e < 4 * e32 + 1e-6, (e, e32)
 
 
+@pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 4), (3, 905, 2), (1, 256, 1), (2, 257, 3), (1, 64, 16), (1, 33, 1), (2, 129, 8), (1, 2305, 2)])
+@pytest.mark.parametrize("f16f8_out", [False, True])
+def test_attention_split_role_split_kernel_equals_lock_step_kernel(B, N, heads, f16f8_out):
+    """attn_split_pp_kernel (variant 2: the two waves of a SIMD half a key tile apart, three-slot K / V ring) issues the same MFMAs in the
+    same order per accumulator and the same softmax as attn_split_kernel (variant 1): every output bit equal -- one tile, ragged last tiles
+    of both halves' widths, short last query tiles (waves without queries), more than one query tile, both output row formats."""
+    D = heads * 64
+    g = torch.Generator(device="cuda").manual_seed(7 * N + heads)
+    qkv = torch.randn(B * N, 3 * D, generator=g, device="cuda") * 1.5
+    qkv[:, 5] *= 6.0
+    packed = torch.cat([ops.split16_pack(qkv[:, i * D:(i + 1) * D].contiguous(), 64.0) for i in range(3)], dim=1)
+    a = ops.attention_split(packed, B, N, D, heads, 64.0, 128.0, f16f8_out=f16f8_out, variant=2)
+    b = ops.attention_split(packed, B, N, D, heads, 64.0, 128.0, f16f8_out=f16f8_out, variant=1)
+    assert torch.equal(a.view(torch.int16), b.view(torch.int16))
+    for _ in range(3):   # the role-split schedule has more ways to race than the lock-step one: the same bits on every launch
+        assert torch.equal(ops.attention_split(packed, B, N, D, heads, 64.0, 128.0, f16f8_out=f16f8_out, variant=2).view(torch.int16), a.view(torch.int16))
+
+
 def test_attention_split_forced_rescale_and_constant_rows():
     """Online-softmax corner cases: a key late in the sequence that dominates every earlier one (the running max jumps at a chosen
     tile and everything accumulated so far is rescaled), and all-equal scores (uniform attention)."""

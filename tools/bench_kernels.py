@@ -82,9 +82,10 @@ def main():
     if "attnsplit" in what:   # the f16x3 mode's attention (split-fp16 operands, three fp16 MFMAs per product)
         x = torch.randn(M, 3 * D, device=dev)
         packed = torch.cat([ops.split16_pack(x[:, i * D:(i + 1) * D].contiguous(), 16.0) for i in range(3)], dim=1)
-        for rep in range(2):
-            ms = timeit(lambda: ops.attention_split(packed, B, N, D, H, 16.0, 16.0))
-            print(f"attn f16x3 B={B} N={N} H={H}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s (fp32-product equivalent)", flush=True)
+        for rep in range(3):
+            for variant in (2, 1):   # 2 = the role-split kernel, 1 = the lock-step kernel
+                ms = timeit(lambda: ops.attention_split(packed, B, N, D, H, 16.0, 16.0, variant=variant))
+                print(f"attn f16x3 B={B} N={N} H={H} variant={variant}: {ms*1e3:8.1f} us  {4.0*B*N*N*D/ms/1e9:7.1f} TF/s (fp32-product equivalent)", flush=True)
     if "attn32" in what:   # the exact-fp32 mode's attention: fp32 MFMA kernel (variant 0) vs the thread-per-query VALU kernel (variant 1)
         qkv = torch.randn(M, 3 * D, device=dev)
         for variant in (0, 1, 0):
