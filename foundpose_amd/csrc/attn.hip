@@ -610,14 +610,257 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 //   K image [64 keys][256 B]: 16-B chunk p of row r holds chunk p ^ (r & 15)        (b128 fragment reads: 16 lanes, 16 rows, 16 slots)
 //   V image [64 keys][256 B]: 64-B unit  u of row r holds unit  u ^ (r & 3)         (transpose reads: a half-wave's four keys x 64 B
 //                                                                                    fall into the four bank quarters)
-constexpr float SPLIT_P_SCALE = 16384.f;
 constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);  // 1 in the exponent, in score units
+
+// Per-wave state and the three per-tile phases both split-fp16 kernels run (the schedules differ, the arithmetic does not: bit-identical outputs).
+//   scores():  S^T = K Q^T for 64 keys.  A-row i of a 32-key half holds key i with bits 2 and 3 swapped, so that output register r of lane
+//              (query l31, half kh) is key 16 (r >> 3) + 8 kh + (r & 7) of its half: eight consecutive keys per 16-key step, which is the B
+//              operand layout of the P V MFMA -- P is packed where it is, no cross-lane exchange.
+//   softmax(): online softmax, lazily rescaled per query (the reference trails the maximum by at most 1 in the exponent: p <= 2); the scale 2^14
+//              of the split P rides in the exponent's offset (p' = 2^14 p <= 2^15 fits fp16), the row sum is taken from p' in four chains;
+//              p' -> (hi, lo) = (f16(p'), f16(p' - hi)) by one v_cvt_pk_f16_f32 per pair + one v_fma_mix{lo,hi}_f16 per value.
+//   pv():      O^T += V^T P^T, V^T by transpose reads; per accumulator lo.hi, hi.lo, hi.hi per 16-key step, steps ascending.
+constexpr float SPLIT_P_LOG2_SCALE = 14.f;
+struct SplitAttnWave {
+  f16x8 qh[4], ql[4];
+  f32x16 sacc[2], oacc[2];
+  f16x8 ph[4], pl[4];
+  float m_run, l_run, c;
+  int l31, kh, krow, kq, vrd0;
+
+  FP_DEVICE void init(int lane, float in_scale) {
+    l31 = lane & 31, kh = lane >> 5;
+    krow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);
+    kq = (lane & 15) >> 2;
+    vrd0 = (kh * 8 + kq) * 256 + ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+    c = 0.125f * 1.44269504088896340736f / (in_scale * in_scale);  // exp2 argument = score * head_dim^-0.5 * log2(e); the scores carry in_scale^2
+    m_run = -INFINITY, l_run = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f, sacc[i][r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) ph[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, pl[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+  }
+  // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d] as (hi, lo)
+  FP_DEVICE void load_q(const _Float16* qp) {
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
+      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
+      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
+    }
+  }
+  // keys_left: N - (first key of the tile); RAGGED: the tile has fewer than 64 live keys, the rest are masked (their K rows are the DMA's
+  // out-of-range zeros).  A compile-time flag: as a run-time test the compiler turns the masking into 32 selects in EVERY tile.
+  template <bool RAGGED>
+  FP_DEVICE void scores(const char* Ks, int keys_left) {
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
+      f16x8 kfh[2], kfl[2];
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int row = ks * 32 + krow;
+        const char* kr = Ks + row * 256;
+#ifdef SPP_NO_LDS   // measurement build: fragments from registers (loop-variant through keys_left, so nothing is hoisted or merged)
+        kfh[ks] = qh[(ds + ks) & 3]; kfl[ks] = ql[(ds + ks + 1) & 3];
+        kfh[ks][0] = (_Float16)(float)(keys_left & 7); kfl[ks][1] = (_Float16)(float)((keys_left >> 3) & 7);
+        (void)kr;
+#else
+        kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
+        kfl[ks] = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
+#endif
+      }
+      // the two key halves' chains interleaved (per accumulator the order is lo.hi, hi.lo, hi.hi over ds ascending)
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
+    }
+    if constexpr (RAGGED) {
+      const int lim = keys_left - 8 * kh;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (ks * 32 + 16 * (r >> 3) + (r & 7) >= lim) sacc[ks][r] = -INFINITY;
+    }
+  }
+  FP_DEVICE void softmax() {
+    // (fmaxf, not v_max3_f32 as inline asm: the hazard recognizer does not place the wait states an MFMA result needs in front of an asm reader)
+    float mch[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {  // four chains of eight scores
+      const f32x16& s = sacc[j >> 1];
+      const int b = (j & 1) * 8;
+      float t = fmaxf(fmaxf(s[b], s[b + 1]), s[b + 2]);
+      t = fmaxf(fmaxf(t, s[b + 3]), s[b + 4]);
+      t = fmaxf(fmaxf(t, s[b + 5]), s[b + 6]);
+      mch[j] = fmaxf(t, s[b + 7]);
+    }
+    float mx = fmaxf(fmaxf(fmaxf(mch[0], mch[1]), mch[2]), mch[3]);
+    {  // the query's other 32 scores live in lane ^ 32 (one v_permlane32_swap; results through temporaries, see attn_bf16_w64_kernel)
+      const unsigned mu = __builtin_bit_cast(unsigned, mx);
+      const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+      const unsigned m0 = sw[0], m1 = sw[1];
+      mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
+    }
+    const bool moves = mx - m_run > SPLIT_LAZY_TH;
+    const bool grow = __any(moves);
+    float alpha = 1.f;
+    if (grow) {
+      const float m_new = moves ? mx : m_run;
+      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
+      m_run = m_new;
+    }
+    const float mc = fmaf(m_run, c, -SPLIT_P_LOG2_SCALE);
+    float ps[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
+        sacc[ks][r] = p;
+        ps[r & 3] += p;
+      }
+#pragma unroll
+      for (int kk = 0; kk < 2; ++kk) {
+        unsigned h[4], l[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pa = sacc[ks][8 * kk + 2 * e], pb = sacc[ks][8 * kk + 2 * e + 1];
+          h[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{pa, pb}, f16x2));  // v_cvt_pk_f16_f32 (RNE)
+          // lo = f16(p' - hi): the difference is exact in fp32, one rounding -- the bits of split16_pack2_inrange
+          asm("v_fma_mixlo_f16 %0, -%1, 1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(l[e]) : "v"(h[e]), "v"(pa));
+          asm("v_fma_mixhi_f16 %0, -%1, 1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l[e]) : "v"(h[e]), "v"(pb));
+        }
+        ph[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(h[0], h[1], h[2], h[3]));
+        pl[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(l[0], l[1], l[2], l[3]));
+      }
+    }
+    if (grow) {
+      l_run *= alpha;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+    }
+    l_run += (ps[0] + ps[1]) + (ps[2] + ps[3]);
+    asm volatile("" : "+v"(l_run));  // the row sum stays in this phase (the scheduler otherwise sinks its adds behind the next phase's MFMAs)
+  }
+  FP_DEVICE void pv(const char* Vs) {
+#pragma unroll
+    for (int kstep = 0; kstep < 4; ++kstep) {
+      f16x8 vfh[2], vfl[2];
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;       // hi unit of d-group dt (+ 1024 B = 4 keys on)
+        const char* vpl = Vs + vrd0 + (((2 * dt + 1) ^ kq) << 6) + kstep * 4096;   // lo unit
+#ifdef SPP_NO_LDS
+        vfh[dt] = qh[(kstep + dt) & 3]; vfl[dt] = ql[(kstep + dt + 1) & 3];
+        vfh[dt][0] = (_Float16)(float)((size_t)Vs & 0x8000 ? 1 : 2); vfl[dt][1] = (_Float16)(float)((size_t)Vs & 0x10000 ? 1 : 3);
+        (void)vph; (void)vpl;
+#else
+        const s16x4 h_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph));
+        const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
+        const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
+        const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
+        vfh[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+        vfl[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
+#endif
+      }
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[0], ph[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[1], ph[kstep], oacc[1], 0, 0, 0);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], pl[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], pl[kstep], oacc[1], 0, 0, 0);
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], ph[kstep], oacc[0], 0, 0, 0);
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], ph[kstep], oacc[1], 0, 0, 0);
+    }
+  }
+  // The matrix phase of the role-split kernel's steady state -- P V of one tile, then S^T of the next -- as one pinned instruction order: the
+  // wave is alone on its SIMD's matrix pipe (its partner is in its softmax), so nobody else hides its LDS latency or fills its issue gaps.
+  // Eight steps of six MFMAs (four P V steps of 16 keys, four S steps of 16 d); the fragments of step i + 1 are read in the gaps behind the
+  // first four MFMAs of step i (two transpose reads or one b128 read per gap), `dma` (the wave's LDS-DMA loads of the tiles ahead) rides in the
+  // gaps of the first S step -- behind the last transpose read of the iteration.  Same MFMAs, same order per accumulator as pv() + scores().
+  template <class F>
+  FP_DEVICE void matrix(const char* Vs, const char* Ks, F&& dma) {
+#define SPP_PIN() __builtin_amdgcn_sched_barrier(0)
+    auto ldv = [&](int kstep, int part) {  // part: 0 = hi of d-group 0, 1 = lo of d-group 0, 2 = hi of d-group 1, 3 = lo of d-group 1
+      const char* vp = Vs + vrd0 + ((part ^ kq) << 6) + kstep * 4096;
+      const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
+      const s16x4 y = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp + 1024));
+      return __builtin_bit_cast(f16x8, __builtin_shufflevector(x, y, 0, 1, 2, 3, 4, 5, 6, 7));
+    };
+    auto ldk = [&](int ds, int part) {     // part: 0 = hi of key half 0, 1 = lo of key half 0, 2 = hi of key half 1, 3 = lo of key half 1
+      const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh + (part & 1) * 4, row = (part >> 1) * 32 + krow;
+      return *reinterpret_cast<const f16x8*>(Ks + row * 256 + ((ch ^ (row & 15)) << 4));
+    };
+    f16x8 c[4], n[4];
+#pragma unroll
+    for (int part = 0; part < 4; ++part) c[part] = ldv(0, part);
+    SPP_PIN();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], ph[k], oacc[0], 0, 0, 0);
+      n[0] = k < 3 ? ldv(k + 1, 0) : ldk(0, 0);
+      SPP_PIN();
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[3], ph[k], oacc[1], 0, 0, 0);
+      n[1] = k < 3 ? ldv(k + 1, 1) : ldk(0, 1);
+      SPP_PIN();
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], pl[k], oacc[0], 0, 0, 0);
+      n[2] = k < 3 ? ldv(k + 1, 2) : ldk(0, 2);
+      SPP_PIN();
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], pl[k], oacc[1], 0, 0, 0);
+      n[3] = k < 3 ? ldv(k + 1, 3) : ldk(0, 3);
+      SPP_PIN();
+      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], ph[k], oacc[0], 0, 0, 0);
+      SPP_PIN();
+      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], ph[k], oacc[1], 0, 0, 0);
+      SPP_PIN();
+#pragma unroll
+      for (int part = 0; part < 4; ++part) c[part] = n[part];
+    }
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ds = 0; ds < 4; ++ds) {
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], qh[ds], ds ? sacc[0] : zero, 0, 0, 0);
+      if (ds < 3) n[0] = ldk(ds + 1, 0);
+      SPP_PIN();
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[3], qh[ds], ds ? sacc[1] : zero, 0, 0, 0);
+      if (ds < 3) n[1] = ldk(ds + 1, 1);
+      SPP_PIN();
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], ql[ds], sacc[0], 0, 0, 0);
+      if (ds < 3) n[2] = ldk(ds + 1, 2);
+      SPP_PIN();
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], ql[ds], sacc[1], 0, 0, 0);
+      if (ds < 3) n[3] = ldk(ds + 1, 3);
+      SPP_PIN();
+      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], qh[ds], sacc[0], 0, 0, 0);
+      if (ds == 0) dma();
+      SPP_PIN();
+      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], qh[ds], sacc[1], 0, 0, 0);
+      SPP_PIN();
+      if (ds < 3) {
+#pragma unroll
+        for (int part = 0; part < 4; ++part) c[part] = n[part];
+      }
+    }
+#undef SPP_PIN
+  }
+};
 
 // Epilogue of the split-fp16 attention kernels: O = sum(P v) / l without the scales of P and v, written as a split-fp16 row or an f16f8 row.
 FP_DEVICE void split_attn_store(const AttnArgs& a, const f32x16 (&oacc)[2], float l_run, int q0, int l31, int kh, int NQ, int sel_base, int img, int N, int head) {
   const int q = q0 + l31;
   const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
-  const float inv = 1.f / (l_tot * SPLIT_P_SCALE * a.in_scale);  // O = sum(P v) / l, minus the scales of P and v
+  const float inv = 1.f / (l_tot * a.in_scale);  // O = sum(P' v') / l': P' and l' carry the same 2^14, v' its operand scale
   // 16-byte stores: a lane's 4 consecutive d and lane ^ 32's next 4 paired by v_permlane32_swap (attn_bf16_w64_kernel's epilogue)
   const size_t orow = a.sel_off ? (size_t)(sel_base + q) : (size_t)img * N + q;  // compact rows in selected mode
   _Float16* o = reinterpret_cast<_Float16*>(a.out) + orow * a.ld_out + head * 128;
@@ -730,168 +973,33 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   const int nkt = (N + 63) / 64;
   stage_tile(0, 0);
 
-  // exp2 argument = score * head_dim^-0.5 * log2(e); the accumulated scores carry the operand scales in_scale^2
-  const float c = 0.125f * 1.44269504088896340736f / (a.in_scale * a.in_scale);
-  // Q fragments straight from global (once per block): B operand, lane holds Q[query][8 d] as (hi, lo)
-  f16x8 qh[4], ql[4];
+  SplitAttnWave w;
+  w.init(lane, a.in_scale);
   {
     const int q = q0 + l31;
     int qc = q < NQ ? q : NQ - 1;
     if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;  // the selected query's token
-    const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
-      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
-      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
-    }
+    w.load_q(qkv + (size_t)qc * a.ld_qkv + head * 128);
   }
-  f32x16 oacc[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-  float m_run = -INFINITY, l_run = 0.f;
-  // transpose-read base inside the V image: key = kh*8 + kq, 16-d block vb, 8-B piece; the 64-B unit is XOR-ed with kq per read
-  const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
-  const int vrd0 = (kh * 8 + kq) * 256 + vb * 32 + (lane & 3) * 8;
-
   __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0) as a builtin (see attn_bf16_w64_kernel)
   __syncthreads();
-  auto tile = [&](int kt, auto ragged, auto halfkeys) {
-    constexpr bool RAGGED = decltype(ragged)::value;
-    constexpr int KS = decltype(halfkeys)::value ? 1 : 2;  // 1: the ragged tile's second key half is all padding and is skipped (attn_bf16_w64_kernel)
-    static_assert(RAGGED || KS == 2, "only the ragged tile can be half empty");
-    const int key0 = kt * 64;
-    const char* Ks = KV[kt & 1][0];
-    const char* Vs = KV[kt & 1][1];
-    if (!RAGGED && kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
-    if (active) {
-      __builtin_amdgcn_iglp_opt(1);  // as in attn_bf16_w64_kernel (+0.5...1 %)
-      // ---- S^T = K Q^T: sacc[ks][r] = score(query l31, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
-      f32x16 sacc[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
-#pragma unroll
-      for (int ds = 0; ds < 4; ++ds) {
-        const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;  // hi chunk of this lane's 8 d; lo chunk 4 further
-        f16x8 kfh[2], kfl[2];
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-          const int row = ks * 32 + l31;
-          const char* kr = Ks + row * 256;
-          kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
-          kfl[ks] = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
-        }
-        // the two key halves' chains interleaved (per accumulator the order stays lo.hi, hi.lo, hi.hi over ds ascending)
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
-        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
-        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
-        sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
-        if constexpr (KS == 2) sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
-      }
-      if constexpr (RAGGED) {  // mask the padded keys
-        const int lim = N - key0 - 4 * kh;
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-          for (int r = 0; r < 16; ++r)
-            if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
-      }
-      // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
-      float mx = KS == 2 ? fmaxf(sacc[0][0], sacc[KS - 1][0]) : sacc[0][0];
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = KS == 2 ? fmaxf(fmaxf(mx, sacc[0][r]), sacc[KS - 1][r]) : fmaxf(mx, sacc[0][r]);
-      {  // the query's other 32 scores live in lane ^ 32 (one v_permlane32_swap; results through temporaries, see attn_bf16_w64_kernel)
-        const unsigned mu = __builtin_bit_cast(unsigned, mx);
-        const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-        const unsigned m0 = sw[0], m1 = sw[1];
-        mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
-      }
-      // lazy rescale, per query (attn_bf16_w64_kernel): here the reference may trail the maximum by at most 1 in the exponent --
-      // p <= 2, and 2 * SPLIT_P_SCALE = 2^15 still splits into fp16 (max 65504): the split below needs no clamp (split16_pack2_inrange)
-      const bool moves = mx - m_run > SPLIT_LAZY_TH;
-      const bool grow = __any(moves);
-      float alpha = 1.f;
-      if (grow) {
-        const float m_new = moves ? mx : m_run;
-        alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-        m_run = m_new;
-      }
-      float psum = 0.f;
-      const float mc = m_run * c;
-      f16x8 ph[4], pl[4];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
-          sacc[ks][r] = p;
-          psum += p;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-          const int r0 = 8 * kk;
-          unsigned a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l;
-          split16_pack2_inrange(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
-          split16_pack2_inrange(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
-          split16_pack2_inrange(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
-          split16_pack2_inrange(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
-          auto h0 = __builtin_amdgcn_permlane32_swap(a0h, b0h, false, false);
-          auto h1 = __builtin_amdgcn_permlane32_swap(a1h, b1h, false, false);
-          auto l0 = __builtin_amdgcn_permlane32_swap(a0l, b0l, false, false);
-          auto l1 = __builtin_amdgcn_permlane32_swap(a1l, b1l, false, false);
-          ph[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(h0[0], h1[0], h0[1], h1[1]));
-          pl[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(l0[0], l1[0], l0[1], l1[1]));
-        }
-      }
-      if (grow) {
-        l_run *= alpha;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-      }
-      l_run += psum;
-      // ---- O^T += V^T P^T over 4 steps of 16 keys; the two d-halves' chains interleaved (per accumulator: lo.hi, hi.lo, hi.hi, k-steps ascending)
-#pragma unroll
-      for (int kstep = 0; kstep < 2 * KS; ++kstep) {
-        f16x8 vfh[2], vfl[2];
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt) {
-          const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;       // hi unit of d-group dt (+ 1024 B = 4 keys on)
-          const char* vpl = Vs + vrd0 + (((2 * dt + 1) ^ kq) << 6) + kstep * 4096;   // lo unit
-          const s16x4 h_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph));
-          const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
-          const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
-          const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
-          vfh[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-          vfl[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        }
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[0], ph[kstep], oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[1], ph[kstep], oacc[1], 0, 0, 0);
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], pl[kstep], oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], pl[kstep], oacc[1], 0, 0, 0);
-        oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], ph[kstep], oacc[0], 0, 0, 0);
-        oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], ph[kstep], oacc[1], 0, 0, 0);
-      }
-    }
-    if constexpr (!RAGGED) {
-      __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
-      __syncthreads();
-    }
-  };
   const int nfull = N / 64;
-  for (int kt = 0; kt < nfull; ++kt) tile(kt, std::false_type{}, std::false_type{});
-  if (nfull < nkt) {
-    if (N - nfull * 64 <= 32) tile(nfull, std::true_type{}, std::true_type{});
-    else tile(nfull, std::true_type{}, std::false_type{});
+  for (int kt = 0; kt < nfull; ++kt) {
+    if (kt + 1 < nkt) stage_tile(kt + 1, (kt + 1) & 1);
+    if (active) {
+      w.scores<false>(KV[kt & 1][0], 64);
+      w.softmax();
+      w.pv(KV[kt & 1][1]);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);  // vmcnt(0): the compiler does not wait for LDS-DMA before a barrier
+    __syncthreads();
   }
-
-  if (active) split_attn_store(a, oacc, l_run, q0, l31, kh, NQ, sel_base, img, N, head);
+  if (nfull < nkt && active) {  // the ragged last tile
+    w.scores<true>(KV[nfull & 1][0], N - nfull * 64);
+    w.softmax();
+    w.pv(KV[nfull & 1][1]);
+  }
+  if (active) split_attn_store(a, w.oacc, w.l_run, q0, l31, kh, NQ, sel_base, img, N, head);
 }
 
 // ---------------------------------------------------------------- split-fp16, role-split ("ping-pong") form: the default of the f16x3 / f16f8 modes
@@ -984,169 +1092,66 @@ __global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
   stage_v(0, 0);
   if (T > 1) stage_k(1, 1);
 
-  const float c = 0.125f * 1.44269504088896340736f / (a.in_scale * a.in_scale);
-  f16x8 qh[4], ql[4];
+  SplitAttnWave w;
+  w.init(lane, a.in_scale);
   {
     const int q = q0 + l31;
     int qc = q < NQ ? q : NQ - 1;
     if (a.sel_rows) qc = a.sel_rows[sel_base + qc] - img * N;
-    const _Float16* qp = qkv + (size_t)qc * a.ld_qkv + head * 128;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      const int off = (ds >> 1) * 64 + (ds & 1) * 16 + kh * 8;
-      qh[ds] = *reinterpret_cast<const f16x8*>(qp + off);
-      ql[ds] = *reinterpret_cast<const f16x8*>(qp + off + 32);
-    }
+    w.load_q(qkv + (size_t)qc * a.ld_qkv + head * 128);
   }
-  f32x16 oacc[2], sacc[2];
-  f16x8 ph[4], pl[4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f, sacc[i][r] = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) ph[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}, pl[i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-  float m_run = -INFINITY, l_run = 0.f;
-  const int kq = (lane & 15) >> 2, vb = (lane >> 4) & 1;
-  const int vrd0 = (kh * 8 + kq) * 256 + vb * 32 + (lane & 3) * 8;
-
-  // ---- S^T(t) = K(t) Q^T from slot `slot`: sacc[ks][r] = score(query l31, key 64 t + ks*32 + (r&3) + 8*(r>>2) + 4*kh) * in_scale^2
+#ifdef SPP_NO_MATRIX   // measurement build (tools/attn_split_ablate.sh): no MFMAs, scores = raw LDS words (values the compiler cannot fold)
   auto s_phase = [&](int t, int slot) {
-    const char* Ks = KVR + slot * SPP_SLOT;
-#ifdef SPP_NO_MATRIX   // measurement build: no MFMAs, scores = raw LDS words (values the compiler cannot fold)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int r = 0; r < 16; r += 4) {
-        const float4 w = *reinterpret_cast<const float4*>(Ks + (ks * 32 + l31) * 256 + kh * 64 + r * 4);
-        sacc[ks][r] = w.x * 1e-30f; sacc[ks][r + 1] = w.y * 1e-30f; sacc[ks][r + 2] = w.z * 1e-30f; sacc[ks][r + 3] = w.w * 1e-30f;
+        const float4 x = *reinterpret_cast<const float4*>(KVR + slot * SPP_SLOT + (ks * 32 + l31) * 256 + kh * 64 + r * 4);
+        w.sacc[ks][r] = x.x * 1e-30f; w.sacc[ks][r + 1] = x.y * 1e-30f; w.sacc[ks][r + 2] = x.z * 1e-30f; w.sacc[ks][r + 3] = x.w * 1e-30f;
       }
-    return;
+  };
+  auto pv_phase = [&](int slot) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w.oacc[0][r] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, w.ph[r & 3])[r >> 2]) * 1e-30f;
+  };
+#else
+  auto s_phase = [&](int t, int slot) {
+    if (N - t * 64 < 64) w.scores<true>(KVR + slot * SPP_SLOT, N - t * 64);   // only the last tile can be ragged
+    else w.scores<false>(KVR + slot * SPP_SLOT, 64);
+  };
+  auto pv_phase = [&](int slot) { w.pv(KVR + slot * SPP_SLOT + 16384); };
 #endif
+#ifdef SPP_NO_SOFTMAX  // measurement build: the matrix phases alone (the scores stay live: no MFMA is eliminated)
+  auto softmax_phase = [&]() {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
-#pragma unroll
-    for (int ds = 0; ds < 4; ++ds) {
-      const int ch = (ds >> 1) * 8 + (ds & 1) * 2 + kh;
-      f16x8 kfh[2], kfl[2];
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        const int row = ks * 32 + l31;
-        const char* kr = Ks + row * 256;
-        kfh[ks] = *reinterpret_cast<const f16x8*>(kr + ((ch ^ (row & 15)) << 4));
-        kfl[ks] = *reinterpret_cast<const f16x8*>(kr + (((ch + 4) ^ (row & 15)) << 4));
-      }
-      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[0], qh[ds], sacc[0], 0, 0, 0);
-      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfl[1], qh[ds], sacc[1], 0, 0, 0);
-      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], ql[ds], sacc[0], 0, 0, 0);
-      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], ql[ds], sacc[1], 0, 0, 0);
-      sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[0], qh[ds], sacc[0], 0, 0, 0);
-      sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh[1], qh[ds], sacc[1], 0, 0, 0);
-    }
-    if (t == T - 1 && (N & 63)) {  // the ragged last tile: mask the padded keys (their K rows are the DMA's out-of-range zeros)
-      const int lim = N - t * 64 - 4 * kh;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks)
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-          if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[ks][r] = -INFINITY;
-    }
+      for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(w.sacc[ks][r]));
   };
-  // ---- online softmax of the scores in sacc (fp32; attn_split_kernel's arithmetic): P leaves as the split pairs (ph, pl)
-  auto softmax_phase = [&]() {
-#ifdef SPP_NO_SOFTMAX   // measurement build: the matrix phases alone
-    return;
+#elif defined(SPP_PRIO) && SPP_PRIO == 1   // measurement builds: the softmax phase / the matrix phase at raised issue priority
+  auto softmax_phase = [&]() { __builtin_amdgcn_s_setprio(3); w.softmax(); __builtin_amdgcn_s_setprio(0); };
+#else
+  auto softmax_phase = [&]() { w.softmax(); };
 #endif
-    float mx = fmaxf(sacc[0][0], sacc[1][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(mx, sacc[0][r]), sacc[1][r]);
-    {
-      const unsigned mu = __builtin_bit_cast(unsigned, mx);
-      const auto sw = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
-      const unsigned m0 = sw[0], m1 = sw[1];
-      mx = fmaxf(__builtin_bit_cast(float, m0), __builtin_bit_cast(float, m1));
-    }
-    const bool moves = mx - m_run > SPLIT_LAZY_TH;
-    const bool grow = __any(moves);
-    float alpha = 1.f;
-    if (grow) {
-      const float m_new = moves ? mx : m_run;
-      alpha = __builtin_amdgcn_exp2f((m_run - m_new) * c);
-      m_run = m_new;
-    }
-    float psum = 0.f;
-    const float mc = m_run * c;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[ks][r], c, -mc));
-        sacc[ks][r] = p;
-        psum += p;
-      }
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        const int r0 = 8 * kk;
-        unsigned a0h, a0l, a1h, a1l, b0h, b0l, b1h, b1l;
-        split16_pack2_inrange(sacc[ks][r0 + 0], sacc[ks][r0 + 1], SPLIT_P_SCALE, a0h, a0l);
-        split16_pack2_inrange(sacc[ks][r0 + 2], sacc[ks][r0 + 3], SPLIT_P_SCALE, a1h, a1l);
-        split16_pack2_inrange(sacc[ks][r0 + 4], sacc[ks][r0 + 5], SPLIT_P_SCALE, b0h, b0l);
-        split16_pack2_inrange(sacc[ks][r0 + 6], sacc[ks][r0 + 7], SPLIT_P_SCALE, b1h, b1l);
-        auto h0 = __builtin_amdgcn_permlane32_swap(a0h, b0h, false, false);
-        auto h1 = __builtin_amdgcn_permlane32_swap(a1h, b1h, false, false);
-        auto l0 = __builtin_amdgcn_permlane32_swap(a0l, b0l, false, false);
-        auto l1 = __builtin_amdgcn_permlane32_swap(a1l, b1l, false, false);
-        ph[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(h0[0], h1[0], h0[1], h1[1]));
-        pl[ks * 2 + kk] = __builtin_bit_cast(f16x8, make_uint4(l0[0], l1[0], l0[1], l1[1]));
-      }
-    }
-    if (grow) {
-      l_run *= alpha;
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-    }
-    l_run += psum;
-  };
-  // ---- O^T += V^T P^T with V from slot `slot`, 4 steps of 16 keys (per accumulator: lo.hi, hi.lo, hi.hi, k-steps ascending)
-  auto pv_phase = [&](int slot) {
-    const char* Vs = KVR + slot * SPP_SLOT + 16384;
-#ifdef SPP_NO_MATRIX
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[0][r] += __builtin_bit_cast(float, __builtin_bit_cast(uint4, ph[r & 3])[r >> 2]) * 1e-30f;
-    return;
-#endif
-#pragma unroll
-    for (int kstep = 0; kstep < 4; ++kstep) {
-      f16x8 vfh[2], vfl[2];
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const char* vph = Vs + vrd0 + (((2 * dt) ^ kq) << 6) + kstep * 4096;
-        const char* vpl = Vs + vrd0 + (((2 * dt + 1) ^ kq) << 6) + kstep * 4096;
-        const s16x4 h_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph));
-        const s16x4 h_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vph + 1024));
-        const s16x4 l_lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl));
-        const s16x4 l_hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vpl + 1024));
-        vfh[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(h_lo, h_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-        vfl[dt] = __builtin_bit_cast(f16x8, __builtin_shufflevector(l_lo, l_hi, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[0], ph[kstep], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfl[1], ph[kstep], oacc[1], 0, 0, 0);
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], pl[kstep], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], pl[kstep], oacc[1], 0, 0, 0);
-      oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[0], ph[kstep], oacc[0], 0, 0, 0);
-      oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vfh[1], ph[kstep], oacc[1], 0, 0, 0);
-    }
-  };
   // this wave's rows of K(t+2) and V(t+1): always four loads (a tile index past the end reads out of range: zeros into a slot nobody reads),
   // so "everything but this iteration's loads has landed" is vmcnt(4) in every iteration
   auto stage_ahead = [&](int t, int s_prev, int s_next) {
     stage_k(t + 2 < T ? t + 2 : T, s_prev);
     stage_v(t + 1 < T ? t + 1 : T, s_next);
   };
+#if defined(SPP_NO_MATRIX) || defined(SPP_NO_LDS) || defined(SPP_NO_PIPE)
+  auto matrix_phase = [&](int t, int sp, int sc, int sn) { pv_phase(sp); stage_ahead(t, sp, sn); s_phase(t, sc); };
+#else
+  auto matrix_phase = [&](int t, int sp, int sc, int sn) {
+#if defined(SPP_PRIO) && SPP_PRIO == 2
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    w.matrix(KVR + sp * SPP_SLOT + 16384, KVR + sc * SPP_SLOT, [&]() { stage_ahead(t, sp, sn); });
+#if defined(SPP_PRIO) && SPP_PRIO == 2
+    __builtin_amdgcn_s_setprio(0);
+#endif
+  };
+#endif
   auto end_of_iteration = [&]() {
     __builtin_amdgcn_s_waitcnt(0x0f74);  // vmcnt(4)
     __builtin_amdgcn_s_barrier();
@@ -1167,6 +1172,14 @@ __global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
     SPP_MID_BARRIER();
     return;
   }
+#ifdef SPP_TIMELINE   // measurement build (tools/spp_timeline.py): s_memtime stamps of one workgroup's steady-state iterations, waves 0 and 4
+  long long* tl = reinterpret_cast<long long*>(KVR + SPP_LDS) + wave * 64;
+  int tl_n = 0;
+  const bool tl_on = blockIdx.x == SPP_TIMELINE && (wave & 3) == 0;
+#define SPP_STAMP() do { if (tl_on && tl_n < 64) { if (lane == 0) tl[tl_n] = clock64(); ++tl_n; } } while (0)
+#else
+#define SPP_STAMP() ((void)0)
+#endif
   if (grp == 0) {
     stage_ahead(0, s_prev, s_next);
     s_phase(0, s_cur);
@@ -1175,12 +1188,22 @@ __global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
     end_of_iteration();
     next(s_prev, s_cur, s_next);
     for (int t = 1; t < T; ++t) {
-      pv_phase(s_prev);
-      stage_ahead(t, s_prev, s_next);
-      s_phase(t, s_cur);
+      SPP_STAMP();
+      if (t < T - 1) {
+        matrix_phase(t, s_prev, s_cur, s_next);
+      } else {
+        pv_phase(s_prev);
+        stage_ahead(t, s_prev, s_next);
+        s_phase(t, s_cur);
+      }
+      SPP_STAMP();
       SPP_MID_BARRIER();
+      SPP_STAMP();
       softmax_phase();
-      end_of_iteration();
+      SPP_STAMP();
+      __builtin_amdgcn_s_waitcnt(0x0f74);
+      SPP_STAMP();
+      __builtin_amdgcn_s_barrier();
       next(s_prev, s_cur, s_next);
     }
     pv_phase(s_prev);
@@ -1192,19 +1215,35 @@ __global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
     end_of_iteration();
     next(s_prev, s_cur, s_next);
     for (int t = 1; t < T; ++t) {
+      SPP_STAMP();
       softmax_phase();   // of tile t - 1
+      SPP_STAMP();
       SPP_MID_BARRIER();
-      pv_phase(s_prev);
-      stage_ahead(t, s_prev, s_next);
-      s_phase(t, s_cur);
-      end_of_iteration();
+      SPP_STAMP();
+      if (t < T - 1) {
+        matrix_phase(t, s_prev, s_cur, s_next);
+      } else {
+        pv_phase(s_prev);
+        stage_ahead(t, s_prev, s_next);
+        s_phase(t, s_cur);
+      }
+      SPP_STAMP();
+      __builtin_amdgcn_s_waitcnt(0x0f74);
+      SPP_STAMP();
+      __builtin_amdgcn_s_barrier();
       next(s_prev, s_cur, s_next);
     }
     softmax_phase();
     SPP_MID_BARRIER();
     pv_phase(s_prev);
   }
-  if (active) split_attn_store(a, oacc, l_run, q0, l31, kh, NQ, sel_base, img, N, head);
+#ifdef SPP_TIMELINE
+  if (tl_on && lane == 0) {
+    long long* g = reinterpret_cast<long long*>(a.sat);   // the measurement build borrows the saturation pointer: [2][64] stamps
+    for (int i = 0; i < 64; ++i) g[(wave >> 2) * 64 + i] = i < tl_n ? tl[i] : 0;
+  }
+#endif
+  if (active) split_attn_store(a, w.oacc, w.l_run, q0, l31, kh, NQ, sel_base, img, N, head);
 }
 
 // ---------------------------------------------------------------- fp32 parity-mode attention
@@ -1406,6 +1445,13 @@ __global__ __launch_bounds__(256, 2) void attn_f32_mfma_kernel(AttnArgs a) {
 
 }  // namespace
 
+#ifdef SPP_TIMELINE
+static long long* spp_tl_buf = nullptr;
+extern "C" int fp_debug_spp_timeline(long long* host_out) {  // [2][64]: wave 0's and wave 4's stamps of the last role-split launch
+  if (!spp_tl_buf) return 1;
+  return hipMemcpy(host_out, spp_tl_buf, 2 * 64 * sizeof(long long), hipMemcpyDeviceToHost) == hipSuccess ? 0 : 3;
+}
+#endif
 int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
   AttnArgs a = a_in;
   FP_REQUIRE(a.dim % 64 == 0 && a.heads * 64 == a.dim, "attention: head_dim must be 64 (dim %d heads %d)", a.dim, a.heads);
@@ -1452,8 +1498,17 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
       hipLaunchKernelGGL(attn_split_kernel, grid, dim3(512), 0, st, a);
     } else {
       static FpDeviceOnce once;
+#ifndef SPP_TIMELINE
       fp_allow_dynamic_lds(once, attn_split_pp_kernel, SPP_LDS);
+#endif
+#ifdef SPP_TIMELINE
+      if (!spp_tl_buf) (void)hipMalloc(&spp_tl_buf, 2 * 64 * sizeof(long long));
+      a.sat = reinterpret_cast<int*>(spp_tl_buf);
+      fp_allow_dynamic_lds(once, attn_split_pp_kernel, SPP_LDS + 4096);
+      hipLaunchKernelGGL(attn_split_pp_kernel, grid, dim3(512), SPP_LDS + 4096, st, a);
+#else
       hipLaunchKernelGGL(attn_split_pp_kernel, grid, dim3(512), SPP_LDS, st, a);
+#endif
     }
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection exists in the bf16 and f16x3 kernels");
