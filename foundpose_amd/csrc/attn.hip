@@ -10,7 +10,10 @@
 //     qkv buffer) staged through registers into LDS, next tile's loads in flight under the MFMAs, one barrier per tile
 //   * S^T = K Q^T with v_mfma_f32_32x32x16_bf16 (operands swapped so a lane owns ONE query's scores:
 //     row max / row sum need a single cross-lane exchange with lane^32)
-//   * P -> bf16 in registers: v_cvt_pk_bf16_f32 + v_permlane32_swap builds the B operand of O^T = V^T P^T
+//   * the K rows enter the score MFMA permuted -- A-row i holds key i with bits 2 and 3 swapped --, so output register r of lane (query, kh)
+//     is key 16 (r >> 3) + 8 kh + (r & 7) of its 32-key half: eight consecutive keys per 16-key step, which IS the B operand layout of
+//     O^T = V^T P^T.  P -> bf16 by v_cvt_pk_bf16_f32 where it sits; no cross-lane exchange (rounds 1-4 paired lanes by v_permlane32_swap:
+//     16 swaps per wave and key tile, ~3 issue slots each)
 //   * V stays row-major ([key][d], exactly as the qkv GEMM wrote it); the A operand V^T of the P*V MFMA is produced by
 //     gfx950's hardware transpose read ds_read_b64_tr_b16 (two per fragment: lane (d = l&31, kh) receives keys
 //     kh*8 + 4r + j of column d) from an LDS image cut into 16-column blocks.  No pre-transposed V^T copy in HBM
@@ -43,6 +46,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][VTR_BYTES];  // [stage][K: 64 rows x 128 B swizzled | V: block image]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
+  const int krow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);  // A-row i of the score MFMA holds key i with bits 2 and 3 swapped (header)
   // Workgroup -> (query tile, head, image).  Consecutive workgroup ids go round-robin over the 8 XCDs, each with its
   // own L2: when the (image, head) pairs divide by 8, all query tiles of a pair are given ids of ONE residue mod 8 so
   // that the pair's K and V (2 x N x 128 B) are fetched into one L2 instead of eight.
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
     const char* Vs = KV[kt & 1][1];
     if (kt + 1 < nkt) ATTN_LOAD_TILE(key0 + 64);  // next tile: HBM/L2 -> registers, lands under this tile's MFMAs
 
-    // ---- S^T = K Q^T : sacc[ks][r] = score(query = l31, key = key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
+    // ---- S^T = K Q^T : sacc[ks][r] = score(query = l31, key = key0 + ks*32 + 16*(r>>3) + 8*kh + (r&7)) -- A-row i holds key krow(i)
     f32x16 sacc[2];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -127,7 +131,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
       for (int r = 0; r < 16; ++r) sacc[ks][r] = 0.f;
 #pragma unroll
       for (int ds = 0; ds < 4; ++ds) {
-        bf16x8 kf = read_frag(Ks, ks * 32 + l31, ds * 2 + kh);
+        bf16x8 kf = read_frag(Ks, ks * 32 + krow, ds * 2 + kh);
         sacc[ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ds], sacc[ks], 0, 0, 0);
       }
     }
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
       for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int key = key0 + ks * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+          const int key = key0 + ks * 32 + 16 * (r >> 3) + 8 * kh + (r & 7);
           if (key >= N) sacc[ks][r] = -INFINITY;
         }
     }
@@ -186,13 +190,9 @@ __global__ __launch_bounds__(256, 4) void attn_bf16_kernel(AttnArgs a) {
 #pragma unroll
       for (int kk = 0; kk < 2; ++kk) {
         const int r0 = 8 * kk;
-        unsigned a0 = pack_bf16x2(sacc[ks][r0 + 0], sacc[ks][r0 + 1]);
-        unsigned a1 = pack_bf16x2(sacc[ks][r0 + 2], sacc[ks][r0 + 3]);
-        unsigned b0 = pack_bf16x2(sacc[ks][r0 + 4], sacc[ks][r0 + 5]);
-        unsigned b1 = pack_bf16x2(sacc[ks][r0 + 6], sacc[ks][r0 + 7]);
-        auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-        auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-        uint4 pw = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        // registers r0 .. r0 + 7 are eight consecutive keys (the K rows' order, header): the B operand as it stands
+        uint4 pw = make_uint4(pack_bf16x2(sacc[ks][r0 + 0], sacc[ks][r0 + 1]), pack_bf16x2(sacc[ks][r0 + 2], sacc[ks][r0 + 3]),
+                              pack_bf16x2(sacc[ks][r0 + 4], sacc[ks][r0 + 5]), pack_bf16x2(sacc[ks][r0 + 6], sacc[ks][r0 + 7]));
         bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         const int kstep = ks * 2 + kk;  // keys kstep*16 .. +15 of the tile
 #pragma unroll
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: DMA offsets
   const int l31 = lane & 31, kh = lane >> 5;
+  const int krow = (l31 & 19) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);  // as in attn_bf16_kernel
   int qt, head, img;
   {
     const int nqt = ((a.sel_off ? a.max_sel : a.n_tok) + QBLK - 1) / QBLK, pairs = a.heads * a.batch, i = blockIdx.x;
@@ -353,7 +354,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(KV[0][0], ks * 32 + l31, ds * 2 + kh);
+      for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(KV[0][0], ks * 32 + krow, ds * 2 + kh);
   }
   // one key tile; RAGGED (the last tile when N % 64 != 0) is a separate instantiation so that the full tiles carry no
   // masking code at all (inlined into one loop the compiler if-converts the mask into 120 selects per tile)
@@ -375,7 +376,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
     bf16x8 pf[QC][4];
     if (active) {
       if constexpr (!PF) __builtin_amdgcn_iglp_opt(1);  // the compiler's MFMA / LDS interleaving strategy 1 for the tile body: +0.5 % same-box (0, 2, 3: -1...-2 %); (its solver does not terminate on the PF body)
-      // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + (r&3) + 8*(r>>2) + 4*kh)
+      // ---- S^T = K Q^T for both query blocks: sacc[qb][ks][r] = score(query l31 of block qb, key key0 + ks*32 + 16*(r>>3) + 8*kh + (r&7))
       f32x16 sacc[QC][2];
       // four independent accumulation chains (2 key halves x 2 query blocks) interleaved over the four 16-d steps (two chains, key
       // half outermost, measured 1 % slower: a dependent MFMA waits for its predecessor's last pass)
@@ -393,7 +394,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           bf16x8 kf = qf[0][ds];
           kf[0] = (__bf16)(float)((kt + ks) & 3);
 #else
-          const bf16x8 kf = PF ? kfn[PF ? ds : 0][ks] : read_frag(Ks, ks * 32 + l31, ds * 2 + kh);  // one K fragment, two MFMAs
+          const bf16x8 kf = PF ? kfn[PF ? ds : 0][ks] : read_frag(Ks, ks * 32 + krow, ds * 2 + kh);  // one K fragment, two MFMAs
 #endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
@@ -421,12 +422,12 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
       for (int qb = 0; qb < QC; ++qb) {
         if constexpr (RAGGED) {  // mask the padded keys (one lane-dependent limit, constant offsets)
-          const int lim = N - key0 - 4 * kh;
+          const int lim = N - key0 - 8 * kh;
 #pragma unroll
           for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-              if (ks * 32 + (r & 3) + 8 * (r >> 2) >= lim) sacc[qb][ks][r] = -INFINITY;
+              if (ks * 32 + 16 * (r >> 3) + (r & 7) >= lim) sacc[qb][ks][r] = -INFINITY;
         }
         // ---- online softmax (fp32). A query's 64 scores live in lanes l31 and l31+32.
         float mx = KS == 2 ? fmaxf(sacc[qb][0][0], sacc[qb][KS - 1][0]) : sacc[qb][0][0];
@@ -480,13 +481,9 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
           for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 8 * kk;
-            unsigned a0 = pack_bf16x2(sacc[qb][ks][r0 + 0], sacc[qb][ks][r0 + 1]);
-            unsigned a1 = pack_bf16x2(sacc[qb][ks][r0 + 2], sacc[qb][ks][r0 + 3]);
-            unsigned b0 = pack_bf16x2(sacc[qb][ks][r0 + 4], sacc[qb][ks][r0 + 5]);
-            unsigned b1 = pack_bf16x2(sacc[qb][ks][r0 + 6], sacc[qb][ks][r0 + 7]);
-            auto s0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
-            auto s1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
-            pf[qb][ks * 2 + kk] = __builtin_bit_cast(bf16x8, make_uint4(s0[0], s1[0], s0[1], s1[1]));
+            // eight consecutive keys per lane and 16-key step (the K rows' order): P is packed where it is, no cross-lane exchange
+            pf[qb][ks * 2 + kk] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(sacc[qb][ks][r0 + 0], sacc[qb][ks][r0 + 1]), pack_bf16x2(sacc[qb][ks][r0 + 2], sacc[qb][ks][r0 + 3]),
+                                                                         pack_bf16x2(sacc[qb][ks][r0 + 4], sacc[qb][ks][r0 + 5]), pack_bf16x2(sacc[qb][ks][r0 + 6], sacc[qb][ks][r0 + 7])));
           }
       }
       // ---- O^T += V^T P^T over 4 steps of 16 keys; one V^T fragment serves both query blocks
@@ -504,7 +501,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
           for (int ds = 0; ds < 4; ++ds)
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(Kn, ks * 32 + l31, ds * 2 + kh);
+            for (int ks = 0; ks < 2; ++ks) kfn[ds][ks] = read_frag(Kn, ks * 32 + krow, ds * 2 + kh);
         }
       }
 #if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
