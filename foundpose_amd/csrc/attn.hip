@@ -789,6 +789,20 @@ struct SplitAttnWave {
   template <class F>
   FP_DEVICE void matrix(const char* Vs, const char* Ks, F&& dma) {
 #define SPP_PIN() __builtin_amdgcn_sched_barrier(0)
+    // (Measurement switches SPP_NOP_A / SPP_NOP_B: `s_nop n` behind every MFMA of this phase, A: one followed by fragment reads, B: one that is not.
+    // A wave whose NEXT instruction is an MFMA waiting for the busy matrix pipe holds the SIMD's issue arbitration -- beside 48 dense MFMAs a
+    // partner's 64 v_fma take 1536 cycles instead of 340, with one s_nop 7 per MFMA 408 (tools/ubench/mfma_valu_corun.hip) -- but THIS phase has
+    // fragment reads and their waits between its MFMAs already: every nop setting measured slower, 803 us without -> 807 ... 845 us.  Off.)
+#ifndef SPP_NOP_A
+#define SPP_NOP_A -1
+#endif
+#ifndef SPP_NOP_B
+#define SPP_NOP_B -1
+#endif
+#define SPP_STR2(x) #x
+#define SPP_STR(x) SPP_STR2(x)
+#define SPP_GAP_A() do { if (SPP_NOP_A >= 0) asm volatile("s_nop " SPP_STR(SPP_NOP_A)); } while (0)
+#define SPP_GAP_B() do { if (SPP_NOP_B >= 0) asm volatile("s_nop " SPP_STR(SPP_NOP_B)); } while (0)
     auto ldv = [&](int kstep, int part) {  // part: 0 = hi of d-group 0, 1 = lo of d-group 0, 2 = hi of d-group 1, 3 = lo of d-group 1
       const char* vp = Vs + vrd0 + ((part ^ kq) << 6) + kstep * 4096;
       const s16x4 x = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(vp));
@@ -806,20 +820,32 @@ struct SplitAttnWave {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], ph[k], oacc[0], 0, 0, 0);
+      SPP_PIN();
       n[0] = k < 3 ? ldv(k + 1, 0) : ldk(0, 0);
+      SPP_GAP_A();
       SPP_PIN();
       oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[3], ph[k], oacc[1], 0, 0, 0);
+      SPP_PIN();
       n[1] = k < 3 ? ldv(k + 1, 1) : ldk(0, 1);
+      SPP_GAP_A();
       SPP_PIN();
       oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], pl[k], oacc[0], 0, 0, 0);
+      SPP_PIN();
       n[2] = k < 3 ? ldv(k + 1, 2) : ldk(0, 2);
+      SPP_GAP_A();
       SPP_PIN();
       oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], pl[k], oacc[1], 0, 0, 0);
+      SPP_PIN();
       n[3] = k < 3 ? ldv(k + 1, 3) : ldk(0, 3);
+      SPP_GAP_A();
       SPP_PIN();
       oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], ph[k], oacc[0], 0, 0, 0);
       SPP_PIN();
+      SPP_GAP_B();
+      SPP_PIN();
       oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], ph[k], oacc[1], 0, 0, 0);
+      SPP_PIN();
+      SPP_GAP_B();
       SPP_PIN();
 #pragma unroll
       for (int part = 0; part < 4; ++part) c[part] = n[part];
@@ -828,27 +854,41 @@ struct SplitAttnWave {
 #pragma unroll
     for (int ds = 0; ds < 4; ++ds) {
       sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[1], qh[ds], ds ? sacc[0] : zero, 0, 0, 0);
+      SPP_PIN();
       if (ds < 3) n[0] = ldk(ds + 1, 0);
+      SPP_GAP_A();
       SPP_PIN();
       sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[3], qh[ds], ds ? sacc[1] : zero, 0, 0, 0);
+      SPP_PIN();
       if (ds < 3) n[1] = ldk(ds + 1, 1);
+      SPP_GAP_A();
       SPP_PIN();
       sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], ql[ds], sacc[0], 0, 0, 0);
+      SPP_PIN();
       if (ds < 3) n[2] = ldk(ds + 1, 2);
+      SPP_GAP_A();
       SPP_PIN();
       sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], ql[ds], sacc[1], 0, 0, 0);
+      SPP_PIN();
       if (ds < 3) n[3] = ldk(ds + 1, 3);
+      SPP_GAP_A();
       SPP_PIN();
       sacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[0], qh[ds], sacc[0], 0, 0, 0);
+      SPP_PIN();
       if (ds == 0) dma();
+      SPP_GAP_B();
       SPP_PIN();
       sacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(c[2], qh[ds], sacc[1], 0, 0, 0);
+      SPP_PIN();
+      SPP_GAP_B();
       SPP_PIN();
       if (ds < 3) {
 #pragma unroll
         for (int part = 0; part < 4; ++part) c[part] = n[part];
       }
     }
+#undef SPP_GAP_A
+#undef SPP_GAP_B
 #undef SPP_PIN
   }
 };

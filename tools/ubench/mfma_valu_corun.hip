@@ -35,6 +35,20 @@ __global__ __launch_bounds__(512, 2) void k(float* out, long long* ticks, int it
           c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
           c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
         }
+      } else if constexpr (MFMA_KIND >= 2) {  // MFMA_KIND - 1 times `s_nop 7` behind every MFMA: the wave does not ask for the issue port while its MFMA runs
+#pragma unroll
+        for (int u = 0; u < 24; ++u) {
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int z = 0; z < MFMA_KIND - 1; ++z) asm volatile("s_nop 7");
+          __builtin_amdgcn_sched_barrier(0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(b, a, c1, 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int z = 0; z < MFMA_KIND - 1; ++z) asm volatile("s_nop 7");
+          __builtin_amdgcn_sched_barrier(0);
+        }
       } else {  // every pair of MFMAs takes a fresh b128 fragment from LDS (one step ahead), like the attention's matrix phase
         f16x8 f = *reinterpret_cast<const f16x8*>(L + (wave & 3) * 8192 + row * 256 + ((khh ^ (row & 15)) << 4));
 #pragma unroll
@@ -132,6 +146,11 @@ int main() {
   run<1>("(v_fma_f32, v_exp_f32) pairs", out, ticks, 5000);
   run<2>("v_fma_f32 over 64 registers", out, ticks, 5000);
   run<3>("softmax-like compiled code (count its VALU in the ISA)", out, ticks, 5000);
+  run<0, 2>("v_fma_f32 stream | 1 x s_nop 7 behind every MFMA", out, ticks, 5000);
+  run<0, 3>("v_fma_f32 stream | 2 x s_nop 7 behind every MFMA", out, ticks, 5000);
+  run<0, 4>("v_fma_f32 stream | 3 x s_nop 7 behind every MFMA", out, ticks, 5000);
+  run<3, 3>("softmax-like | 2 x s_nop 7 behind every MFMA", out, ticks, 5000);
+  run<3, 4>("softmax-like | 3 x s_nop 7 behind every MFMA", out, ticks, 5000);
   run<0, 1>("v_fma_f32 stream | MFMAs fed by LDS reads", out, ticks, 5000);
   run<3, 1>("softmax-like | MFMAs fed by LDS reads", out, ticks, 5000);
   return 0;
