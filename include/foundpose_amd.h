@@ -384,7 +384,9 @@ int fp_gemm_fp8(const void* A, int lda, const void* W, int ldw, int M, int N, in
 int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, const float* gamma,
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
 /* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, split-fp16 rows of scale in_scale) -> out [B*N, 2D] halves (scale out_scale);
- * out_dtype FP_F16X3: a split-fp16 row, FP_F16F8: an f16f8 row (the f16f8 mode's proj operand). */
+ * out_dtype FP_F16X3: a split-fp16 row, FP_F16F8: an f16f8 row (the f16f8 mode's proj operand); optionally OR-ed with FP_ATTN_VARIANT(v), test bits as in
+ * fp_attention: 0 = the kernel the pipeline runs (the lock-step kernel; the role-split one with FP_ATTN_SPLIT_PP=1 in the environment), 1 = the lock-step kernel,
+ * 2 = the role-split kernel (the two waves of a SIMD half a key tile apart; measured not faster, profiles/EXPERIMENTS.md section 0).  All bit-identical. */
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
                        int out_dtype, fp_stream_t stream);
 /* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes), FP_F16X3 (split row of y * out_scale) or FP_F16F8 (f16f8 row) */
