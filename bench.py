@@ -5,6 +5,7 @@ bank, one process per GPU.  Contract: see the task prompt / DESIGN.md "Measureme
   python bench.py                       # 1 GPU, finishes in a few minutes
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N ...          # no launcher: starts the line above itself (self_launch) and returns its exit code
 
 The workload is PLANTED (foundpose_amd/workload.py): every crop's fp32 features sit, with graded noise, in five
 consecutive templates of the bank, so the expected output of a step is known and the line carries index-agreement
@@ -76,6 +77,21 @@ def time_kernel(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
+def self_launch(n):
+    """Re-executes this script as `python -m torch.distributed.run --nnodes=1 --nproc-per-node n --master-addr 127.0.0.1 --master-port <free> bench.py
+    <same arguments>` (the driver's own launch line) and returns its exit code.  stdout / stderr are inherited: rank 0's JSON line is ours."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: what RCCL needs on this host driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -120,8 +136,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+        if world == 1 and args.gpus > 1 and "RANK" not in os.environ:
+            # `python bench.py --gpus N` without a launcher: start the N ranks ourselves (one process per GPU under torch.distributed.run on
+            # 127.0.0.1, a free port) and hand its exit code back; rank 0 of that job prints the one JSON line on our stdout.
+            sys.exit(self_launch(args.gpus))
+        sys.exit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus} (or with no launcher at all)")
     # FP_BENCH_ONE_DEVICE=1 (+ FP_BENCH_BACKEND=gloo): dry run of the multi-rank path on a single-GPU box -- every rank
     # uses cuda:0 and the records travel through host memory.  Never set by the driver; the real runs use RCCL.
     if os.environ.get("FP_BENCH_ONE_DEVICE") == "1":
@@ -235,7 +254,7 @@ def main():
     if args.skip_probes:
         if rank == 0:
             print(json.dumps({"metric": "detections/sec (ViT+kNN match) on 518^2 crops vs 10k-template bank", "value": round(det_per_s, 2), "unit": "detections/s",
-                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "probes": "skipped",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "probes": "skipped", "ranks_seen": ranks_seen,
                               **({"multi_gpu": multi} if multi is not None else {})}), flush=True)
         if world > 1:
             dist.barrier()

@@ -124,3 +124,24 @@ def test_gather_world2_gloo_ids_above_2_24_exact():
     assert want.max() > (1 << 24)
     for rank in range(world):
         assert np.array_equal(ret[rank][0], want)   # every rank holds every rank's ids, bit for bit
+
+
+def test_bench_self_launch_builds_the_drivers_launch_line(monkeypatch):
+    """`python bench.py --gpus N` with no launcher re-executes itself under torch.distributed.run (bench.self_launch): the command is the
+    driver's own launch line on 127.0.0.1 with this process's arguments, and its exit code is handed back."""
+    import subprocess
+    import sys
+    import bench
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen.update(cmd=cmd, env=env)
+        return 7
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    assert bench.self_launch(4) == 7
+    cmd, env = seen["cmd"], seen["env"]
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"

@@ -34,6 +34,21 @@ def test_bench_two_ranks_dry_run():
     assert d["config"]["tie_order"] == "torch" and d["parity"]["planted"]["planted_top1"] == 8
 
 
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with NO launcher (WORLD_SIZE unset): bench.py starts torch.distributed.run itself, rank 0 prints the one JSON line and
+    both ranks' records arrive in the gather -- a driver that calls the N > 1 run the way it calls N = 1 still gets a measurement."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(FP_BENCH_ONE_DEVICE="1", FP_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--templates", "600", "--batch", "8",
+           "--version", "vits14-reg", "--layer", "9", "--size", "224", "--skip-probes"]
+    out = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["ranks_seen"] == 2 and d["steps"] == 2 and d["value"] > 0
+
+
 def test_uneven_shards_through_the_real_engine():
     """37 detections over 2 ranks (shards of 19 and 18, cut inside an object group): the real FoundPoseEngine on each shard, then
     pack_result -> pad_records -> gather_records -> unpack_result; every gathered detection equals the single-process result bit for
