@@ -119,6 +119,7 @@ def main():
                          "fp32: the exact-fp32 MFMA mode) with its index agreement against oracle A and the fp32 mode")
     ap.add_argument("--parity-steps", type=int, default=5)
     ap.add_argument("--no-parity-fast", action="store_true", help="skip `parity_mode_fast` (the f16f8 mode timed next to the f16x3 parity mode)")
+    ap.add_argument("--no-mode-f16", action="store_true", help="skip `mode_f16` (the fp16-operand mode timed next to the bf16 headline)")
     ap.add_argument("--skip-probes", action="store_true", help="time the steps and stop: no roofline probe launches, no parity passes (tools/pmc_bench.sh: every "
                                                                 "launch the counters see then belongs to a step of the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -307,6 +308,19 @@ def main():
                "what": "as f16x3 with the two cross terms of every GEMM product (hi lo + lo hi, ~2^-11 of the product) on the fp8 MFMA: rows carry the fp16 high halves + e4m3 "
                        "copies of hi and lo, 8 instead of 12 fp16-MFMA units per 64 k (a product good to ~14 bits at the worst); q / k / v and the attention's own products stay "
                        "three-fp16-MFMA"}
+    # ... and the fp16-operand mode: the headline pipeline (same kernels, tiles, bytes) on IEEE fp16 operands, driver-timed the same way -> `mode_f16`
+    pm16, ex_pm16 = None, None
+    if args.precision == "bf16" and not args.no_mode_f16 and arch.dim % 128 == 0:
+        ex_pm16 = feature_util.make_feature_extractor(name, random_init_seed=1234, precision="f16").to(dev)
+        eng_pm16 = fe.FoundPoseEngine(ex_pm16, bank, 14.0, 5, 300, tie_order=args.tie_order)
+        step(eng_pm16)
+        step(eng_pm16)
+        el_16, (_, last_pm16) = timed(eng_pm16, args.steps)
+        pm16 = {"precision": "f16", "value": round(world * B * args.steps / el_16, 2), "unit": "detections/s", "ms_per_step": round(1e3 * el_16 / args.steps, 3),
+                "steps": args.steps, "n_gpus": world, "vs_headline": round(world * B * args.steps / el_16 / det_per_s, 4),
+                "what": "the headline pipeline -- folded LayerNorms, (hi, lo) residual stream, token-selected hooked block, the same kernel templates, tiles and operand bytes -- on "
+                        "IEEE fp16 operands (v_mfma_f32_32x32x16_f16: 11 significant bits per operand instead of bf16's 8), GELU in its erf form; an activation beyond "
+                        "+-65504 is reported, never silently wrong"}
     if rank == 0:
         n_tok = 1 + arch.registers + (args.size // 14) ** 2
         mv = B * n_tok
@@ -315,14 +329,17 @@ def main():
         # ---- roofline of the dominant kernel = the largest time bucket of a step: the LayerScale+residual GEMM template
         # (gemm_bf16_kernel<LS_RESID>), launched twice per block: attn.proj (K = D) and mlp.fc2 (K = hidden)
         fold = getattr(extractor, "fold_layernorm", False)   # bf16: the block LayerNorms live inside these GEMMs (fp_vit_model.ln_fold)
-        hilo = fold and os.environ.get("FP_RESID_HILO", "1") != "0"   # ... and the residual stream in front of the hooked block is a (hi, lo) bf16 pair
+        hilo = fold and (os.environ.get("FP_RESID_HILO", "1") != "0" or args.precision == "f16")   # ... and the residual stream in front of the hooked block is a (hi, lo) 16-bit pair
         from foundpose_amd._lib import call as _call, ptr as _ptr, stream as _stream
 
+        dt16 = torch.float16 if args.precision == "f16" else torch.bfloat16
+        f16_bit = (1 << 21) if args.precision == "f16" else 0   # FP_GEMM_F16
+
         def gemm_ms(n, k, epi):
-            a = torch.randn(M, k, device=dev).to(torch.bfloat16)
-            w = (torch.randn(n, k, device=dev) * 0.02).to(torch.bfloat16)
+            a = torch.randn(M, k, device=dev).to(dt16)
+            w = (torch.randn(n, k, device=dev) * 0.02).to(dt16)
             bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
-            out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else torch.bfloat16, device=dev)
+            out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else dt16, device=dev)
             if args.precision in ("f16x3", "f16f8"):   # split operands: the algorithmic FLOPs are those of the fp32 product
                 pack = ops.splitx_pack if args.precision == "f16f8" else ops.split16_pack
                 a3, w3 = pack(a.float(), 128.0, 64), pack(w.float(), ops.pow2_scale(w.float()), 64)
@@ -333,13 +350,13 @@ def main():
                 col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
                 return time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=out, epilogue=epi, m_valid=mv))
             if fold and epi == 3:   # the kernel the pipeline launches 36 times per step: the residual update on the (hi, lo) bf16 stream + LayerNorm row
-                xb = torch.zeros(M, n, dtype=torch.bfloat16, device=dev)   # sums (epilogue 8; FP_RESID_HILO=0: fp32 stream + bf16 copy, epilogue 7)
+                xb = torch.zeros(M, n, dtype=dt16, device=dev)   # sums (epilogue 8; FP_RESID_HILO=0: fp32 stream + bf16 copy, epilogue 7)
                 st = torch.zeros(n // 128, M, 2, device=dev)
                 if hilo:
-                    xl = torch.zeros(M, n, dtype=torch.bfloat16, device=dev)
-                    return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(xl), n, 8,
+                    xl = torch.zeros(M, n, dtype=dt16, device=dev)
+                    return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(xl), n, 8 | f16_bit,
                                                      None, None, _ptr(xb), n, _ptr(st), _stream()))
-                return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(out), n, 7,
+                return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(out), n, 7 | f16_bit,
                                                  None, None, _ptr(xb), n, _ptr(st), _stream()))
             if fold:                # ... and the normalising epilogues of qkv / fc1
                 cs, ln_row = torch.zeros(n, device=dev), torch.ones(M, 2, device=dev)
@@ -352,13 +369,13 @@ def main():
         fl = lambda n, k: 2.0 * mv * n * k     # algorithmic: valid rows only
         # attention of one block at the step's shape (all tokens as queries; the precision's own kernel), 4 N^2 d per (image, head)
         attn_info = None
-        if args.precision in ("bf16", "fp8", "f16x3", "f16f8"):
+        if args.precision in ("bf16", "f16", "fp8", "f16x3", "f16f8"):
             xq = torch.randn(M, 3 * arch.dim, device=dev)
             if args.precision in ("f16x3", "f16f8"):
                 pk = torch.cat([ops.split16_pack(xq[:, i * arch.dim:(i + 1) * arch.dim].contiguous(), 16.0) for i in range(3)], dim=1)
                 ms_attn = time_kernel(lambda: ops.attention_split(pk, B, n_tok, arch.dim, arch.heads, 16.0, 16.0))
             else:
-                xq16 = xq.to(torch.bfloat16)
+                xq16 = xq.to(dt16)
                 ms_attn = time_kernel(lambda: ops.attention(xq16, B, n_tok, arch.dim, arch.heads))
             attn_flops = 4.0 * B * n_tok * n_tok * arch.dim
             attn_info = {"kernel": "attn_split_kernel (three fp16 MFMAs per product; FLOPs of the fp32 product)" if args.precision in ("f16x3", "f16f8") else "attn_bf16_w64_kernel",
@@ -494,6 +511,9 @@ def main():
         lists_pmf = [last_pmf.corresp_list(b) for b in range(B)] if pmf is not None else None
         if pmf is not None:
             pmf["planted"] = workload.planted_stats(lists_pmf, wl.targets.tolist())
+        lists_pm16 = [last_pm16.corresp_list(b) for b in range(B)] if pm16 is not None else None
+        if pm16 is not None:
+            pm16["planted"] = workload.planted_stats(lists_pm16, wl.targets.tolist())
         if not args.no_parity:  # the library's fp32 mode on every detection of the batch (same bank, same tie order)
             eng32 = fe.FoundPoseEngine(ex32, bank, 14.0, 5, 300, tie_order=args.tie_order)
             res32 = eng32.infer_batch(images, masks, det_obj)
@@ -503,6 +523,8 @@ def main():
                 pm["vs_fp32_mode"] = workload.parity_stats(lists_pm, lists32)
             if pmf is not None:
                 pmf["vs_fp32_mode"] = workload.parity_stats(lists_pmf, lists32)
+            if pm16 is not None:
+                pm16["vs_fp32_mode"] = workload.parity_stats(lists_pm16, lists32)
         if not args.no_cpu_baseline and world == 1:  # the CPU baseline is timed at N = 1 only
             dbg = eng.infer_batch(images, masks, det_obj, keep_debug=True)   # one untimed step that keeps the visual-word ids (stage attribution)
             q_cnt = [int(masks[b, 7::14, 7::14].sum()) for b in range(B)]
@@ -516,6 +538,8 @@ def main():
                 pm["vs_oracle_a"] = workload.parity_stats(lists_pm[:len(ora)], ora)
             if pmf is not None:
                 pmf["vs_oracle_a"] = workload.parity_stats(lists_pmf[:len(ora)], ora)
+            if pm16 is not None:
+                pm16["vs_oracle_a"] = workload.parity_stats(lists_pm16[:len(ora)], ora)
         else:
             oracle_feats = None
         if world == 1 and not args.no_hard:
@@ -525,6 +549,8 @@ def main():
                 exs[args.parity_precision] = ex_pm
             if ex_pmf is not None:
                 exs["f16f8"] = ex_pmf
+            if ex_pm16 is not None:
+                exs["f16"] = ex_pm16
             parity["hard"] = hard_parity(args, wl, exs, oracle_feats, dict(batch=B, full_mask=full_mask, W_words=W_words, wpt=wpt, rank=rank, dev=dev))
         if pm is not None:  # north_star's index bar, stated as booleans next to the mode's throughput
             pm["index_exact_vs_oracle_a"] = ("vs_oracle_a" in pm and pm["vs_oracle_a"]["corresp_equal"] == pm["vs_oracle_a"]["slots_compared"]
@@ -536,6 +562,8 @@ def main():
                 if key in pmf:
                     pmf["index_exact_" + key] = pmf[key]["corresp_equal"] == pmf[key]["slots_compared"] and pmf[key]["templates_equal"] == pmf[key]["detections"]
             result["parity_mode_fast"] = pmf
+        if pm16 is not None:
+            result["mode_f16"] = pm16
         result["parity"] = parity
         if world == 1 and not args.no_latency:
             result["latency_b1"], result["pipeline"] = latency_and_pipeline(args, wl, bank, extractor, eng, result.get("cpu_baseline"))
@@ -546,6 +574,8 @@ def main():
                 del eng_pm, ex_pm, last_pm
             if pmf is not None:
                 del eng_pmf, ex_pmf, last_pmf
+            if pm16 is not None:
+                del eng_pm16, ex_pm16, last_pm16
             import gc
             gc.collect()
             torch.cuda.empty_cache()
@@ -865,11 +895,13 @@ def other_config(label, args, dev, rank, steps=5, parity_steps=3):
     ex = None
     gc.collect()
     torch.cuda.empty_cache()
-    for key, prec in (("parity_mode", "f16x3"), ("parity_mode_fast", "f16f8")):
+    for key, prec in (("mode_f16", "f16"), ("parity_mode", "f16x3"), ("parity_mode_fast", "f16f8")):
+        if prec == "f16" and args.no_mode_f16:
+            continue
         ex3 = feature_util.make_feature_extractor(name, state_dict=sd, precision=prec).to(dev)
-        v3, ms3, lists3 = run(ex3, parity_steps, 1)
+        v3, ms3, lists3 = run(ex3, steps if prec == "f16" else parity_steps, 2 if prec == "f16" else 1)
         st3 = workload.parity_stats(lists3, lists32)
-        out[key] = {"precision": prec, "value": v3, "unit": "detections/s", "ms_per_step": ms3, "steps": parity_steps,
+        out[key] = {"precision": prec, "value": v3, "unit": "detections/s", "ms_per_step": ms3, "steps": steps if prec == "f16" else parity_steps,
                     "planted": workload.planted_stats(lists3, wl.targets.tolist()), "vs_fp32_mode": st3,
                     "index_exact_vs_fp32_mode": st3["corresp_equal"] == st3["slots_compared"] and st3["templates_equal"] == st3["detections"]}
         ex3 = None

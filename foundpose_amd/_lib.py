@@ -14,10 +14,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # export the same ABI version.  Never a different implementation: there is one product path.
 LIB_PATH = os.environ.get("FOUNDPOSE_AMD_LIB") or os.path.join(_HERE, "lib", "libfoundpose_amd.so")
 
-FP_F32, FP_BF16, FP_FP8, FP_F16X3, FP_F16F8 = 0, 1, 2, 3, 4
+FP_F32, FP_BF16, FP_FP8, FP_F16X3, FP_F16F8, FP_F16 = 0, 1, 2, 3, 4, 5
 GEMM_SPLIT_F16F8 = 1 << 20   # FP_GEMM_SPLIT_F16F8 of the header
+GEMM_F16 = 1 << 21           # FP_GEMM_F16 of the header: IEEE fp16 operands / outputs in fp_gemm_bf16, fp_gemm_bf16_ln
 SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 

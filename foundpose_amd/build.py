@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 SO = os.path.join(LIBDIR, "libfoundpose_amd.so")
-SOURCES = ["api.cpp", "f32_tile.hip", "knn_cand.hip", "match.hip", "gemm_bf16.hip", "gemm_fp8.hip", "gemm_split.hip", "gemm_splitx.hip", "attn.hip", "vit.hip", "crop.hip", "pnp.hip"]
+SOURCES = ["api.cpp", "f32_tile.hip", "knn_cand.hip", "match.hip", "gemm_bf16.hip", "gemm_fp8.hip", "gemm_split.hip", "gemm_splitx.hip", "gemm_f16.hip", "attn.hip", "vit.hip", "crop.hip", "pnp.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "stl_order.hpp", "stl_wave.hpp", "gemm_bf16.hip", os.path.join("..", "..", "include", "foundpose_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value",
          # MFMA results feed VALU epilogues/softmax directly: keep accumulators in the VGPR half of the unified

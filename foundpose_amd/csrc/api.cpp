@@ -291,6 +291,7 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
                  const float* gamma, void* out, int ldo, int epilogue, fp_stream_t stream) {
   FP_REQUIRE(A && W && out, "fp_gemm_bf16: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;  // tuning bits: force the 128 or 256 block tile
+  const bool f16 = (epilogue >> 21) & 1;     // FP_GEMM_F16: IEEE fp16 operands and 16-bit outputs
   epilogue &= 0xff;
   FP_REQUIRE(tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16: bad tile override %d", tile);
 
@@ -303,13 +304,14 @@ int fp_gemm_bf16(const void* A, int lda, const void* W, int ldw, int M, int N, i
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = gamma; a.out = out; a.ldo = ldo;
   a.tile_override = tile;
-  return gemm_bf16_launch(epilogue, a, ST(stream));
+  return f16 ? gemm_f16_launch(epilogue, a, ST(stream)) : gemm_bf16_launch(epilogue, a, ST(stream));
 }
 
 int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias, void* out, int ldo,
                     int epilogue, const float* colsum, const float* ln_row, void* xb, int ld_xb, float* stats, fp_stream_t stream) {
   FP_REQUIRE(A && W && out && bias, "fp_gemm_bf16_ln: null pointer");
   const int tile = (epilogue >> 8) & 0xfff;
+  const bool f16 = (epilogue >> 21) & 1;     // FP_GEMM_F16: IEEE fp16 operands, 16-bit outputs and (hi, lo) stream
   epilogue &= 0xff;
   FP_REQUIRE(tile == 0 || tile == 64 || tile == 128 || tile == 256 || tile == 320, "fp_gemm_bf16_ln: bad tile override %d", tile);
   GemmBf16Args a;
@@ -330,7 +332,7 @@ int fp_gemm_bf16_ln(const void* A, int lda, const void* W, int ldw, int M, int N
     FP_REQUIRE(colsum && ln_row, "fp_gemm_bf16_ln: colsum and ln_row are required");
     a.colsum = colsum; a.ln_stats = reinterpret_cast<const float2*>(ln_row); a.ln_eps = 1e-6f;
   }
-  return gemm_bf16_launch(epilogue, a, ST(stream));
+  return f16 ? gemm_f16_launch(epilogue, a, ST(stream)) : gemm_bf16_launch(epilogue, a, ST(stream));
 }
 
 int fp_ln_finalize(const float* stats, int parts, int stats_stride, int rows, int dim, float eps, float* ln_row, fp_stream_t stream) {
@@ -498,8 +500,11 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   const bool f8 = m->weight_dtype == FP_DTYPE_FP8;  // e4m3 block matrices; activations and patch embed stay bf16
   const bool sx = m->weight_dtype == FP_DTYPE_F16F8;  // f16f8 rows (common.hpp): the split mode with the cross terms on the fp8 pipe
   const bool sp = m->weight_dtype == FP_DTYPE_F16X3 || sx;  // split-fp16 operands everywhere (near-exact modes): rows of 2 x halves
-  const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8;
-  const int adt = sx ? FP_DTYPE_F16F8 : (sp ? FP_DTYPE_F16X3 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32));
+  const bool h16 = m->weight_dtype == FP_DTYPE_F16;  // the "f16" mode: the bf16 pipeline (folded LayerNorms, (hi, lo) stream) on IEEE fp16 operands
+  const bool bf = m->weight_dtype == FP_DTYPE_BF16 || f8 || h16;
+  const int adt = sx ? FP_DTYPE_F16F8 : (sp ? FP_DTYPE_F16X3 : (h16 ? FP_DTYPE_F16 : (bf ? FP_DTYPE_BF16 : FP_DTYPE_F32)));
+  const int attn_dt = h16 ? FP_DTYPE_F16 : FP_DTYPE_BF16;
+  FP_REQUIRE(!h16 || m->ln_fold, "fp_vit_forward: weight_dtype FP_F16 runs the folded-LayerNorm pipeline only (ln_fold = 1, dim %% 128 == 0)");
   FP_REQUIRE(!sx || (D % 64 == 0 && m->hidden % 64 == 0 && m->patch_k_pad % 64 == 0), "fp_vit_forward: the f16f8 mode needs dim, hidden and patch_k_pad to be multiples of 64");
   const int em = sp ? 2 : 1;                          // stored elements per logical element of an operand row
   FP_REQUIRE(!sp || m->patch_acc_scale > 0.f, "fp_vit_forward: the f16x3 mode needs patch_acc_scale");
@@ -529,7 +534,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     g.W = reinterpret_cast<const __bf16*>(m->patch_w); g.ldw = m->patch_k_pad;
     g.M = ws->m_patch_pad; g.N = D; g.K = m->patch_k_pad; g.M_valid = Mp; g.bias = m->patch_b;
     g.out = ws->x; g.ldo = D; g.pos = m->pos_patch; g.tok_np = np; g.tok_n = ntok; g.tok_skip = 1 + m->registers;
-    TRY(gemm_bf16_launch(GEMM_EPI_TOKENS_F32, g, st));
+    TRY(h16 ? gemm_f16_launch(GEMM_EPI_TOKENS_F32, g, st) : gemm_bf16_launch(GEMM_EPI_TOKENS_F32, g, st));
   } else {
     F32TileArgs a = zero_tile_args();
     a.A = reinterpret_cast<const float*>(ws->patches); a.lda = m->patch_k_pad;
@@ -566,7 +571,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     FP_REQUIRE(ws->xb && ws->stats, "fp_vit_forward: ln_fold needs workspace xb and stats");
     FP_REQUIRE(D % 128 == 0, "fp_vit_forward: ln_fold needs dim %% 128 == 0");
     ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
-    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st, ws->xl));
+    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st, ws->xl, h16, ws->sat));
   }
   // Blocks in FRONT of the hooked one keep the residual stream as (hi, lo) bf16 arrays (ws->xb, ws->xl) instead of fp32 + a bf16 copy: the
   // residual GEMMs then read 4 and write 4 bytes per element instead of 4 + 6 (hi IS the next GEMM's A operand).  16 mantissa bits per update
@@ -586,7 +591,8 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
     if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; g.xl = reinterpret_cast<__bf16*>(ws->xl); }
-    return gemm_bf16_launch(epi, g, st);
+    g.sat = ws->sat;   // (read by the fp16 kernels only: overflow report of their 16-bit outputs)
+    return h16 ? gemm_f16_launch(epi, g, st) : gemm_bf16_launch(epi, g, st);
   };
 
   const int i_first = mode == VIT_LAST_SELECTED ? layer : 0, i_last = mode == VIT_PREFIX ? layer - 1 : layer;
@@ -603,9 +609,9 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
       AttnArgs as = at;
       as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;
-      TRY(attn_launch(as, FP_DTYPE_BF16, st));
+      TRY(attn_launch(as, attn_dt, st));
       float* xs = reinterpret_cast<float*>(ws->qkv);  // qkv is dead after the attention: [num_sel, D] fp32 rows of the stream
-      if (hilo && layer > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, sel->rows, sel->num, D, xs, st));   // the blocks in front left (hi, lo) pairs
+      if (hilo && layer > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, sel->rows, sel->num, D, xs, st, h16));   // the blocks in front left (hi, lo) pairs
       else TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xs, st));
       rows_valid = sel->num;
       rows_pad = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
@@ -623,10 +629,10 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
       const bool pair = hilo && i < layer;            // a block in front of the hooked one: (hi, lo) stream
       const int resid = pair ? GEMM_EPI_RESID_HILO : GEMM_EPI_RESID_F32;
-      if (hilo && i == layer && i > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, nullptr, Mtok, D, ws->x, st));   // VIT_FULL: the hooked block's fp32 stream, all rows
+      if (hilo && i == layer && i > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, nullptr, Mtok, D, ws->x, st, h16));   // VIT_FULL: the hooked block's fp32 stream, all rows
       TRY(finalize());
       TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
-      TRY(attn_launch(at, FP_DTYPE_BF16, st));
+      TRY(attn_launch(at, attn_dt, st));
       TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, resid, nullptr, true));
       // x += ls2 * fc2(act(fc1(ln2(x))))
       TRY(finalize());

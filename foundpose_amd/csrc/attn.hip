@@ -243,7 +243,9 @@ typedef __attribute__((address_space(3))) void lds_void_t;
 // PF (variant 4, measurement): the NEXT tile's eight K fragments are read into registers under the current tile's P V MFMAs (its DMA was
 // issued at the top of this tile and has landed by then: the compiler drains vmcnt before the first transpose read anyway; one extra
 // barrier publishes the other waves' pieces), so the next tile's score MFMAs start without waiting for LDS.  Same arithmetic.
-template <int QB, int NW = 8 / QB, bool PF = false>
+// H16 ("f16" mode): q | k | v, P and the output are IEEE fp16 instead of bf16 (v_mfma_f32_32x32x16_f16; p <= 2^8 and a convex combination of v rows
+// both fit the format); everything else -- layouts, schedule, fp32 online softmax -- is shared.
+template <int QB, int NW = 8 / QB, bool PF = false, bool H16 = false>
 __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
   constexpr int QBLK = NW * 32 * QB, GW = 8 / NW;
   __shared__ __attribute__((aligned(16))) char KV[2][2][8192];  // [stage][K | V]
@@ -398,7 +400,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
-            sacc[qb][ks] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[qb][ds], sacc[qb][ks], 0, 0, 0);
+            sacc[qb][ks] = mfma_h<H16>(kf, qf[qb][ds], sacc[qb][ks]);
         }
 #if !defined(FP_ATTN_NO_LDS) && defined(FP_ATTN_TR_ASM)
       // (-DFP_ATTN_TR_ASM, measured and NOT the default.)  The tile's eight V^T fragments issued HERE (they land under the softmax)
@@ -482,8 +484,8 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
           for (int kk = 0; kk < 2; ++kk) {
             const int r0 = 8 * kk;
             // eight consecutive keys per lane and 16-key step (the K rows' order): P is packed where it is, no cross-lane exchange
-            pf[qb][ks * 2 + kk] = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16x2(sacc[qb][ks][r0 + 0], sacc[qb][ks][r0 + 1]), pack_bf16x2(sacc[qb][ks][r0 + 2], sacc[qb][ks][r0 + 3]),
-                                                                         pack_bf16x2(sacc[qb][ks][r0 + 4], sacc[qb][ks][r0 + 5]), pack_bf16x2(sacc[qb][ks][r0 + 6], sacc[qb][ks][r0 + 7])));
+            pf[qb][ks * 2 + kk] = __builtin_bit_cast(bf16x8, make_uint4(pack_h2<H16>(sacc[qb][ks][r0 + 0], sacc[qb][ks][r0 + 1]), pack_h2<H16>(sacc[qb][ks][r0 + 2], sacc[qb][ks][r0 + 3]),
+                                                                         pack_h2<H16>(sacc[qb][ks][r0 + 4], sacc[qb][ks][r0 + 5]), pack_h2<H16>(sacc[qb][ks][r0 + 6], sacc[qb][ks][r0 + 7])));
           }
       }
       // ---- O^T += V^T P^T over 4 steps of 16 keys; one V^T fragment serves both query blocks
@@ -528,7 +530,7 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #endif
 #pragma unroll
           for (int qb = 0; qb < QC; ++qb)
-            oacc[qb][dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[qb][kstep], oacc[qb][dt], 0, 0, 0);
+            oacc[qb][dt] = mfma_h<H16>(vf, pf[qb][kstep], oacc[qb][dt]);
         }
     }
 #ifndef FP_ATTN_NO_BARRIER  // (measurement builds: no per-tile wait + barrier; only meaningful together with FP_ATTN_NO_DMA)
@@ -584,10 +586,10 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const int g0 = 2 * j, g1 = 2 * j + 1;
-            const unsigned x0 = pack_bf16x2(oacc[qb][dt][4 * g0 + 0] * inv, oacc[qb][dt][4 * g0 + 1] * inv);
-            const unsigned x1 = pack_bf16x2(oacc[qb][dt][4 * g0 + 2] * inv, oacc[qb][dt][4 * g0 + 3] * inv);
-            const unsigned y0 = pack_bf16x2(oacc[qb][dt][4 * g1 + 0] * inv, oacc[qb][dt][4 * g1 + 1] * inv);
-            const unsigned y1 = pack_bf16x2(oacc[qb][dt][4 * g1 + 2] * inv, oacc[qb][dt][4 * g1 + 3] * inv);
+            const unsigned x0 = pack_h2<H16>(oacc[qb][dt][4 * g0 + 0] * inv, oacc[qb][dt][4 * g0 + 1] * inv);
+            const unsigned x1 = pack_h2<H16>(oacc[qb][dt][4 * g0 + 2] * inv, oacc[qb][dt][4 * g0 + 3] * inv);
+            const unsigned y0 = pack_h2<H16>(oacc[qb][dt][4 * g1 + 0] * inv, oacc[qb][dt][4 * g1 + 1] * inv);
+            const unsigned y1 = pack_h2<H16>(oacc[qb][dt][4 * g1 + 2] * inv, oacc[qb][dt][4 * g1 + 3] * inv);
             const auto s0 = __builtin_amdgcn_permlane32_swap(x0, y0, false, false);  // lanes < 32: {own x, partner's x}; >= 32: {partner's y, own y}
             const auto s1 = __builtin_amdgcn_permlane32_swap(x1, y1, false, false);
             if (q < NQ) *reinterpret_cast<uint4*>(o + dt * 32 + 16 * j + 8 * kh) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
@@ -1493,7 +1495,10 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
   AttnArgs a = a_in;
   FP_REQUIRE(a.dim % 64 == 0 && a.heads * 64 == a.dim, "attention: head_dim must be 64 (dim %d heads %d)", a.dim, a.heads);
   FP_REQUIRE(a.n_tok >= 1 && a.batch >= 1, "attention: empty problem");
-  if (dtype == FP_DTYPE_BF16) {
+  if (dtype == FP_DTYPE_BF16 || dtype == FP_DTYPE_F16) {
+    const bool h16 = dtype == FP_DTYPE_F16;   // IEEE fp16 q | k | v and output (the "f16" mode): the default work split only
+    FP_REQUIRE(!h16 || (a.variant == 0 && a.out_fp8_scale <= 0.f && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull),
+               "attention(f16): the default kernel only (no work-split variants, no fp8 output), one image's qkv rows within 4 GiB");
     FP_REQUIRE(a.ld_qkv % 8 == 0 && (a.out_fp8_scale > 0.f ? a.ld_out % 4 == 0 : a.ld_out % 8 == 0), "attention(bf16): leading dims must keep 16-byte alignment");
     FP_REQUIRE(a.variant >= 0 && a.variant <= 4, "attention: unknown kernel variant %d", a.variant);
 #ifdef FP_ATTN_DEFAULT_VARIANT  // (measurement build for same-box A/B runs of the whole pipeline: that split where 0 was asked for)
@@ -1517,6 +1522,7 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
       if (variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, true>), dim3(grid), dim3(256), 0, st, a);
       else if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
+      else if (h16) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);

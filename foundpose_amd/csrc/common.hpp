@@ -72,14 +72,39 @@ FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(p, bf16x2));  // v_cvt_pk_bf16_f32 (RNE)
 }
 
+// ---- the two 16-bit operand formats of the single-pass ViT pipeline: bf16 (H16 = false: precision "bf16") and IEEE fp16 (H16 = true: precision
+// "f16" -- the same MFMA rate and the same bytes, 11 significant bits instead of 8, range +-65504 instead of +-3e38).  The fp16 conversion is
+// v_cvt_pk_f16_f32 (round to nearest even, subnormals kept, a value beyond the range becomes inf): producers of fp16 rows keep the running maximum
+// of what they packed and report through the saturation counter (slot 0) -- nothing is clamped, a reported batch is simply not usable.
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
+FP_DEVICE unsigned pack_f16x2(float lo, float hi) {
+  f32x2 p = {lo, hi};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(p, f16x2));
+}
+template <bool H16> FP_DEVICE unsigned pack_h2(float lo, float hi) {
+  if constexpr (H16) return pack_f16x2(lo, hi);
+  else return pack_bf16x2(lo, hi);
+}
+template <bool H16> FP_DEVICE unsigned pack_h2(float lo, float hi, float& amax) {   // ... with the running maximum an fp16 producer reports
+  if constexpr (H16) amax = nanmax3(amax, fabsf(lo), fabsf(hi));
+  return pack_h2<H16>(lo, hi);
+}
+template <bool H16> FP_DEVICE f32x2 unpack_h2(unsigned w) {   // the two 16-bit elements of a dword as fp32 (exact)
+  if constexpr (H16) return __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);
+  else return f32x2{__uint_as_float(w << 16), __uint_as_float(w & 0xffff0000u)};
+}
+template <bool H16> FP_DEVICE f32x16 mfma_h(bf16x8 a, bf16x8 b, f32x16 c) {   // 32x32x16, operands as raw 16-byte fragments of either format
+  if constexpr (H16) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
 // ---- split-fp16 operands of the f16x3 mode (near-exact fp32 products on the fp16 MFMA).
 // A logical fp32 row x[0..K) (K % 32 == 0) is stored as 2K halves: group g = k / 32 holds hi(x[32g .. 32g+31]) in halves
 // [64g, 64g + 32) and lo(...) in [64g + 32, 64g + 64), with hi = f16(s x), lo = f16(s x - hi) (round to nearest even, s a
 // power-of-two scale so that typical magnitudes sit well inside the fp16 normal range; saturating at +-65504).  hi + lo
 // carries 22 mantissa bits of s x; the product of two such operands is accumulated as hi*hi + hi*lo + lo*hi in fp32
 // (the dropped lo*lo term is <= 2^-22 relative).
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
-typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 FP_DEVICE void split16_pack2(float a, float b, float scale, unsigned& hi, unsigned& lo) {
   a = __builtin_amdgcn_fmed3f(a * scale, -65504.f, 65504.f);
   b = __builtin_amdgcn_fmed3f(b * scale, -65504.f, 65504.f);

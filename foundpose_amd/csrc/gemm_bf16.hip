@@ -142,9 +142,13 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // and a 128-B tile [e4m3(hi 2^-7) x 64 | e4m3(lo 2^4) x 64] consumed by two 64-wide fp8 MFMAs (lo_w * hi_a, hi_w * lo_a; block scale 2^3 on one
 // operand) -- 8 instead of 12 fp16-MFMA units per 64 k at the same operand bytes.  The GELU / SwiGLU outputs (the next GEMM's A operand) leave as
 // f16f8 rows; the BIAS output (q | k | v for the attention kernel) stays a split-fp16 row.
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false>
+// H16 ("f16" mode): the bf16 kernel on IEEE fp16 operands -- v_mfma_f32_32x32x16_f16, fp16 outputs of the 16-bit epilogues and of the (hi, lo) residual stream
+// (common.hpp pack_h2 / unpack_h2), GELU in the erf form at fp32 accuracy (the polynomial of the bf16 epilogue is good to 1.7e-4: below a bf16 half-ulp,
+// not below an fp16 one); overflow of an fp16 output (|v| > 65504 -> inf) is reported through a.sat, slot 0.
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   static_assert(!SX || SP, "f16f8 rows are a form of the split operands");
+  static_assert(!H16 || (!F8 && !SP), "plain fp16 operands exclude the fp8 and the split forms");
   static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
   static_assert(!(SP && F8) && (!SPOUT || SP), "split-fp16 and fp8 operands exclude each other; a split output needs split operands");
   static_assert(SPOUT == (SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "f16x3: the half-precision epilogues write split rows");
@@ -402,7 +406,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[j], af[i], acc[i][j], 0, 0, 0);
+              acc[i][j] = mfma_h<H16>(wf[j], af[i], acc[i][j]);
         }
       }
         }
@@ -533,7 +537,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             v0 *= gm.x; v1 *= gm.y; v2 *= gm.z; v3 *= gm.w;
           }
           if constexpr (EPI == GEMM_EPI_GELU_BF16) {
-            if constexpr (SP) {  // the erf form at fp32 accuracy: this mode does not approximate below the arithmetic it emulates
+            if constexpr (SP || H16) {  // the erf form at fp32 accuracy: these modes do not approximate below the arithmetic they emulate / the rounding of their output
 #ifdef FP_SPLIT_GELU_OCML   // (measurement build: ocml's erff, the round-3 epilogue)
               v0 = 0.5f * v0 * (1.f + erff(v0 * 0.70710678118654752440f)); v1 = 0.5f * v1 * (1.f + erff(v1 * 0.70710678118654752440f));
               v2 = 0.5f * v2 * (1.f + erff(v2 * 0.70710678118654752440f)); v3 = 0.5f * v3 * (1.f + erff(v3 * 0.70710678118654752440f));
@@ -570,7 +574,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               *reinterpret_cast<unsigned*>(sp) = hi;
               *reinterpret_cast<unsigned*>(sp + 64) = lo;
             } else if constexpr (F8OUT) *reinterpret_cast<unsigned short*>(srow + (col >> 1)) = (unsigned short)pack_fp8x4(h0 * a.out_scale, h1 * a.out_scale, 0.f, 0.f, band_amax);
-            else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_bf16x2(h0, h1);
+            else *reinterpret_cast<unsigned*>(srow + (col >> 1) * 2) = pack_h2<H16>(h0, h1, band_amax);
           } else if constexpr (SPOUT && SX && EPI != GEMM_EPI_BIAS_BF16) {
             unsigned h01, p01, h23, p23;
             splitx_pack2(v0, v1, a.out_scale, h01, p01, band_amax);
@@ -585,9 +589,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
             *reinterpret_cast<uint2*>(sp + 64) = make_uint2(l01, l23);
           } else if constexpr (OUT_F32) *reinterpret_cast<float4*>(srow + col * 4) = make_float4(v0, v1, v2, v3);
           else if constexpr (F8OUT) *reinterpret_cast<unsigned*>(srow + col) = pack_fp8x4(v0 * a.out_scale, v1 * a.out_scale, v2 * a.out_scale, v3 * a.out_scale, band_amax);
-          else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+          else *reinterpret_cast<uint2*>(srow + col * 2) = make_uint2(pack_h2<H16>(v0, v1, band_amax), pack_h2<H16>(v2, v3, band_amax));
         }
-      if constexpr (SPOUT || F8OUT) {
+      if constexpr (SPOUT || F8OUT || (H16 && !OUT_F32)) {
         if (m < a.M_valid) sat_amax = nanmax3(sat_amax, band_amax, 0.f);  // padding rows (computed, never stored) do not report
       }
       __syncthreads();
@@ -607,10 +611,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           float s1 = 0.f, s2 = 0.f;
   #pragma unroll
           for (int q = 0; q < 4; ++q) {   // x = hi + lo (exact in fp32: lo lies within 2^-9 of hi's last place), x' = x + (acc + bias)
-            v[2 * q] += __uint_as_float(hw[q] << 16) + __uint_as_float(lw[q] << 16);
-            v[2 * q + 1] += __uint_as_float(hw[q] & 0xffff0000u) + __uint_as_float(lw[q] & 0xffff0000u);
-            ho[q] = pack_bf16x2(v[2 * q], v[2 * q + 1]);
-            lo[q] = pack_bf16x2(v[2 * q] - __uint_as_float(ho[q] << 16), v[2 * q + 1] - __uint_as_float(ho[q] & 0xffff0000u));
+            const f32x2 xh = unpack_h2<H16>(hw[q]), xlo = unpack_h2<H16>(lw[q]);
+            v[2 * q] += xh[0] + xlo[0];
+            v[2 * q + 1] += xh[1] + xlo[1];
+            ho[q] = pack_h2<H16>(v[2 * q], v[2 * q + 1], sat_amax);   // (live rows only: padding rows `continue` above)
+            const f32x2 nh = unpack_h2<H16>(ho[q]);
+            lo[q] = pack_h2<H16>(v[2 * q] - nh[0], v[2 * q + 1] - nh[1]);
             s1 += v[2 * q] + v[2 * q + 1];
             s2 += fmaf(v[2 * q], v[2 * q], v[2 * q + 1] * v[2 * q + 1]);
           }
@@ -643,7 +649,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.out) + orow_it * a.ldo + n0 + c * 4) = v;
           if constexpr (EPI == GEMM_EPI_RESID_F32 && !F8) {
             if (a.xb) {  // the next GEMM's A operand + this tile's share of the row's LayerNorm statistics
-              *reinterpret_cast<uint2*>(a.xb + orow_it * a.ld_xb + n0 + c * 4) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+              *reinterpret_cast<uint2*>(a.xb + orow_it * a.ld_xb + n0 + c * 4) = make_uint2(pack_h2<H16>(v.x, v.y, sat_amax), pack_h2<H16>(v.z, v.w, sat_amax));
               // partial sums over 128-column groups -- 32 lanes x float4, the same tree whatever the tile width, so a row's
               // statistics (and everything downstream) do not depend on which tile shape the batch size selects.  DPP adds
               // (VALU rate): the ds_bpermute chain of __shfl_xor cost 24 k cycles per tile here.
@@ -657,7 +663,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       }
       if (!TWO_SLABS && tm + 1 < TM) __syncthreads();
     }
-    if constexpr (SPOUT) report_saturation(a.sat, 0, sat_amax, FP_F16_MAX);
+    if constexpr (SPOUT || H16) report_saturation(a.sat, 0, sat_amax, FP_F16_MAX);
     if constexpr (F8OUT) report_saturation(a.sat, 1, sat_amax, FP_E4M3_MAX);
     } else {
     float4 bias[TN][4], gam[TN][4];
@@ -711,7 +717,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
               const f32x2 g01 = gelu_pk(f32x2{v0, v1}), g23 = gelu_pk(f32x2{v2, v3});
               v0 = g01[0]; v1 = g01[1]; v2 = g23[0]; v3 = g23[1];
             }
-            uint2 pk = make_uint2(pack_bf16x2(v0, v1), pack_bf16x2(v2, v3));
+            uint2 pk = make_uint2(pack_h2<H16>(v0, v1), pack_h2<H16>(v2, v3));
             *reinterpret_cast<uint2*>(reinterpret_cast<__bf16*>(a.out) + out_row * a.ldo + n) = pk;
           } else if constexpr (EPI == GEMM_EPI_LS_RESID_F32) {
             const float4 gm = gam[tn][g];
@@ -757,7 +763,7 @@ static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
   return {0, 0};
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   // M is padded to whole tiles of every shape in use; tiles of padding rows only are not launched (they would all sit at the end of the
@@ -778,8 +784,8 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   }
   const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
   static FpDeviceOnce attr;
-  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX>, (int)lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16>, (int)lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
@@ -808,7 +814,7 @@ static bool tall_tile_wins(const GemmBf16Args& a) {
 
 // Tile selection: 256x256 (8 waves, 1 block/CU, 128 KiB LDS) when the shape allows it and fills the chip,
 // otherwise 128x128 (4 waves, 2 blocks/CU).
-template <int EPI, bool SP = false, bool SPOUT = false, bool SX = false>
+template <int EPI, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
 int launch(const GemmBf16Args& a, hipStream_t st) {
   const int force = a.tile_override;
   const bool big_ok = a.M % 256 == 0 && a.N % 256 == 0;
@@ -820,25 +826,25 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   //  2064 = 8 x 256 + 16 -- as 128^2 tiles in a second launch: 334 vs 289 us; a dependent second launch costs its own latency.)
   if constexpr (!SP && (EPI == GEMM_EPI_BIAS_BF16 || EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_RESID_HILO)) {
     if ((force == 320 && a.M % 320 == 0 && a.N % 256 == 0) || (force == 0 && use_big && tall_tile_wins(a)))
-      return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT>(a, st);
+      return launch_cfg<EPI, 320, 256, 2, 4, false, false, SP, SPOUT, false, H16>(a, st);
   }
-  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT, SX>(a, st);
+  if (use_big) return launch_cfg<EPI, 256, 256, 2, 4, false, false, SP, SPOUT, SX, H16>(a, st);
   // Small M (a batch of one or two crops -- the reference loop's shape, one detection at a time, scripts/infer.py:368): the N = D outputs (proj,
   // fc2) are 12 x 8 = 96 tiles of 128^2 at B = 1 and leave 160 of the 256 CUs idle through fc2's 64 K-tiles (43 us per launch, the largest
   // bucket of a B = 1 forward).  64 x 128 tiles double the count; same k order per output element -> the same bits.
   if constexpr (!SP && (EPI == GEMM_EPI_RESID_HILO || EPI == GEMM_EPI_RESID_F32 || EPI == GEMM_EPI_LS_RESID_F32)) {
     const int tiles_128 = (a.M_valid > 0 ? (a.M_valid + 127) / 128 : a.M / 128) * (a.N / 128);
     if ((force == 64 && a.M % 64 == 0) || (force == 0 && a.M % 64 == 0 && tiles_128 <= cus / 2))
-      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT>(a, st);
+      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT, false, H16>(a, st);
   }
-  return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT, SX>(a, st);
+  return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT, SX, H16>(a, st);
 }
 
 }  // namespace
 
 // The kernel template above is instantiated by four translation units so that no single compile holds every instantiation (the one-file build
-// ran out of memory): gemm_bf16.hip (bf16 operands), gemm_fp8.hip (-> FP_GEMM_TU == 2), gemm_split.hip (-> 3), gemm_splitx.hip (-> 4); the latter three
-// are one-line files that define FP_GEMM_TU and include this one.
+// ran out of memory): gemm_bf16.hip (bf16 operands), gemm_fp8.hip (-> FP_GEMM_TU == 2), gemm_split.hip (-> 3), gemm_splitx.hip (-> 4), gemm_f16.hip (-> 5);
+// the latter four are one-line files that define FP_GEMM_TU and include this one.
 #ifndef FP_GEMM_TU
 #define FP_GEMM_TU 1
 #endif
@@ -906,29 +912,37 @@ int gemm_splitx_launch(int epi, const GemmBf16Args& a_in, hipStream_t st) {
 }
 #endif  // FP_GEMM_TU == 3 || 4
 
+#if FP_GEMM_TU == 1 || FP_GEMM_TU == 5
+// TU 1: bf16 operands (gemm_bf16_launch); TU 5 (gemm_f16.hip): the same kernels on IEEE fp16 operands (gemm_f16_launch, the "f16" mode)
 #if FP_GEMM_TU == 1
+#define L(EPI) launch<EPI>(a, st)
 int gemm_bf16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
+#else
+#define L(EPI) launch<EPI, false, false, false, true>(a, st)
+int gemm_f16_launch(int epi, const GemmBf16Args& a, hipStream_t st) {
+#endif
   FP_REQUIRE(a.M > 0 && a.M % 128 == 0, "gemm_bf16: M (%d) must be a positive multiple of 128 (pad the activation buffer)", a.M);
   FP_REQUIRE(a.N > 0 && a.N % 128 == 0, "gemm_bf16: N (%d) must be a multiple of 128", a.N);
   FP_REQUIRE(a.K > 0 && a.K % BK == 0, "gemm_bf16: K (%d) must be a multiple of %d", a.K, BK);
   FP_REQUIRE(a.bias != nullptr, "gemm_bf16: bias is required (pass zeros)");
   FP_REQUIRE(a.lda % 8 == 0 && a.ldw % 8 == 0 && a.ldo % 4 == 0, "gemm_bf16: leading dims must keep 16-byte alignment");
   switch (epi) {
-    case GEMM_EPI_BIAS_BF16: return launch<GEMM_EPI_BIAS_BF16>(a, st);
-    case GEMM_EPI_GELU_BF16: return launch<GEMM_EPI_GELU_BF16>(a, st);
-    case GEMM_EPI_LS_RESID_F32: return launch<GEMM_EPI_LS_RESID_F32>(a, st);
-    case GEMM_EPI_RESID_F32: return launch<GEMM_EPI_RESID_F32>(a, st);
+    case GEMM_EPI_BIAS_BF16: return L(GEMM_EPI_BIAS_BF16);
+    case GEMM_EPI_GELU_BF16: return L(GEMM_EPI_GELU_BF16);
+    case GEMM_EPI_LS_RESID_F32: return L(GEMM_EPI_LS_RESID_F32);
+    case GEMM_EPI_RESID_F32: return L(GEMM_EPI_RESID_F32);
     case GEMM_EPI_RESID_HILO:
       FP_REQUIRE(a.xb && a.xl && a.stats_out && a.N % 128 == 0 && a.ld_xb >= a.N, "gemm_bf16: the (hi, lo) residual epilogue needs xb, xl, stats and N %% 128 == 0");
       // a lane moves 8 bf16 (16 bytes) of xb and of xl per access
       FP_REQUIRE(a.ld_xb % 8 == 0 && reinterpret_cast<uintptr_t>(a.xb) % 16 == 0 && reinterpret_cast<uintptr_t>(a.xl) % 16 == 0,
                  "gemm_bf16: the (hi, lo) residual epilogue needs 16-byte aligned xb / xl and a row stride that is a multiple of 8 elements (ld_xb = %d)", a.ld_xb);
-      return launch<GEMM_EPI_RESID_HILO>(a, st);
-    case GEMM_EPI_TOKENS_F32: return launch<GEMM_EPI_TOKENS_F32>(a, st);
-    case GEMM_EPI_BIAS_F32: return launch<GEMM_EPI_BIAS_F32>(a, st);
-    case GEMM_EPI_SWIGLU_BF16: return launch<GEMM_EPI_SWIGLU_BF16>(a, st);
+      return L(GEMM_EPI_RESID_HILO);
+    case GEMM_EPI_TOKENS_F32: return L(GEMM_EPI_TOKENS_F32);
+    case GEMM_EPI_BIAS_F32: return L(GEMM_EPI_BIAS_F32);
+    case GEMM_EPI_SWIGLU_BF16: return L(GEMM_EPI_SWIGLU_BF16);
   }
   fp_set_error("gemm_bf16: unknown epilogue %d", epi);
   return FP_ERR_INVALID;
 }
-#endif  // FP_GEMM_TU == 1
+#undef L
+#endif  // FP_GEMM_TU == 1 || 5

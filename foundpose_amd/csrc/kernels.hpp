@@ -158,9 +158,13 @@ int gemm_split_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 // the GELU / SwiGLU outputs are f16f8 rows, the BIAS output (q | k | v) stays a split-fp16 row for the attention kernel
 int gemm_splitx_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
+// "f16" mode: gemm_bf16_launch's kernels with IEEE fp16 operands and fp16 outputs behind the __bf16 pointers (A, W, out of the 16-bit epilogues, xb / xl
+// of the residual epilogues); v_mfma_f32_32x32x16_f16, the exact-erf GELU; a.sat (may be null) receives the overflow report of the fp16 outputs
+int gemm_f16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 
 // ---------------------------------------------------------------- dtypes of the C ABI
-enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2, FP_DTYPE_F16X3 = 3, FP_DTYPE_F16F8 = 4 };   // F16F8: common.hpp "f16f8 rows"
+enum : int { FP_DTYPE_F32 = 0, FP_DTYPE_BF16 = 1, FP_DTYPE_FP8 = 2, FP_DTYPE_F16X3 = 3, FP_DTYPE_F16F8 = 4,   // F16F8: common.hpp "f16f8 rows"
+             FP_DTYPE_F16 = 5 };   // plain IEEE fp16 rows: the "f16" mode = the bf16 pipeline (same kernels, same bytes) on fp16 operands
 
 // ---------------------------------------------------------------- attn.hip
 struct AttnArgs {
@@ -206,9 +210,9 @@ int query_select_launch(const unsigned char* masks, int B, int H, int W, const i
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);
 int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st,
-                         void* xl = nullptr);   // xl: also write lo = bf16(x - bf16(x)) (row stride ld_xb)
+                         void* xl = nullptr, bool h16 = false, int* sat = nullptr);   // xl: also write lo = bf16(x - bf16(x)) (row stride ld_xb); h16: fp16 instead of bf16
 // out[r] = float(xb[row]) + float(xl[row]) (fp32 [n, dim]); row = rows[r], or r when rows is null: the (hi, lo) stream back as fp32
-int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st);
+int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st, bool h16 = false);
 
 int patchify_launch(const float* images, int batch, int height, int width, int patch, void* out, int ld_out,
                     int out_dtype, hipStream_t st, float out_scale = 1.f);  // out_scale: FP_DTYPE_F16X3 rows only

@@ -103,12 +103,16 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
           __bf16* o = reinterpret_cast<__bf16*>(a.out) + (size_t)row * a.ld_out + c;
           if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_bf16x2(y[0], y[1]), pack_bf16x2(y[2], y[3]));
           else *reinterpret_cast<unsigned*>(o) = pack_bf16x2(y[0], y[1]);
+        } else if (a.out_dtype == FP_DTYPE_F16) {   // plain fp16 row (the "f16" mode's operand format)
+          _Float16* o = reinterpret_cast<_Float16*>(a.out) + (size_t)row * a.ld_out + c;
+          if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_h2<true>(y[0], y[1], amax), pack_h2<true>(y[2], y[3], amax));
+          else *reinterpret_cast<unsigned*>(o) = pack_h2<true>(y[0], y[1], amax);
         } else {
           *reinterpret_cast<vec_t*>(reinterpret_cast<float*>(a.out) + (size_t)row * a.ld_out + c) = y;
         }
       }
   }
-  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8 || a.out_dtype == FP_DTYPE_F16) report_saturation(a.sat, 0, amax, FP_F16_MAX);
   else if (a.out_dtype == FP_DTYPE_FP8) report_saturation(a.sat, 1, amax, FP_E4M3_MAX);
 }
 
@@ -366,6 +370,7 @@ __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __re
   }
   if constexpr (OUT == 0) reinterpret_cast<float*>(out)[(size_t)row * ld + col] = v;
   else if constexpr (OUT == 1) reinterpret_cast<__bf16*>(out)[(size_t)row * ld + col] = (__bf16)v;
+  else if constexpr (OUT == 4) reinterpret_cast<_Float16*>(out)[(size_t)row * ld + col] = (_Float16)v;   // plain fp16 rows (the "f16" mode)
   else if constexpr (OUT == 3) {
     unsigned h, p8;
     splitx_pack2(v, 0.f, scale, h, p8);
@@ -384,26 +389,29 @@ __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __re
 
 // Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
 // LayerScale GEMM has produced yet.  One wave per row; slot 0 of the partial-sum table gets the whole row, the others zero.
+// H16: the 16-bit arrays are IEEE fp16 (the "f16" mode) instead of bf16; an element beyond +-65504 is reported through sat[0].
+template <bool H16>
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, int rows, int dim, __bf16* __restrict__ xb, int ld_xb,
-                                                            float2* __restrict__ stats, int stats_stride, int parts, __bf16* __restrict__ xl) {
+                                                            float2* __restrict__ stats, int stats_stride, int parts, __bf16* __restrict__ xl, int* sat) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * dim;
-  float s1 = 0.f, s2 = 0.f;
+  float s1 = 0.f, s2 = 0.f, amax = 0.f;
   for (int c = lane * 4; c < dim; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
-    const uint2 h = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    const uint2 h = make_uint2(pack_h2<H16>(v.x, v.y, amax), pack_h2<H16>(v.z, v.w, amax));
     *reinterpret_cast<uint2*>(xb + (size_t)row * ld_xb + c) = h;
-    if (xl)   // the (hi, lo) residual stream: lo = bf16(x - hi)
-      *reinterpret_cast<uint2*>(xl + (size_t)row * ld_xb + c) =
-          make_uint2(pack_bf16x2(v.x - __uint_as_float(h.x << 16), v.y - __uint_as_float(h.x & 0xffff0000u)),
-                     pack_bf16x2(v.z - __uint_as_float(h.y << 16), v.w - __uint_as_float(h.y & 0xffff0000u)));
+    if (xl) {  // the (hi, lo) residual stream: lo = 16-bit(x - hi)
+      const f32x2 h01 = unpack_h2<H16>(h.x), h23 = unpack_h2<H16>(h.y);
+      *reinterpret_cast<uint2*>(xl + (size_t)row * ld_xb + c) = make_uint2(pack_h2<H16>(v.x - h01[0], v.y - h01[1]), pack_h2<H16>(v.z - h23[0], v.w - h23[1]));
+    }
     s1 += (v.x + v.y) + (v.z + v.w);
     s2 += fmaf(v.x, v.x, v.y * v.y) + fmaf(v.z, v.z, v.w * v.w);
   }
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane < parts) stats[(size_t)lane * stats_stride + row] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
+  if constexpr (H16) report_saturation(sat, 0, amax, FP_F16_MAX);
 }
 
 // Folded LayerNorm: the residual GEMM's column tiles leave `parts` partial sums per row; one thread per row adds them in
@@ -533,6 +541,7 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 }
 
 // the (hi, lo) bf16 residual stream back as fp32 rows: out[r] = hi[row] + lo[row], row = rows[r] (the selected tokens of the hooked block) or r
+template <bool H16>   // H16: the pair is IEEE fp16 (the "f16" mode)
 __global__ __launch_bounds__(256) void hilo_rows_kernel(const __bf16* __restrict__ xb, const __bf16* __restrict__ xl, int ld, const int* __restrict__ rows,
                                                         int n, int dim, float* __restrict__ out) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -540,9 +549,8 @@ __global__ __launch_bounds__(256) void hilo_rows_kernel(const __bf16* __restrict
   const size_t row = rows ? (size_t)rows[r] : (size_t)r;
   for (int c = lane * 4; c < dim; c += 256) {
     const uint2 h = *reinterpret_cast<const uint2*>(xb + row * ld + c), l = *reinterpret_cast<const uint2*>(xl + row * ld + c);
-    *reinterpret_cast<float4*>(out + (size_t)r * dim + c) =
-        make_float4(__uint_as_float(h.x << 16) + __uint_as_float(l.x << 16), __uint_as_float(h.x & 0xffff0000u) + __uint_as_float(l.x & 0xffff0000u),
-                    __uint_as_float(h.y << 16) + __uint_as_float(l.y << 16), __uint_as_float(h.y & 0xffff0000u) + __uint_as_float(l.y & 0xffff0000u));
+    const f32x2 h01 = unpack_h2<H16>(h.x), h23 = unpack_h2<H16>(h.y), l01 = unpack_h2<H16>(l.x), l23 = unpack_h2<H16>(l.y);
+    *reinterpret_cast<float4*>(out + (size_t)r * dim + c) = make_float4(h01[0] + l01[0], h01[1] + l01[1], h23[0] + l23[0], h23[1] + l23[1]);
   }
 }
 
@@ -638,6 +646,7 @@ int patchify_strided_launch(const float* images, int batch, int height, int widt
   if (out_dtype == FP_DTYPE_F16F8) hipLaunchKernelGGL(patchify_strided_kernel<3>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
   else if (split) hipLaunchKernelGGL(patchify_strided_kernel<2>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, out_scale);
   else if (out_dtype == FP_DTYPE_BF16) hipLaunchKernelGGL(patchify_strided_kernel<1>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
+  else if (out_dtype == FP_DTYPE_F16) hipLaunchKernelGGL(patchify_strided_kernel<4>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
   else hipLaunchKernelGGL(patchify_strided_kernel<0>, dim3(grid), dim3(256), 0, st, images, batch, height, width, patch, stride, gh, gw, out, ld_out, cols_pad, 1.f);
   FP_CHECK_LAUNCH("patchify_strided");
   return FP_OK;
@@ -656,7 +665,8 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
   FP_REQUIRE(ld_out % (16 / esz) == 0, "patchify: ld_out must keep 16-byte rows");
   const size_t lds = (size_t)(width / patch) * (ld_out + 16 / esz) * esz + (size_t)width * 2;  // the row of patches in output layout + the x table
   FP_REQUIRE(lds <= 160 * 1024 && patch <= 255 && width / patch <= 255, "patchify: a row of patches (%d x %d columns) does not fit LDS", width / patch, ld_out);
-  static FpDeviceOnce attr_b, attr_f, attr_s, attr_x;
+  static FpDeviceOnce attr_b, attr_f, attr_s, attr_x, attr_h;
+  fp_allow_dynamic_lds(attr_h, &patchify_kernel<_Float16, 0>, 160 * 1024);
   fp_allow_dynamic_lds(attr_x, &patchify_kernel<_Float16, 2>, 160 * 1024);
   fp_allow_dynamic_lds(attr_b, &patchify_kernel<__bf16>, 160 * 1024);
   fp_allow_dynamic_lds(attr_f, &patchify_kernel<float>, 160 * 1024);
@@ -667,6 +677,8 @@ int patchify_launch(const float* images, int batch, int height, int width, int p
     hipLaunchKernelGGL((patchify_kernel<_Float16, 1>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, out_scale);
   else if (out_dtype == FP_DTYPE_BF16)
     hipLaunchKernelGGL(patchify_kernel<__bf16>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<__bf16*>(out), ld_out, 1.f);
+  else if (out_dtype == FP_DTYPE_F16)   // plain fp16 rows (normalised pixels: |v| < 3)
+    hipLaunchKernelGGL((patchify_kernel<_Float16, 0>), dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<_Float16*>(out), ld_out, 1.f);
   else
     hipLaunchKernelGGL(patchify_kernel<float>, dim3(grid), dim3(256), lds, st, images, batch, height, width, patch, reinterpret_cast<float*>(out), ld_out, 1.f);
   FP_CHECK_LAUNCH("patchify");
@@ -680,19 +692,25 @@ int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, i
   return FP_OK;
 }
 
-int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st, void* xl) {
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st, void* xl, bool h16,
+                         int* sat) {
   FP_REQUIRE(dim % 4 == 0 && ld_xb % 4 == 0 && parts >= 1 && parts <= 64, "rowstats_cast: dim / ld_xb must be multiples of 4, parts in [1, 64]");
   if (rows == 0) return FP_OK;
-  hipLaunchKernelGGL(rowstats_cast_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
-                     reinterpret_cast<__bf16*>(xl));
+  if (h16)
+    hipLaunchKernelGGL(rowstats_cast_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
+                       reinterpret_cast<__bf16*>(xl), sat);
+  else
+    hipLaunchKernelGGL(rowstats_cast_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
+                       reinterpret_cast<__bf16*>(xl), sat);
   FP_CHECK_LAUNCH("rowstats_cast");
   return FP_OK;
 }
 
-int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st) {
+int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st, bool h16) {
   FP_REQUIRE(xb && xl && out && dim % 4 == 0 && ld % 4 == 0, "hilo_rows: bad arguments");
   if (n == 0) return FP_OK;
-  hipLaunchKernelGGL(hilo_rows_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(xb), reinterpret_cast<const __bf16*>(xl), ld, rows, n, dim, out);
+  if (h16) hipLaunchKernelGGL(hilo_rows_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(xb), reinterpret_cast<const __bf16*>(xl), ld, rows, n, dim, out);
+  else hipLaunchKernelGGL(hilo_rows_kernel<false>, dim3(cdiv(n, 4)), dim3(256), 0, st, reinterpret_cast<const __bf16*>(xb), reinterpret_cast<const __bf16*>(xl), ld, rows, n, dim, out);
   FP_CHECK_LAUNCH("hilo_rows");
   return FP_OK;
 }

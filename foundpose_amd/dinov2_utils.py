@@ -89,8 +89,13 @@ class DinoFeatureExtractor(torch.nn.Module):
             raise NotImplementedError("use_graph replays the token path only")
         if not 0 <= self.layer < self.arch.depth:
             raise ValueError(f"layer {self.layer} out of range for {self.version}")
-        if precision not in ("bf16", "fp32", "fp8", "f16x3", "f16f8"):
-            raise ValueError("precision must be 'bf16', 'fp32', 'f16x3', 'f16f8' or 'fp8'")
+        if precision not in ("bf16", "f16", "fp32", "fp8", "f16x3", "f16f8"):
+            raise ValueError("precision must be 'bf16', 'f16', 'fp32', 'f16x3', 'f16f8' or 'fp8'")
+        # "f16": the bf16 pipeline -- same kernels, tiles, bytes and speed -- on IEEE fp16 operands (11 significant bits instead of 8; include/foundpose_amd.h
+        # "plain fp16 rows"): closer to the reference's fp32 arithmetic at no cost.  What it gives up is bf16's range: an activation beyond +-65504 is
+        # reported (FoundPoseSaturationError), never silently wrong.
+        if precision == "f16" and self.arch.dim % 128:
+            raise NotImplementedError(f"precision='f16' runs the folded-LayerNorm pipeline: dim must be a multiple of 128 ({self.version}: {self.arch.dim})")
         # "f16x3": the near-exact mode.  The reference computes in fp32 (scripts/infer.py:468-473); the fp32-input MFMA runs at 1/16
         # of the fp16 rate, so this mode carries every GEMM / attention operand as a (hi, lo) pair of fp16 numbers (22 mantissa
         # bits) and builds each product from three fp16 MFMAs with fp32 accumulation (include/foundpose_amd.h "split-fp16 rows").
@@ -115,7 +120,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         # bf16 mode: the two LayerNorms of every block folded into the GEMMs around them (fp_vit_model.ln_fold): gain into the
         # qkv / fc1 matrices, shift into their biases, LayerScale into the proj / fc2 matrices -- no LayerNorm kernel runs
         # inside the blocks (they were 6.5 % of a step).  fold_layernorm=False keeps the kernel-per-LayerNorm sequence.
-        self.fold_layernorm = bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0"  # FP_LN_FOLD=0: A/B switch
+        self.fold_layernorm = (bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0") or precision == "f16"  # FP_LN_FOLD=0: A/B switch (bf16)
         self._sd, self.weights_source = _weights.resolve(self.model_base_name, self.arch, state_dict, weights, random_init_seed)
         self._device: Optional[torch.device] = None
         self._w: Dict[str, torch.Tensor] = {}
@@ -145,7 +150,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         a, sd = self.arch, self._sd
         if self.precision in ("f16x3", "f16f8"):
             return self._prepare_split(dev)
-        wdt = torch.float32 if self.precision == "fp32" else torch.bfloat16
+        wdt = torch.float32 if self.precision == "fp32" else (torch.float16 if self.precision == "f16" else torch.bfloat16)
         w: Dict[str, torch.Tensor] = {}
 
         # Row strides of the block matrices and of the y / h activation buffers are padded by `pad` elements so that a
@@ -248,7 +253,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m.dim, m.depth, m.heads, m.hidden, m.registers, m.patch = a.dim, a.depth, a.heads, a.hidden, a.registers, a.patch
         m.ffn_swiglu = int(a.ffn != "mlp")
         m.patch_stride = 0 if self.stride == self.patch_size else self.stride
-        m.weight_dtype = _lib.FP_F32 if self.precision == "fp32" else _lib.FP_BF16  # "fp8": bf16 until calibrated (_to_fp8)
+        m.weight_dtype = _lib.FP_F32 if self.precision == "fp32" else (_lib.FP_F16 if self.precision == "f16" else _lib.FP_BF16)  # "fp8": bf16 until calibrated (_to_fp8)
         m.patch_w, m.patch_k_pad, m.patch_b = ptr(w["patch_w"]), kpad, ptr(w["patch_embed.proj.bias"])
         m.norm_w, m.norm_b = ptr(w["norm.weight"]), ptr(w["norm.bias"])
         m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
@@ -375,7 +380,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         if key not in self._ws:
             a, dev = self.arch, self._device
             sp = self.precision in ("f16x3", "f16f8")
-            adt = torch.float32 if self.precision == "fp32" else (torch.float16 if sp else torch.bfloat16)
+            adt = torch.float32 if self.precision == "fp32" else (torch.float16 if (sp or self.precision == "f16") else torch.bfloat16)
             em = 2 if sp else 1  # stored elements per logical element of an operand row (split rows: hi + lo halves)
             np_, ntok = gh * gw, 1 + a.registers + gh * gw
             m_pad = self.padded_rows(B * ntok)
@@ -392,11 +397,11 @@ class DinoFeatureExtractor(torch.nn.Module):
                 bufs.append(torch.zeros(m_pad, max(a.dim, a.hidden) + p8, dtype=torch.uint8, device=dev))
             ws = _lib.VitWorkspace()
             if self.fold_layernorm:  # bf16 copy of the residual stream + partial row sums per 128-column tile
-                bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=torch.bfloat16, device=dev))
+                bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev))
                 bufs.append(torch.zeros(a.dim // 128 + 1, m_pad, 2, dtype=torch.float32, device=dev))
                 ws.xb, ws.stats = ptr(bufs[-2]), ptr(bufs[-1])
-                if os.environ.get("FP_RESID_HILO", "1") != "0":   # low halves of the (hi, lo) residual stream of the blocks in front of the hooked one (A/B switch)
-                    bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=torch.bfloat16, device=dev))
+                if os.environ.get("FP_RESID_HILO", "1") != "0" or self.precision == "f16":   # low halves of the (hi, lo) residual stream of the blocks in front of the hooked one (A/B switch)
+                    bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev))
                     ws.xl = ptr(bufs[-1])
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
             ws.a8 = ptr(bufs[5]) if self.precision == "fp8" else None
@@ -437,6 +442,10 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def report_saturation(self, n16: int, n8: int) -> None:
         """The verdict for a pair of counts (split-fp16 clamps, e4m3 clamps): raises in the f16x3 mode, warns once in the fp8 mode."""
+        if n16 and self.precision == "f16":
+            raise _lib.FoundPoseSaturationError(
+                f"precision='f16': {n16} kernel thread(s) produced a 16-bit activation beyond the fp16 range (|x| > 65504 -> inf) or met a NaN: the features of this "
+                "batch are not usable.  Use precision='bf16' or 'fp32' for this checkpoint (or reset_saturation() to acknowledge).")
         if n16 and self.precision in ("f16x3", "f16f8"):
             raise _lib.FoundPoseSaturationError(
                 f"precision='{self.precision}': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
@@ -479,7 +488,7 @@ class DinoFeatureExtractor(torch.nn.Module):
     @property
     def supports_token_selection(self) -> bool:
         """The hooked block can be computed for a subset of the tokens (fp_vit_block_selected): bf16 with folded LayerNorms, fp8, or f16x3."""
-        mode_ok = (self.precision == "bf16" and self.fold_layernorm) or self.precision in ("f16x3", "f16f8", "fp8")
+        mode_ok = (self.precision in ("bf16", "f16") and self.fold_layernorm) or self.precision in ("f16x3", "f16f8", "fp8")
         return (self.facet == "token" and not self.use_graph and mode_ok and self.layer >= 0
                 and self.stride == self.patch_size)   # the selection maps query points to 14-px cells
 
@@ -670,7 +679,7 @@ class DinoFeatureExtractor(torch.nn.Module):
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
         B, _, H, W = images.shape
         fmap, cls = self.forward_tokens(images)
-        if self.precision in ("f16x3", "f16f8", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
+        if self.precision in ("f16", "f16x3", "f16f8", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
             self.check_saturation()   # one host sync; the reference's forward is synchronous too (CPU tensors)
         gh, gw = self._grid(H, W)
         # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output

@@ -140,7 +140,7 @@ class FoundPoseEngine:
         self._mark("start")
         # f16x3 / fp8: clamped activations are reported per BATCH -- the sticky device counters are snapshotted before and after the backbone
         # of this batch (two 8-byte device copies, no sync); the result raises / warns for what ITS batch clamped, whatever happened before
-        track_sat = self.extractor.precision in ("f16x3", "f16f8", "fp8")
+        track_sat = self.extractor.precision in ("f16", "f16x3", "f16f8", "fp8")
         sat0 = self.extractor.saturation_snapshot() if track_sat else None
         pending = self._query_points_begin(masks, select_tokens=select)
         if select:
@@ -166,7 +166,9 @@ class FoundPoseEngine:
         sat_delta = None
         if track_sat:
             sat1 = self.extractor.saturation_snapshot()
-            sat_delta = sat1 if sat0 is None else sat1 - sat0
+            # (clamped at 0: a reset_saturation() between the two snapshots must not turn into a "negative count", which would read as a verdict.
+            #  The counters belong to the extractor: one extractor must not serve two concurrently running engines in the reporting modes.)
+            sat_delta = sat1 if sat0 is None else (sat1 - sat0).clamp_min_(0)
         if not self.overlap_matching:
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")

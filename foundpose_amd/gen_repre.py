@@ -152,7 +152,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--opts", required=True)
     ap.add_argument("--output-path", required=True, help="root holding templates/ (input) and object_repre/ (output)")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16x3", "f16f8", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f16x3", "f16f8", "fp32"])
     ap.add_argument("--weights", default=None, help="DINOv2 checkpoint file (upstream key names) or a directory holding the upstream file name; "
                     "default $FOUNDPOSE_DINOV2_WEIGHTS, then the torch hub cache; without one the run fails (no random-weight fallback)")
     args = ap.parse_args(argv)

@@ -237,7 +237,7 @@ def main(argv: Optional[Sequence[str]] = None) -> None:
     ap.add_argument("--detections", required=True, help="CNOS detections in the BOP format")
     ap.add_argument("--repre-dir", required=True, help="<output>/object_repre (repre.pth under <version>/<dataset>/<lid>/)")
     ap.add_argument("--output-dir", required=True)
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16x3", "f16f8", "fp32"])
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "f16", "f16x3", "f16f8", "fp32"])
     ap.add_argument("--weights", default=None, help="DINOv2 checkpoint: a .pth with the upstream key names, or a directory holding the upstream file "
                     "(dinov2_vitl14_pretrain.pth, dinov2_vits14_reg4_pretrain.pth, ...); default $FOUNDPOSE_DINOV2_WEIGHTS, then the torch hub cache. "
                     "Without a checkpoint the run fails: there is no random-weight fallback")

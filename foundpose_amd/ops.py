@@ -122,16 +122,24 @@ def gemm_f32(a: torch.Tensor, w: torch.Tensor, bias=None, gamma=None, out=None, 
     return out
 
 
+def _h16_bit(a: torch.Tensor, w: torch.Tensor) -> int:
+    """FP_GEMM_F16 when the operands are IEEE fp16 (the "f16" mode's kernels), 0 for bf16; both operands must agree."""
+    if a.dtype != w.dtype or a.dtype not in (torch.bfloat16, torch.float16):
+        raise ValueError("the 16-bit GEMMs take two bf16 or two fp16 operands")
+    return _lib.GEMM_F16 if a.dtype == torch.float16 else 0
+
+
 def gemm_bf16(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, gamma=None, out=None, epilogue: int = 0,
               m_valid: Optional[int] = None) -> torch.Tensor:
+    """bf16 operands, or fp16 ones (the "f16" mode: same kernels on v_mfma_f32_32x32x16_f16; 16-bit outputs are then fp16)."""
     require_cuda(a, w, bias)
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        dt = torch.float32 if (epilogue & 0xff) in (3, 5) else torch.bfloat16
-        out = torch.zeros(M, N, dtype=dt, device=a.device)
+        dt = torch.float32 if (epilogue & 0xff) in (3, 5) else a.dtype
+        out = torch.zeros(M, N // 2 if (epilogue & 0xff) == 6 else N, dtype=dt, device=a.device)
     call("fp_gemm_bf16", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid,
-         ptr(bias), ptr(gamma), ptr(out), out.stride(0), epilogue, stream())
+         ptr(bias), ptr(gamma), ptr(out), out.stride(0), epilogue | _h16_bit(a, w), stream())
     return out
 
 
@@ -141,10 +149,10 @@ def gemm_bf16_resid_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x: 
     require_cuda(a, w, bias, x)
     M, K = a.shape
     N = w.shape[0]
-    xb = torch.zeros(M, N, dtype=torch.bfloat16, device=a.device) if emit else None
+    xb = torch.zeros(M, N, dtype=a.dtype, device=a.device) if emit else None
     stats = torch.zeros(N // 128, M, 2, dtype=torch.float32, device=a.device) if emit else None
     call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(x), x.stride(0),
-         7 | (tile << 8), None, None, ptr(xb), N, ptr(stats), stream())
+         7 | (tile << 8) | _h16_bit(a, w), None, None, ptr(xb), N, ptr(stats), stream())
     return xb, stats
 
 
@@ -154,13 +162,13 @@ def gemm_bf16_resid_hilo(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, x
     require_cuda(a, w, bias, xb, xl)
     M, K = a.shape
     N = w.shape[0]
-    if xb.dtype != torch.bfloat16 or xl.dtype != torch.bfloat16 or xb.stride(0) != xl.stride(0):
-        raise ValueError("xb / xl are bf16 arrays with one row stride")
+    if xb.dtype != a.dtype or xl.dtype != a.dtype or xb.stride(0) != xl.stride(0):
+        raise ValueError("xb / xl are arrays of the operands' 16-bit type with one row stride")
     if xb.stride(0) % 8 or xb.data_ptr() % 16 or xl.data_ptr() % 16 or xb.stride(1) != 1 or xl.stride(1) != 1:
         raise ValueError("xb / xl: 16-byte aligned rows (row stride a multiple of 8 elements, unit column stride) -- the epilogue moves 8 bf16 per access")
     stats = torch.zeros(N // 128, M, 2, dtype=torch.float32, device=a.device)
     call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(xl), xl.stride(0),
-         8 | (tile << 8), None, None, ptr(xb), xb.stride(0), ptr(stats), stream())
+         8 | (tile << 8) | _h16_bit(a, w), None, None, ptr(xb), xb.stride(0), ptr(stats), stream())
     return stats
 
 
@@ -180,9 +188,9 @@ def gemm_bf16_ln(a: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, colsum: t
     M, K = a.shape
     N = w.shape[0]
     if out is None:
-        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=torch.bfloat16, device=a.device)
+        out = torch.zeros(M, N // 2 if epilogue == 6 else N, dtype=a.dtype, device=a.device)
     call("fp_gemm_bf16_ln", ptr(a), a.stride(0), ptr(w), w.stride(0), M, N, K, M if m_valid is None else m_valid, ptr(bias), ptr(out), out.stride(0),
-         epilogue | (tile << 8), ptr(colsum), ptr(ln_row), None, 0, None, stream())
+         epilogue | (tile << 8) | _h16_bit(a, w), ptr(colsum), ptr(ln_row), None, 0, None, stream())
     return out
 
 
@@ -219,17 +227,17 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, out_dty
     rows, D = x.shape
     out = torch.empty(rows, D, dtype=out_dtype, device=x.device)
     call("fp_layernorm", ptr(x), x.stride(0), ptr(weight), ptr(bias), eps, ptr(out), D,
-         _lib.FP_BF16 if out_dtype == torch.bfloat16 else _lib.FP_F32, D, rows, rows, rows, 0, stream())
+         {torch.bfloat16: _lib.FP_BF16, torch.float16: _lib.FP_F16, torch.float32: _lib.FP_F32}[out_dtype], D, rows, rows, rows, 0, stream())
     return out
 
 
 def attention(qkv: torch.Tensor, batch: int, n_tok: int, dim: int, heads: int, variant: int = 0):
     """variant: bf16 work split (FP_ATTN_VARIANT in the header; all bit-identical) -- 0 is what the pipeline runs."""
     require_cuda(qkv)
-    bf = qkv.dtype == torch.bfloat16
+    dt = {torch.bfloat16: _lib.FP_BF16, torch.float16: _lib.FP_F16, torch.float32: _lib.FP_F32}[qkv.dtype]   # fp16: the "f16" mode's kernel (variant 0 only)
     out = torch.zeros(qkv.shape[0], dim, dtype=qkv.dtype, device=qkv.device)
     call("fp_attention", ptr(qkv), qkv.stride(0), ptr(out), dim,
-         batch, n_tok, dim, heads, (_lib.FP_BF16 if bf else _lib.FP_F32) | (int(variant) << 8), stream())
+         batch, n_tok, dim, heads, dt | (int(variant) << 8), stream())
     return out
 
 

@@ -24,8 +24,9 @@ extern "C" {
 
 typedef void* fp_stream_t; /* hipStream_t */
 
-enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3 weights,
-                                                               fp_vit_model only; FP_F16X3: split-fp16 rows, FP_F16F8: f16f8 rows, see below) */
+enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4, FP_F16 = 5 }; /* element types of activation / weight buffers (FP_FP8: OCP e4m3
+                                                               weights, fp_vit_model only; FP_F16X3: split-fp16 rows, FP_F16F8: f16f8 rows, see below;
+                                                               FP_F16: plain IEEE fp16 -- the "f16" mode, see FP_GEMM_F16) */
 
 /* ---- split-fp16 rows (the "f16x3" near-exact mode) --------------------------------------------------------------------
  * The reference computes the backbone in fp32 (scripts/infer.py:468-473).  The fp32-input MFMA runs at 1/16 of the fp16 /
@@ -53,7 +54,16 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4 }; /* ele
  * attention's own products stay split-fp16 (three fp16 MFMAs). */
 #define FP_GEMM_SPLIT_F16F8 (1 << 20) /* OR-ed into fp_gemm_split's `epilogue`: A, W (and a GELU / SwiGLU output) are f16f8 rows, K % 64 == 0 */
 
-#define FP_ABI_VERSION 15
+/* ---- plain fp16 rows (the "f16" mode) ------------------------------------------------------------------------------------------
+ * The bf16 pipeline of fp_vit_forward -- folded LayerNorms, (hi, lo) residual stream, the same kernels, tiles and bytes -- on IEEE fp16 operands
+ * (v_mfma_f32_32x32x16_f16 runs at the bf16 rate): 11 significant bits per operand instead of 8, and the GELU in its erf form at fp32 accuracy.
+ * fp16 has bf16's speed but not its range: a 16-bit output beyond +-65504 becomes inf (nothing is clamped) and is reported through
+ * fp_vit_workspace.sat[0]; the Python extractor raises FoundPoseSaturationError for such a batch.  No operand scales: the residual stream and the
+ * activations of DINOv2 checkpoints sit orders of magnitude inside the range, values below 6e-5 keep an absolute error <= 3e-8 (fp16 subnormals,
+ * which the MFMA honours). */
+#define FP_GEMM_F16 (1 << 21) /* OR-ed into fp_gemm_bf16's / fp_gemm_bf16_ln's `epilogue`: A, W, the 16-bit outputs and the (xb, xl) stream are IEEE fp16 */
+
+#define FP_ABI_VERSION 16
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -227,7 +237,7 @@ typedef struct {
   int dim, depth, heads, hidden, registers, patch;
   int ffn_swiglu;          /* 1 for ViT-g: fc1_w/fc1_b hold mlp.w12 with rows INTERLEAVED (x1_j, x2_j) [2*hidden, D],
                               fc2_w/fc2_b hold mlp.w3 [D, hidden]; h = silu(x1) * x2 is fused into the first GEMM */
-  int weight_dtype;        /* FP_BF16 | FP_F32: dtype of the matrices and of the activation buffers; FP_FP8: e4m3 block
+  int weight_dtype;        /* FP_BF16 | FP_F32 | FP_F16: dtype of the matrices and of the activation buffers (FP_F16 needs ln_fold = 1); FP_FP8: e4m3 block
                               matrices (see fp_vit_block), bf16 activation buffers and patch-embed weight */
   const void* patch_w;     /* [D, patch_k_pad]: conv weight flattened (c,py,px), zero padded */
   int patch_k_pad;         /* multiple of 64 */
@@ -243,7 +253,7 @@ typedef struct {
                               patch_vit_resolution, utils/dinov2_utils.py:364-389) give overlapping patches: 1 + (size - patch) / stride
                               tokens per axis, pos_patch then holds the reference's strided position encoding; full forward only */
   float patch_acc_scale;   /* FP_F16X3 only: 1 / (FP_SPLIT_SCALE_ACT x scale of the split patch_w [D, 2 * patch_k_pad]) */
-  int ln_fold;             /* FP_BF16 only.  1: the two LayerNorms of a block are folded into the GEMMs around them -- no
+  int ln_fold;             /* FP_BF16 / FP_F16 only.  1: the two LayerNorms of a block are folded into the GEMMs around them -- no
                               LayerNorm kernel runs inside the blocks.  qkv_w / fc1_w then hold W * diag(ln weight) (bf16),
                               qkv_b / fc1_b hold b + W ln_bias, *_colsum the row sums of those matrices; proj_w / fc2_w hold
                               diag(LayerScale) W and proj_b / fc2_b hold LayerScale * b (ls1 / ls2 are then unused); the
