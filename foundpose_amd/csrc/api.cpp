@@ -571,7 +571,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     FP_REQUIRE(ws->xb && ws->stats, "fp_vit_forward: ln_fold needs workspace xb and stats");
     FP_REQUIRE(D % 128 == 0, "fp_vit_forward: ln_fold needs dim %% 128 == 0");
     ln_parts = D / 128;  // one partial sum per 128-column group of the residual GEMMs, whatever tile they run with
-    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st, ws->xl, h16, ws->sat));
+    if (layer >= 0 && mode != VIT_LAST_SELECTED) TRY(rowstats_cast_launch(ws->x, Mtok, D, ws->xb, ldy, stats, ws->m_pad, ln_parts, st, ws->xl, h16));
   }
   // Blocks in FRONT of the hooked one keep the residual stream as (hi, lo) bf16 arrays (ws->xb, ws->xl) instead of fp32 + a bf16 copy: the
   // residual GEMMs then read 4 and write 4 bytes per element instead of 4 + 6 (hi IS the next GEMM's A operand).  16 mantissa bits per update
@@ -591,7 +591,6 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
     if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; g.xl = reinterpret_cast<__bf16*>(ws->xl); }
-    g.sat = ws->sat;   // (read by the fp16 kernels only: overflow report of their 16-bit outputs)
     return h16 ? gemm_f16_launch(epi, g, st) : gemm_bf16_launch(epi, g, st);
   };
 
@@ -796,6 +795,7 @@ int fp_vit_features(const fp_vit_model* m, const fp_vit_workspace* ws, int B, in
     memset(&ln, 0, sizeof(ln));
     ln.x = ws->x; ln.ld_x = D; ln.weight = m->norm_w; ln.bias = m->norm_b; ln.eps = 1e-6f;
     ln.out_dtype = FP_DTYPE_F32; ln.dim = D; ln.in_rows_per_img = ntok; ln.ld_out = D;
+    ln.sat = m->weight_dtype == FP_DTYPE_F16 ? ws->sat : nullptr;   // the "f16" mode's overflow report: non-finite features (common.hpp)
     ln.out = fmap; ln.out_rows = B * n_patches; ln.out_rows_per_img = n_patches; ln.in_skip = 1 + m->registers;
     TRY(layernorm_launch(ln, st));
     if (cls) {
@@ -818,7 +818,7 @@ int fp_vit_sample_features(const fp_vit_model* m, const fp_vit_workspace* ws, in
   FP_REQUIRE(B >= 1 && grid_h >= 1 && grid_w >= 1 && img_w >= 1 && img_h >= 1, "fp_vit_sample_features: bad sizes");
   const int ntok = 1 + m->registers + grid_h * grid_w;
   return ln_sample_launch(ws->x, m->dim, m->norm_w, m->norm_b, 1e-6f, apply_norm, m->dim, ntok, 1 + m->registers, grid_h, grid_w, img_w, img_h,
-                          points, point_img, num_points, out, ST(stream));
+                          points, point_img, num_points, out, ST(stream), nullptr, m->weight_dtype == FP_DTYPE_F16 ? ws->sat : nullptr);
 }
 
 int fp_query_select(const uint8_t* masks, int B, int H, int W, const int32_t* pix_x, const int32_t* pix_y, const float* grid_points, int num_points,
@@ -838,7 +838,7 @@ int fp_vit_sample_features_selected(const fp_vit_model* m, const fp_vit_workspac
   const int ntok = 1 + m->registers + grid_h * grid_w;
   // fp_vit_block_selected left the selected tokens' rows of the residual stream, compact, where the qkv projections were
   return ln_sample_launch(reinterpret_cast<const float*>(ws->qkv), m->dim, m->norm_w, m->norm_b, 1e-6f, apply_norm, m->dim, ntok, 1 + m->registers,
-                          grid_h, grid_w, img_w, img_h, points, point_img, num_points, out, ST(stream), row_map);
+                          grid_h, grid_w, img_w, img_h, points, point_img, num_points, out, ST(stream), row_map, m->weight_dtype == FP_DTYPE_F16 ? ws->sat : nullptr);
 }
 
 }  // extern "C"

@@ -74,8 +74,10 @@ FP_DEVICE unsigned pack_bf16x2(float lo, float hi) {
 
 // ---- the two 16-bit operand formats of the single-pass ViT pipeline: bf16 (H16 = false: precision "bf16") and IEEE fp16 (H16 = true: precision
 // "f16" -- the same MFMA rate and the same bytes, 11 significant bits instead of 8, range +-65504 instead of +-3e38).  The fp16 conversion is
-// v_cvt_pk_f16_f32 (round to nearest even, subnormals kept, a value beyond the range becomes inf): producers of fp16 rows keep the running maximum
-// of what they packed and report through the saturation counter (slot 0) -- nothing is clamped, a reported batch is simply not usable.
+// v_cvt_pk_f16_f32 (round to nearest even, subnormals kept, a value beyond the range becomes inf).  Nothing is clamped and nothing is tracked where the
+// rows are produced (a running maximum in the GEMM epilogues cost 3-5 % of their launches): an inf poisons its row's residual stream and, through the
+// keys and values of the next attention, every token of the image, so the LAST kernel of the pipeline (final norm / sampling) counts non-finite
+// features into the saturation counter (slot 0) -- a reported batch is not usable, an unreported one never saw an overflow that mattered.
 typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(2))) _Float16 f16x2;
 FP_DEVICE unsigned pack_f16x2(float lo, float hi) {
@@ -85,10 +87,6 @@ FP_DEVICE unsigned pack_f16x2(float lo, float hi) {
 template <bool H16> FP_DEVICE unsigned pack_h2(float lo, float hi) {
   if constexpr (H16) return pack_f16x2(lo, hi);
   else return pack_bf16x2(lo, hi);
-}
-template <bool H16> FP_DEVICE unsigned pack_h2(float lo, float hi, float& amax) {   // ... with the running maximum an fp16 producer reports
-  if constexpr (H16) amax = nanmax3(amax, fabsf(lo), fabsf(hi));
-  return pack_h2<H16>(lo, hi);
 }
 template <bool H16> FP_DEVICE f32x2 unpack_h2(unsigned w) {   // the two 16-bit elements of a dword as fp32 (exact)
   if constexpr (H16) return __builtin_convertvector(__builtin_bit_cast(f16x2, w), f32x2);

@@ -159,7 +159,7 @@ int gemm_split_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_splitx_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 int gemm_fp8_launch(int epi, const GemmBf16Args& a, hipStream_t st);  // A, W: OCP fp8 e4m3 bytes behind the __bf16 pointers
 // "f16" mode: gemm_bf16_launch's kernels with IEEE fp16 operands and fp16 outputs behind the __bf16 pointers (A, W, out of the 16-bit epilogues, xb / xl
-// of the residual epilogues); v_mfma_f32_32x32x16_f16, the exact-erf GELU; a.sat (may be null) receives the overflow report of the fp16 outputs
+// of the residual epilogues); v_mfma_f32_32x32x16_f16, the nine-coefficient GELU polynomial; an fp16 output beyond +-65504 becomes inf (no report here: see common.hpp)
 int gemm_f16_launch(int epi, const GemmBf16Args& a, hipStream_t st);
 
 // ---------------------------------------------------------------- dtypes of the C ABI
@@ -196,12 +196,13 @@ struct LayerNormArgs {
   int dim;
   int out_rows;                  // rows to produce
   int out_rows_per_img, in_rows_per_img, in_skip;  // out row r -> in row (r / orpi) * irpi + in_skip + r % orpi
-  int* sat;                      // may be null; else [2] sticky saturation counters: split-fp16 / e4m3 outputs report clamps
+  int* sat;                      // may be null; else [2] sticky saturation counters: split-fp16 / e4m3 outputs report clamps, an fp32 output reports
+                                 // non-finite values (the final norm of the "f16" mode)
 };
 int layernorm_launch(const LayerNormArgs& a, hipStream_t st);
 int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
                      int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st,
-                     const int* row_map = nullptr);
+                     const int* row_map = nullptr, int* sat = nullptr);   // sat: non-finite features are counted into sat[0] (the "f16" mode's overflow report)
 int gather_rows_launch(const float* x, const int* rows, int n, int dim, float* out, hipStream_t st);
 int query_select_launch(const unsigned char* masks, int B, int H, int W, const int* pix_x, const int* pix_y, const float* grid_pts, int G,
                         const long long* cells9, int C, int n_tok, int* scratch, int* counts, float* out_pts, int* out_img, int* q_off, int* sel_rows,
@@ -210,7 +211,7 @@ int query_select_launch(const unsigned char* masks, int B, int H, int W, const i
 // partial sums [parts][rows] (sum x, sum x^2) over `dim` columns -> out[row] = (rstd, mean * rstd)
 int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, int dim, float eps, float2* out, hipStream_t st);
 int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st,
-                         void* xl = nullptr, bool h16 = false, int* sat = nullptr);   // xl: also write lo = bf16(x - bf16(x)) (row stride ld_xb); h16: fp16 instead of bf16
+                         void* xl = nullptr, bool h16 = false);   // xl: also write lo = bf16(x - bf16(x)) (row stride ld_xb); h16: fp16 instead of bf16
 // out[r] = float(xb[row]) + float(xl[row]) (fp32 [n, dim]); row = rows[r], or r when rows is null: the (hi, lo) stream back as fp32
 int hilo_rows_launch(const void* xb, const void* xl, int ld, const int* rows, int n, int dim, float* out, hipStream_t st, bool h16 = false);
 

@@ -105,14 +105,19 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
           else *reinterpret_cast<unsigned*>(o) = pack_bf16x2(y[0], y[1]);
         } else if (a.out_dtype == FP_DTYPE_F16) {   // plain fp16 row (the "f16" mode's operand format)
           _Float16* o = reinterpret_cast<_Float16*>(a.out) + (size_t)row * a.ld_out + c;
-          if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_h2<true>(y[0], y[1], amax), pack_h2<true>(y[2], y[3], amax));
-          else *reinterpret_cast<unsigned*>(o) = pack_h2<true>(y[0], y[1], amax);
+          if constexpr (VEC == 4) *reinterpret_cast<uint2*>(o) = make_uint2(pack_h2<true>(y[0], y[1]), pack_h2<true>(y[2], y[3]));
+          else *reinterpret_cast<unsigned*>(o) = pack_h2<true>(y[0], y[1]);
         } else {
           *reinterpret_cast<vec_t*>(reinterpret_cast<float*>(a.out) + (size_t)row * a.ld_out + c) = y;
+          if (a.sat) {   // fp32 output with a counter (the final norm of the "f16" mode): non-finite features are reported (common.hpp, "16-bit operand formats")
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) amax = nanmax3(amax, fabsf(y[e]), 0.f);
+          }
         }
       }
   }
-  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8 || a.out_dtype == FP_DTYPE_F16) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  else if (a.out_dtype == FP_DTYPE_F32) report_saturation(a.sat, 0, amax, 3.0e38f);
   else if (a.out_dtype == FP_DTYPE_FP8) report_saturation(a.sat, 1, amax, FP_E4M3_MAX);
 }
 
@@ -130,6 +135,8 @@ struct LnSampleArgs {
   float* out;                           // [num_points, dim]
   const int* row_map;                   // null: x holds every token.  Else x holds the SELECTED tokens only, compact:
                                         // row_map[img * gh * gw + cell] = the patch token's row in x (< 0: not selected)
+  int* sat;                             // may be null; else [2] sticky counters: slot 0 counts threads that produced a non-finite feature (the "f16" mode's
+                                        // overflow report: an fp16 activation beyond +-65504 anywhere in the backbone ends up here as inf / NaN)
 };
 
 // NVT = vectors of VEC floats a lane may hold of one row (dim <= 64 * VEC * NVT); small NVT keeps two rows in registers
@@ -249,9 +256,15 @@ __global__ __launch_bounds__(256) void ln_sample_kernel(LnSampleArgs a) {
 #pragma unroll
     for (int i = 0; i < NVT; ++i) v[i] = vn[i];
   }
+  float amax = 0.f;
 #pragma unroll
   for (int i = 0; i < NVT; ++i)
-    if (i < nv) *reinterpret_cast<vec_t*>(a.out + (size_t)p * a.dim + (i * 64 + lane) * VEC) = acc[i];
+    if (i < nv) {
+      *reinterpret_cast<vec_t*>(a.out + (size_t)p * a.dim + (i * 64 + lane) * VEC) = acc[i];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) amax = nanmax3(amax, fabsf(acc[i][e]), 0.f);
+    }
+  report_saturation(a.sat, 0, amax, 3.0e38f);   // (sat null: no report)
 }
 
 // images [B,3,H,W] in [0,1] -> rows of the patch-embed GEMM: row = b*Np + gy*gw + gx,
@@ -389,17 +402,17 @@ __global__ __launch_bounds__(256) void patchify_strided_kernel(const float* __re
 
 // Entry of the folded-LayerNorm block chain: xb = bf16(x) and the row sums (sum x, sum x^2) of the token embedding, which no
 // LayerScale GEMM has produced yet.  One wave per row; slot 0 of the partial-sum table gets the whole row, the others zero.
-// H16: the 16-bit arrays are IEEE fp16 (the "f16" mode) instead of bf16; an element beyond +-65504 is reported through sat[0].
+// H16: the 16-bit arrays are IEEE fp16 (the "f16" mode) instead of bf16.
 template <bool H16>
 __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restrict__ x, int rows, int dim, __bf16* __restrict__ xb, int ld_xb,
-                                                            float2* __restrict__ stats, int stats_stride, int parts, __bf16* __restrict__ xl, int* sat) {
+                                                            float2* __restrict__ stats, int stats_stride, int parts, __bf16* __restrict__ xl) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   if (row >= rows) return;
   const float* xr = x + (size_t)row * dim;
-  float s1 = 0.f, s2 = 0.f, amax = 0.f;
+  float s1 = 0.f, s2 = 0.f;
   for (int c = lane * 4; c < dim; c += 256) {
     const float4 v = *reinterpret_cast<const float4*>(xr + c);
-    const uint2 h = make_uint2(pack_h2<H16>(v.x, v.y, amax), pack_h2<H16>(v.z, v.w, amax));
+    const uint2 h = make_uint2(pack_h2<H16>(v.x, v.y), pack_h2<H16>(v.z, v.w));
     *reinterpret_cast<uint2*>(xb + (size_t)row * ld_xb + c) = h;
     if (xl) {  // the (hi, lo) residual stream: lo = 16-bit(x - hi)
       const f32x2 h01 = unpack_h2<H16>(h.x), h23 = unpack_h2<H16>(h.y);
@@ -411,7 +424,6 @@ __global__ __launch_bounds__(256) void rowstats_cast_kernel(const float* __restr
   s1 = wave_sum(s1);
   s2 = wave_sum(s2);
   if (lane < parts) stats[(size_t)lane * stats_stride + row] = lane == 0 ? make_float2(s1, s2) : make_float2(0.f, 0.f);
-  if constexpr (H16) report_saturation(sat, 0, amax, FP_F16_MAX);
 }
 
 // Folded LayerNorm: the residual GEMM's column tiles leave `parts` partial sums per row; one thread per row adds them in
@@ -620,10 +632,10 @@ int gather_rows_launch(const float* x, const int* rows, int n, int dim, float* o
 
 int ln_sample_launch(const float* x, int ld_x, const float* weight, const float* bias, float eps, int apply_norm, int dim, int ntok, int skip,
                      int gh, int gw, int img_w, int img_h, const float* points, const int* point_img, int num_points, float* out, hipStream_t st,
-                     const int* row_map) {
+                     const int* row_map, int* sat) {
   FP_REQUIRE(dim % 128 == 0 && dim <= 2048, "ln_sample: dim (%d) must be a multiple of 128, at most 2048", dim);
   if (num_points == 0) return FP_OK;
-  LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out, row_map};
+  LnSampleArgs a{x, ld_x, weight, bias, eps, apply_norm, dim, ntok, skip, gh, gw, img_w, img_h, points, point_img, num_points, out, row_map, sat};
   const dim3 grid(cdiv(num_points, 4));
   if (dim % 256 == 0 && dim <= 1024) hipLaunchKernelGGL((ln_sample_kernel<4, 4>), grid, dim3(256), 0, st, a);
   else if (dim % 256 == 0) hipLaunchKernelGGL((ln_sample_kernel<4, 8>), grid, dim3(256), 0, st, a);
@@ -692,16 +704,15 @@ int ln_finalize_launch(const float2* partial, int parts, int stride, int rows, i
   return FP_OK;
 }
 
-int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st, void* xl, bool h16,
-                         int* sat) {
+int rowstats_cast_launch(const float* x, int rows, int dim, void* xb, int ld_xb, float2* stats, int stats_stride, int parts, hipStream_t st, void* xl, bool h16) {
   FP_REQUIRE(dim % 4 == 0 && ld_xb % 4 == 0 && parts >= 1 && parts <= 64, "rowstats_cast: dim / ld_xb must be multiples of 4, parts in [1, 64]");
   if (rows == 0) return FP_OK;
   if (h16)
     hipLaunchKernelGGL(rowstats_cast_kernel<true>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
-                       reinterpret_cast<__bf16*>(xl), sat);
+                       reinterpret_cast<__bf16*>(xl));
   else
     hipLaunchKernelGGL(rowstats_cast_kernel<false>, dim3(cdiv(rows, 4)), dim3(256), 0, st, x, rows, dim, reinterpret_cast<__bf16*>(xb), ld_xb, stats, stats_stride, parts,
-                       reinterpret_cast<__bf16*>(xl), sat);
+                       reinterpret_cast<__bf16*>(xl));
   FP_CHECK_LAUNCH("rowstats_cast");
   return FP_OK;
 }

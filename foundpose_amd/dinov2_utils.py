@@ -444,8 +444,9 @@ class DinoFeatureExtractor(torch.nn.Module):
         """The verdict for a pair of counts (split-fp16 clamps, e4m3 clamps): raises in the f16x3 mode, warns once in the fp8 mode."""
         if n16 and self.precision == "f16":
             raise _lib.FoundPoseSaturationError(
-                f"precision='f16': {n16} kernel thread(s) produced a 16-bit activation beyond the fp16 range (|x| > 65504 -> inf) or met a NaN: the features of this "
-                "batch are not usable.  Use precision='bf16' or 'fp32' for this checkpoint (or reset_saturation() to acknowledge).")
+                f"precision='f16': {n16} kernel thread(s) of the final norm produced non-finite features -- an activation beyond the fp16 range (|x| > 65504 -> inf) "
+                "somewhere in the backbone, or a NaN: the features of this batch are not usable.  Use precision='bf16' or 'fp32' for this checkpoint "
+                "(or reset_saturation() to acknowledge).")
         if n16 and self.precision in ("f16x3", "f16f8"):
             raise _lib.FoundPoseSaturationError(
                 f"precision='{self.precision}': {n16} kernel thread(s) clamped an activation to the split-fp16 range (|x| > {65504 / _lib.SPLIT_SCALE_ACT:.0f} for "
@@ -681,6 +682,9 @@ class DinoFeatureExtractor(torch.nn.Module):
         fmap, cls = self.forward_tokens(images)
         if self.precision in ("f16", "f16x3", "f16f8", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
             self.check_saturation()   # one host sync; the reference's forward is synchronous too (CPU tensors)
+        if self.precision == "f16" and (not self.apply_norm or self.facet != "token") and not bool(torch.isfinite(fmap).all()):
+            # (no final-norm kernel ran on this output: raw hidden states or a q / k / v facet -- the same verdict, checked here)
+            raise _lib.FoundPoseSaturationError("precision='f16': non-finite features -- an activation beyond the fp16 range (|x| > 65504) in the backbone, or a NaN")
         gh, gw = self._grid(H, W)
         # [B, D, Hp, Wp] as a permuted VIEW of the token-major buffer, exactly like the reference's output
         return {"cls_tokens": cls, "feature_maps": fmap.reshape(B, gh, gw, self.arch.dim).permute(0, 3, 1, 2)}

@@ -56,11 +56,12 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4, FP_F16 =
 
 /* ---- plain fp16 rows (the "f16" mode) ------------------------------------------------------------------------------------------
  * The bf16 pipeline of fp_vit_forward -- folded LayerNorms, (hi, lo) residual stream, the same kernels, tiles and bytes -- on IEEE fp16 operands
- * (v_mfma_f32_32x32x16_f16 runs at the bf16 rate): 11 significant bits per operand instead of 8, and the GELU in its erf form at fp32 accuracy.
- * fp16 has bf16's speed but not its range: a 16-bit output beyond +-65504 becomes inf (nothing is clamped) and is reported through
- * fp_vit_workspace.sat[0]; the Python extractor raises FoundPoseSaturationError for such a batch.  No operand scales: the residual stream and the
- * activations of DINOv2 checkpoints sit orders of magnitude inside the range, values below 6e-5 keep an absolute error <= 3e-8 (fp16 subnormals,
- * which the MFMA honours). */
+ * (v_mfma_f32_32x32x16_f16 runs at the bf16 rate): 11 significant bits per operand instead of 8, and a GELU polynomial good to 3.8e-5 (bf16 epilogue: 4e-4).
+ * fp16 has bf16's speed but not its range: a 16-bit output beyond +-65504 becomes inf (nothing is clamped).  An inf poisons its row's residual stream and, through
+ * the next attention's keys and values, every token of the image, so the pipeline's last kernel (fp_vit_features / fp_vit_sample_features*) counts non-finite
+ * features into fp_vit_workspace.sat[0]; the Python extractor raises FoundPoseSaturationError for such a batch (apply_norm = 0: the caller checks the copy).
+ * No operand scales: the residual stream and the activations of DINOv2 checkpoints sit orders of magnitude inside the range, values below 6e-5 keep an
+ * absolute error <= 3e-8 (fp16 subnormals, which the MFMA honours). */
 #define FP_GEMM_F16 (1 << 21) /* OR-ed into fp_gemm_bf16's / fp_gemm_bf16_ln's `epilogue`: A, W, the 16-bit outputs and the (xb, xl) stream are IEEE fp16 */
 
 #define FP_ABI_VERSION 16
@@ -280,6 +281,8 @@ typedef struct {
                     [0] FP_F16X3: a producer of split-fp16 rows (LayerNorm, the qkv / GELU / SwiGLU epilogues) clamped |s x| > 65504,
                         i.e. an activation beyond +-4094 (LayerNorm outputs, q, k, v) or +-16376 (hidden) -- the near-exact mode's
                         features are then NOT the fp32 arithmetic's; the Python extractor raises FoundPoseSaturationError on it;
+                        FP_F16: the last kernel of the pipeline (final norm / sampling) produced a non-finite feature -- an fp16 activation
+                        beyond +-65504 somewhere in the backbone (see "plain fp16 rows");
                     [1] FP_FP8: a quantising producer (LayerNorm, attention output, GELU / SwiGLU epilogue) clamped |s x| > 448
                         (an input beyond its static calibration scale).
                     Counted per reporting thread, not per element: non-zero means "at least one live output row clamped".

@@ -26,8 +26,8 @@ def rel_err(a, b):
 @pytest.mark.parametrize("tile", [128, 256])
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (1408, 3072, 1024), (384, 1024, 4096), (256, 256, 192)])
 def test_gemm_f16_epilogues_vs_fp64(M, N, K, tile):
-    """bias -> fp32, bias -> fp16, exact-erf GELU -> fp16, SwiGLU -> fp16, LayerScale + residual (fp32) against fp64 on the same fp16 operands:
-    fp32 accumulation error for the fp32 outputs, ONE fp16 rounding of the result for the 16-bit ones (the GELU included: no polynomial error)."""
+    """bias -> fp32, bias -> fp16, GELU -> fp16, SwiGLU -> fp16, LayerScale + residual (fp32) against fp64 on the same fp16 operands: fp32 accumulation
+    error for the fp32 outputs, ONE fp16 rounding of the result for the 16-bit ones (+ 3.8e-5 absolute for the GELU's nine-coefficient polynomial)."""
     from foundpose_amd import ops
     if tile == 256 and (M % 256 or N % 256):
         pytest.skip("256 tile needs M, N multiples of 256")
@@ -44,7 +44,7 @@ def test_gemm_f16_epilogues_vs_fp64(M, N, K, tile):
     out = ops.gemm_bf16(ac, wc, bc, epilogue=0 | t).cpu()
     assert out.dtype == H and float((out.double() - ref).abs().max()) < 1.01 * EPS16 * scale
     out = ops.gemm_bf16(ac, wc, bc, epilogue=1 | t).cpu()
-    assert float((out.double() - torch.nn.functional.gelu(ref)).abs().max()) < 1.01 * EPS16 * scale
+    assert float((out.double() - torch.nn.functional.gelu(ref)).abs().max()) < 1.01 * EPS16 * scale + 4e-5
     out = ops.gemm_bf16(ac, wc, bc, epilogue=6 | t).cpu()
     sref = torch.nn.functional.silu(ref[:, 0::2]) * ref[:, 1::2]
     assert out.shape == (M, N // 2) and float((out.double() - sref).abs().max()) < 1.01 * EPS16 * float(sref.abs().max())
@@ -52,9 +52,9 @@ def test_gemm_f16_epilogues_vs_fp64(M, N, K, tile):
     ops.gemm_bf16(ac, wc, bc, gamma=gamma.cuda(), out=x, epilogue=3 | t)
     rref = resid.double() + gamma.double() * ref
     assert float((x.cpu().double() - rref).abs().max()) < 3e-5 * float(rref.abs().max()) * max(1, K / 1024)
-    out = torch.full((M, N), 7.0, dtype=H).cuda()   # rows past M_valid stay untouched
+    out = torch.full((M, N), 777.0, dtype=H).cuda()   # rows past M_valid stay untouched
     ops.gemm_bf16(ac, wc, bc, out=out, epilogue=0 | t, m_valid=M - 5)
-    assert torch.all(out[M - 5:] == 7.0) and torch.all(out[:M - 5] != 7.0)
+    assert torch.all(out[M - 5:] == 777.0) and torch.all(out[:M - 5] != 777.0)
 
 
 def test_gemm_f16_is_closer_to_fp32_than_bf16_on_the_same_fp32_operands():
@@ -85,10 +85,10 @@ def test_gemm_f16_tile_shapes_agree_bitwise(M, N, K, m_valid):
     for epi in (0, 1):
         outs = []
         for tile in (256, 320):
-            out = torch.full((M, N), 7.0, dtype=H, device="cuda")
+            out = torch.full((M, N), 777.0, dtype=H, device="cuda")
             ops.gemm_bf16(a, w, bias, out=out, epilogue=epi | (tile << 8), m_valid=m_valid)
             outs.append(out)
-        assert torch.equal(outs[0], outs[1]) and bool(torch.all(outs[1][m_valid:] == 7.0))
+        assert torch.equal(outs[0], outs[1]) and bool(torch.all(outs[1][m_valid:] == 777.0))
         assert torch.equal(ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, tile=256, m_valid=m_valid)[:m_valid],
                            ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, tile=320, m_valid=m_valid)[:m_valid])
     x0 = torch.randn(M, N, generator=g) * 3 + 0.7
@@ -125,9 +125,9 @@ def test_folded_layernorm_pair_and_hi_lo_stream_f16(tile, M, D, N2):
     xb7, st7 = ops.gemm_bf16_resid_ln(h.cuda(), w_out.cuda(), b_out.cuda(), x7, tile=tile, m_valid=mv)
     assert rel_err(x7[:mv].cpu(), x_ref[:mv]) < 3e-5
     assert torch.equal(xb[:mv], xb7[:mv]) and torch.equal(xb7[:mv].cpu(), x7[:mv].cpu().to(H))
-    got = xb.float() + xl.float()
-    err = (got[:mv].cpu().double() - x_ref[:mv]).abs() / x_ref[:mv].abs().clamp_min(1e-3)
-    assert float(err.max()) < 2e-5                                 # fp32 accumulation noise; the pair itself carries 21+ bits
+    got = (xb.float() + xl.float())[:mv].cpu().double()            # the pair represents epilogue 7's fp32 x' (the same value, asserted through xb above) ...
+    x7d = x7[:mv].cpu().double()
+    assert bool(((got - x7d).abs() <= 2.0 ** -21 * x7d.abs() + 6e-8).all())   # ... to 21+ bits (a low half below 6e-5 is an fp16 subnormal: 3e-8 absolute)
     assert torch.equal(xb[mv:].cpu(), hi[mv:]) and torch.equal(xl[mv:].cpu(), lo[mv:])
     torch.testing.assert_close(st[:, :mv], st7[:, :mv], rtol=2e-6, atol=2e-2)
     ln_row = ops.ln_finalize(st, D)
@@ -144,7 +144,7 @@ def test_folded_layernorm_pair_and_hi_lo_stream_f16(tile, M, D, N2):
         if epi == 1:
             ref = torch.nn.functional.gelu(ref)
         # (the massive channel makes rstd * (acc - mean * colsum) a cancellation of fp32 terms ~200 x the result: its noise rides on top of the rounding)
-        assert float((out - ref).abs().max()) < (1.5 * EPS16 + 2e-4) * float(ref.abs().max()), (epi, tile)
+        assert float((out - ref).abs().max()) < (1.5 * EPS16 + 2e-4) * float(ref.abs().max()) + 4e-5, (epi, tile)
 
 
 def _ref_attention(q, k, v, B, N, heads):
@@ -243,7 +243,8 @@ def test_extractor_f16_batch_invariance_token_selection_and_swiglu():
             os.environ.pop("FP_TOKEN_SELECT", None)
         outs.append(res)
     for f in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d", "query_tfidf"):
-        assert torch.equal(getattr(outs[0], f), getattr(outs[1], f)), f
+        x, y = getattr(outs[0], f), getattr(outs[1], f)
+        assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), f
     # SwiGLU architecture
     sdg = synthetic.make_vit_state_dict(TINY_G, seed=7)
     nm = f"dinov2_version={TINY_G.name}_stride=14_facet=token_layer=1_norm=1"
@@ -276,9 +277,10 @@ def test_extractor_f16_with_massive_activation_channels():
 
 @pytest.mark.parametrize("where", ["hidden", "qkv", "stream", "nan"])
 def test_f16_overflow_is_loud(where):
-    """fp16 has bf16's speed, not its range.  A 16-bit activation beyond +-65504 (or a NaN) is REPORTED: the device-side counter goes up, the
-    extractor's forward raises FoundPoseSaturationError and keeps raising until reset_saturation(), a result of the batched engine raises when read;
-    the bf16 mode computes the same weights without complaint."""
+    """fp16 has bf16's speed, not its range.  A 16-bit activation beyond +-65504 becomes inf, poisons the token's residual stream and -- through the
+    keys and values of the next attention -- the whole image: the last kernel of the pipeline finds non-finite features and REPORTS them (a NaN
+    likewise): the device-side counter goes up, the extractor's forward raises FoundPoseSaturationError and keeps raising until reset_saturation(), a
+    result of the batched engine raises when read; the bf16 mode computes the same weights without complaint."""
     from foundpose_amd import engine as fe, feature_util, workload
     from foundpose_amd.bank import DeviceBank
     arch = ARCHS["vits14-reg"]
@@ -296,7 +298,7 @@ def test_f16_overflow_is_loud(where):
         sd["blocks.1.attn.qkv.bias"][2 * arch.dim + 5] = float("nan")   # planted behind the load-time validation
     ex = ex.to("cuda")
     imgs = synthetic.make_crops(3, 112, seed=2).cuda()
-    with pytest.raises(_lib.FoundPoseSaturationError, match="beyond the fp16 range"):
+    with pytest.raises(_lib.FoundPoseSaturationError, match="beyond the fp16 range"):   # (the report comes from the final norm: non-finite features)
         ex(imgs)
     assert ex.saturation_counts()[0] > 0
     with pytest.raises(_lib.FoundPoseSaturationError):
