@@ -403,7 +403,34 @@ def main():
         tie_mode = 1 if args.tie_order == "torch" else 0
         knn = lambda mode: time_kernel(lambda: call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank.descs_n), ptr(bank.obj_tpl_off),
                                                     1, args.templates, W_words, 5, ptr(sims), ptr(sc), ptr(ids), mode, stream()), iters=50)  # the first object's templates
-        ms_knn, ms_knn_other = knn(tie_mode), knn(1 - tie_mode)
+        ms_knn, ms_knn_other = knn(tie_mode), knn(1 - tie_mode)   # WARM: back-to-back calls over one 82 MB bank, which the 256 MiB Infinity Cache keeps on the die
+        # COLD: the caches emptied before every call (2 GiB streamed through a 1 GiB buffer), one call per HIP-event pair -- the bank comes from HBM
+        evict = torch.zeros(1 << 28, device=dev)
+
+        def knn_cold(mode, iters=12):
+            tot = 0.0
+            for _ in range(iters):
+                evict.add_(1.0)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                call("fp_cosine_topk", ptr(desc_n), ptr(seg), ptr(nt), Bq, Bq, ptr(bank.descs_n), ptr(bank.obj_tpl_off), 1, args.templates, W_words, 5, ptr(sims), ptr(sc), ptr(ids),
+                     mode, stream())
+                e1.record()
+                e1.synchronize()
+                tot += e0.elapsed_time(e1)
+            return tot / iters
+        ms_knn_cold = knn_cold(tie_mode)
+        del evict
+        # IN THE PIPELINE: HIP events around the retrieval call inside 5 extra steps (behind the backbone and the word search of the same batch: tens of GB of
+        # ViT traffic have passed through the caches since the bank was last read) -- the figure profiles/*_per_step_kernels.csv reproduces
+        # (cosine_fused_kernel + cand_merge_replay_kernel) and the one `frac` is built on
+        eng.record_stage_times = True
+        ms_knn_pipe = 0.0
+        for _ in range(5):
+            fe.pack_result(eng.infer_batch(images, masks, det_obj))
+            ms_knn_pipe += 1e3 * eng.retrieval_time() / 5
+        eng.record_stage_times = False
+        knn_obj_dets = max(list(det_obj).count(o) for o in set(det_obj))   # detections per object in the step's retrieval call
         knn_bytes = args.templates * W_words * 4 + Bq * W_words * 4 + Bq * args.templates * 4   # bank (read once) + queries + finished scores
         knn_flops = 2.0 * Bq * args.templates * W_words
         # the same call at BASELINE config 5's bank size (50 000 templates, one 32-detection pass): the stream is long enough to
@@ -471,10 +498,16 @@ def main():
                                         "flops_per_detection_all_tokens": vit_flops_per_crop(arch, args.size, args.layer),
                                         "mfma_busy_pmc": PMC_MFMA_UTIL.get(key), "mfma_busy_pmc_source": PMC_MFMA_UTIL_SOURCE if key in PMC_MFMA_UTIL else None},
             "token_selection": sel_info,
-            "roofline_knn": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}' (template-descriptor streaming + top-5, whole call)", "bound": "hbm",
-                             "achieved": round(knn_bytes / (ms_knn * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                             "frac": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn, 4),
-                             "launch_ms_" + other: round(ms_knn_other, 4), "bytes_per_launch": knn_bytes, "detections_per_launch": Bq,
+            "roofline_knn": {"kernel": f"fp_cosine_topk, tie order '{args.tie_order}' (template-descriptor streaming + top-5, whole call = cosine_fused_kernel + cand_merge_replay_kernel)", "bound": "hbm",
+                             "achieved": round(knn_bytes / (ms_knn_pipe * 1e-3) / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                             "frac": round(knn_bytes / (ms_knn_pipe * 1e-3) / 1e9 / PEAK_HBM_GBS, 4), "launch_ms": round(ms_knn_pipe, 4),
+                             "what": "`achieved` / `frac` / `launch_ms` are the call as it runs INSIDE a step (HIP events around it, mean of 5 steps; north_star target 0.60: not met); "
+                                     "the cache-cold and the warm-cache probes of the same call are listed beside it",
+                             "launch_ms_in_pipeline": round(ms_knn_pipe, 4), "launch_ms_cold": round(ms_knn_cold, 4), "launch_ms_warm_cache": round(ms_knn, 4),
+                             "frac_cold": round(knn_bytes / (ms_knn_cold * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                             "frac_warm_cache": round(knn_bytes / (ms_knn * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                             "warm_cache_note": "back-to-back launches over the same 82 MB bank: it stays in the 256 MiB Infinity Cache, so this is not an HBM rate",
+                             "launch_ms_warm_cache_" + other: round(ms_knn_other, 4), "bytes_per_launch": knn_bytes, "detections_per_launch": Bq, "detections_per_launch_in_pipeline": knn_obj_dets,
                              "fp32_mfma_tflops": round(knn_flops / (ms_knn * 1e-3) / 1e12, 1), "fp32_mfma_peak": 157.3,
                              "note": "exact-fp32 scores: at 32 detections per bank pass the op sits at the fp32-MFMA / HBM ridge (16 FLOP/B vs 19.7), "
                                      "more detections per object add passes (32 at a time) and make it MFMA-bound"},
@@ -713,9 +746,10 @@ def hard_parity(args, wl, extractors, oracle_feats, ctx):
     q_cnt = [int(wlh.masks[b, 7::14, 7::14].sum()) for b in range(B)]
     q_off = np.concatenate([[0], np.cumsum(q_cnt)])
     srt = lambda ws: [np.sort(np.asarray(w), axis=1) for w in ws]
-    lists, words = {}, {}
+    lists, words, results = {}, {}, {}
     for prec, ex in extractors.items():
         res = fe.FoundPoseEngine(ex, bank_h, 14.0, 5, 300, tie_order=args.tie_order).infer_batch(wlh.crops, wlh.masks, wlh.det_obj, keep_debug=True)
+        results[prec] = res
         lists[prec] = [res.corresp_list(b) for b in range(B)]
         words[prec] = srt([res.word_ids[q_off[b]:q_off[b + 1]].cpu().numpy() for b in range(B)]) if (args.size % 14 == 0 and res.word_ids is not None) else None
     out = {"workload": f"as config.workload, but only template t_b of each detection is planted (features + {workload.HARD_NOISE[0]} sigma noise, "
@@ -736,6 +770,32 @@ def hard_parity(args, wl, extractors, oracle_feats, ctx):
             st = workload.parity_stats(lists[prec], lists["fp32"])
             st["by_stage"] = workload.stage_flips(lists[prec], lists["fp32"], words[prec], words["fp32"])
             out[prec + "_vs_fp32_mode"] = st
+    out["pose_under_noise"] = pose_under_noise(wlh, bank_h, results, B)
+    return out
+
+
+def pose_under_noise(wl, bank, results, B, sigmas=(0.5, 2.0)):
+    """north_star's third clause -- the final pose within 1e-4 relative on R, t -- measured where it can fail: the planted 2D-3D pairs carry sigma px of
+    reprojection noise (workload.noisy_vertices), so a mode whose correspondence indices differ from the fp32 mode's feeds the PnP-RANSAC tail
+    (/root/reference/scripts/infer.py:552-602, utils/pnp_util.py:20-84; here csrc/pnp.hip with a fixed seed) another inlier set and gets another pose.
+    Per sigma and mode: best coarse pose of every detection against the fp32 mode's on the same noisy bank, and the fp32 mode's own distance from the
+    planted pose (the noise floor the differences sit on)."""
+    from foundpose_amd import pnp_util, workload
+    out = {"what": "planted vertices re-derived from query pixels displaced by N(0, sigma^2) px; 400 RANSAC iterations, 10 px, confidence 0.99, LM refinement, seed 0; "
+                   "poses compared over all detections: max |dR| (entries), max relative |dt|, detections within 1e-4 on both, detections with identical poses"}
+    cams = [wl.K.numpy()] * B
+    for sg in sigmas:
+        V = workload.noisy_vertices(wl, sg, seed=11)
+        best = {prec: pnp_util.select_best_coarse(pnp_util.estimate_poses(workload.with_vertices(res, bank, V, wl.det_obj), cams, "opencv", 400, 10.0, 0.99, True))
+                for prec, res in results.items()}
+        entry = {}
+        if "fp32" in best:
+            truth = {"found": torch.ones(B, dtype=torch.bool, device=best["fp32"]["R"].device), "R": wl.R.to(best["fp32"]["R"].device), "t": wl.t.to(best["fp32"]["R"].device)}
+            entry["fp32_mode_vs_planted_pose"] = workload.pose_agreement(best["fp32"], truth)
+            for prec in best:
+                if prec != "fp32":
+                    entry[prec + "_vs_fp32_mode"] = workload.pose_agreement(best[prec], best["fp32"])
+        out[f"sigma_{sg}px"] = entry
     return out
 
 

@@ -18,7 +18,7 @@ FP_F32, FP_BF16, FP_FP8, FP_F16X3, FP_F16F8, FP_F16 = 0, 1, 2, 3, 4, 5
 GEMM_SPLIT_F16F8 = 1 << 20   # FP_GEMM_SPLIT_F16F8 of the header
 GEMM_F16 = 1 << 21           # FP_GEMM_F16 of the header: IEEE fp16 operands / outputs in fp_gemm_bf16, fp_gemm_bf16_ln
 SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -64,6 +64,8 @@ _PROTOS = {
     "fp_vit_sample_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp],
     "fp_query_select": [vp, i32, i32, i32, vp, vp, vp, i32, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp],
     "fp_vit_forward_prefix": [C.POINTER(VitModel), C.POINTER(VitWorkspace), vp, i32, i32, i32, i32, vp],
+    "fp_vit_stream_f32": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, vp, vp],
+    "fp_vit_forward_blocks": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp],
     "fp_vit_block_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, vp, vp, i32, i32, vp],
     "fp_vit_sample_features_selected": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, vp],
     "fp_vit_features": [C.POINTER(VitModel), C.POINTER(VitWorkspace), i32, i32, i32, vp, vp, vp],

@@ -484,9 +484,12 @@ struct VitSelection { const int32_t* rows; const int32_t* off; int num, max_per_
 // the fp32 stream ws->x, its bf16 copy and the LayerNorm row sums -- or, with ws->xl set (the default, FP_RESID_HILO=1) and layer > 0,
 // the (xb, xl) pair and the row sums ONLY: ws->x is then stale (it holds the token embedding) and must not be read by a caller.  VIT_LAST_SELECTED: block `layer` alone, computed for the selected
 // tokens only (queries of the attention, rows of proj / fc1 / fc2) on top of a VIT_PREFIX run -- keys and values are all tokens.
+// first_block > 0 (precision schedules, fp_vit_forward_blocks): no embedding -- the fp32 stream of blocks 0..first_block-1 is already in ws->x (another model's
+// blocks left it there) and blocks first_block..layer of THIS model continue from it (a folded-LayerNorm model starts its chain -- 16-bit copy, row sums -- from that stream).
 int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer, int mode,
-                     const VitSelection* sel, fp_stream_t stream) {
-  FP_REQUIRE(m && ws && (images || mode == VIT_LAST_SELECTED) && m->blocks, "fp_vit_forward: null pointer");
+                     const VitSelection* sel, fp_stream_t stream, int first_block = 0) {
+  FP_REQUIRE(m && ws && (images || mode == VIT_LAST_SELECTED || first_block > 0) && m->blocks, "fp_vit_forward: null pointer");
+  FP_REQUIRE(first_block >= 0 && first_block <= layer, "fp_vit_forward_blocks: first_block %d out of range (layer %d)", first_block, layer);
   FP_REQUIRE(layer >= -1 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);  // -1: token embedding only
   const int pstride = m->patch_stride > 0 ? m->patch_stride : m->patch;  // the conv stride of the patch embedding (dinov2_utils.py:364-389)
   FP_REQUIRE(pstride != m->patch || (H % m->patch == 0 && W % m->patch == 0), "fp_vit_forward: image size must be a multiple of the patch size");
@@ -514,7 +517,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
              "fp_vit_forward: fp8 row strides (bytes) must cover the row and keep 16-byte alignment");
 
   // tokens: [cls + pos0 | registers | patch_embed(x) + pos]
-  if (mode != VIT_LAST_SELECTED) {
+  if (mode != VIT_LAST_SELECTED && first_block == 0) {
   if (pstride == m->patch) TRY(patchify_launch(images, B, H, W, m->patch, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
   else TRY(patchify_strided_launch(images, B, H, W, m->patch, pstride, ws->patches, em * m->patch_k_pad, adt, st, FP_SPLIT_SCALE_ACT));
   TRY(prefix_tokens_launch(m->prefix, 1 + m->registers, D, ws->x, B, ntok, st));
@@ -594,7 +597,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     return h16 ? gemm_f16_launch(epi, g, st) : gemm_bf16_launch(epi, g, st);
   };
 
-  const int i_first = mode == VIT_LAST_SELECTED ? layer : 0, i_last = mode == VIT_PREFIX ? layer - 1 : layer;
+  const int i_first = mode == VIT_LAST_SELECTED ? layer : first_block, i_last = mode == VIT_PREFIX ? layer - 1 : layer;
   for (int i = i_first; i <= i_last; ++i) {
     const fp_vit_block& b = m->blocks[i];
     if (fold && mode == VIT_LAST_SELECTED) {
@@ -773,6 +776,22 @@ int fp_vit_forward_prefix(const fp_vit_model* m, const fp_vit_workspace* ws, con
                           int layer, fp_stream_t stream) {
   FP_REQUIRE(layer >= 0, "fp_vit_forward_prefix: layer must be >= 0");
   return vit_forward_impl(m, ws, images, B, H, W, layer, VIT_PREFIX, nullptr, stream);
+}
+
+int fp_vit_forward_blocks(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int H, int W, int first_block, int layer, int prefix_only, fp_stream_t stream) {
+  FP_REQUIRE(first_block >= 1, "fp_vit_forward_blocks: first_block must be >= 1 (fp_vit_forward runs the embedding and every block)");
+  return vit_forward_impl(m, ws, nullptr, B, H, W, layer, prefix_only ? VIT_PREFIX : VIT_FULL, nullptr, stream, first_block);
+}
+
+int fp_vit_stream_f32(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int H, int W, int layer, float* out, fp_stream_t stream) {
+  FP_REQUIRE(m && ws && out && layer >= 0, "fp_vit_stream_f32: null pointer");
+  const int pstride = m->patch_stride > 0 ? m->patch_stride : m->patch;
+  const int np = (1 + (H - m->patch) / pstride) * (1 + (W - m->patch) / pstride), rows = B * (1 + m->registers + np), D = m->dim;
+  const bool h16 = m->weight_dtype == FP_DTYPE_F16;
+  const bool pair = m->ln_fold && (m->weight_dtype == FP_DTYPE_BF16 || h16) && ws->xl != nullptr && layer > 0;   // what fp_vit_forward_prefix(layer) left behind
+  if (pair) return hilo_rows_launch(ws->xb, ws->xl, ws->ld_y ? ws->ld_y : D, nullptr, rows, D, out, ST(stream), h16);
+  if (out != ws->x) HIP_TRY(hipMemcpyAsync(out, ws->x, (size_t)rows * D * 4, hipMemcpyDeviceToDevice, ST(stream)), "fp_vit_stream_f32: copy");
+  return FP_OK;
 }
 
 int fp_vit_block_selected(const fp_vit_model* m, const fp_vit_workspace* ws, int B, int H, int W, int layer,

@@ -61,7 +61,7 @@ def _interpolate_pos_embed_strided(pos_embed: torch.Tensor, patch: int, stride: 
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, weights: Optional[str] = None,
                  random_init_seed: Optional[int] = None, precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
-                 act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True) -> None:
+                 act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True, head_blocks: int = 0, head_precision: str = "f16") -> None:
         """Weights (the reference: hub model with pretrained=True, dinov2_utils.py:81-84): `state_dict=` (upstream key names), `weights=` (checkpoint
         file, or directory holding the upstream file name), else $FOUNDPOSE_DINOV2_WEIGHTS, else the torch hub cache the reference's own call fills;
         none of them -> FoundPoseWeightsError.  Random weights only on an explicit `random_init_seed=` (tests, benchmarks).  Every dict is checked
@@ -122,6 +122,19 @@ class DinoFeatureExtractor(torch.nn.Module):
         # inside the blocks (they were 6.5 % of a step).  fold_layernorm=False keeps the kernel-per-LayerNorm sequence.
         self.fold_layernorm = (bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0") or precision == "f16"  # FP_LN_FOLD=0: A/B switch (bf16)
         self._sd, self.weights_source = _weights.resolve(self.model_base_name, self.arch, state_dict, weights, random_init_seed)
+        # Precision schedule: blocks 0 .. head_blocks-1 run in `head_precision`, blocks head_blocks .. layer in this extractor's own precision, over one
+        # fp32 stream (fp_vit_stream_f32 / fp_vit_forward_blocks): the fast "f16" pipeline in front of a near-exact tail, or the other way round.
+        # Measured and NOT a shipped default: see profiles/EXPERIMENTS.md "precision schedules" (tools/schedule_sweep.py).
+        self.head_blocks = int(head_blocks)
+        self._head: Optional["DinoFeatureExtractor"] = None
+        if self.head_blocks:
+            modes = ("f16", "f16x3", "f16f8", "fp32")
+            if precision not in modes or head_precision not in modes or not 0 < self.head_blocks <= self.layer or self.facet != "token" or use_graph:
+                raise ValueError("head_blocks: 1 .. layer blocks in one of 'f16' / 'f16x3' / 'f16f8' / 'fp32' in front of an extractor of another of them (token facet, no graph replay)")
+            # a folded-LayerNorm head stops BEFORE block k (fp_vit_forward_prefix, layer = k); the others run blocks 0 .. k-1 in full (fp_vit_forward, layer = k - 1)
+            self._head_fold = head_precision == "f16"
+            head_name = f"dinov2_version={self.version}_stride={self.stride}_facet=token_layer={self.head_blocks if self._head_fold else self.head_blocks - 1}_norm=1"
+            self._head = DinoFeatureExtractor(head_name, state_dict=self._sd, precision=head_precision, arch=arch)
         self._device: Optional[torch.device] = None
         self._w: Dict[str, torch.Tensor] = {}
         self._model = None
@@ -141,6 +154,8 @@ class DinoFeatureExtractor(torch.nn.Module):
         if dev.type != "cuda":
             raise _lib.FoundPoseNativeError("DinoFeatureExtractor runs on the MI355X only (device must be 'cuda'); no CPU path exists")
         self._prepare(dev)
+        if self._head is not None:
+            self._head.to(dev)
         return self
 
     def cuda(self, device=None):  # type: ignore[override]
@@ -341,6 +356,24 @@ class DinoFeatureExtractor(torch.nn.Module):
         self._ws.clear()
         self._graphs.clear()
 
+    def _run_backbone(self, images, ws, B: int, H: int, W: int, prefix_only: bool) -> None:
+        """fp_vit_forward / fp_vit_forward_prefix, or -- with a precision schedule -- the head's blocks in the f16 mode, its stream as fp32 into this
+        workspace, and this model's blocks behind it."""
+        if self._head is None:
+            call("fp_vit_forward_prefix" if prefix_only else "fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+            return
+        hd, k = self._head, self.head_blocks
+        gh, gw = hd._grid(H, W)
+        pos_patch, prefix = hd._grid_tables(gh, gw, H, W)
+        hd._model.pos_patch, hd._model.prefix = ptr(pos_patch), ptr(prefix)
+        hws, _ = hd._workspace(B, gh, gw)
+        if self._head_fold:
+            call("fp_vit_forward_prefix", C.byref(hd._model), C.byref(hws), ptr(images), B, H, W, k, stream())      # embedding + blocks 0 .. k-1, the stream as the (hi, lo) pair
+        else:
+            call("fp_vit_forward", C.byref(hd._model), C.byref(hws), ptr(images), B, H, W, k - 1, stream())         # embedding + blocks 0 .. k-1, the stream in its ws.x
+        call("fp_vit_stream_f32", C.byref(hd._model), C.byref(hws), B, H, W, k, ws.x, stream())                      # -> this workspace's fp32 stream
+        call("fp_vit_forward_blocks", C.byref(self._model), C.byref(ws), B, H, W, k, self.layer, int(prefix_only), stream())
+
     def _grid(self, H: int, W: int) -> Tuple[int, int]:
         """Patch tokens per axis (dinov2_utils.py:266-269): 1 + (size - patch) // stride; at stride == patch size the image must tile."""
         if self.stride == self.patch_size:
@@ -513,7 +546,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         ws, _ = self._workspace(B, gh, gw)
         if self.precision == "fp8" and self._model.weight_dtype != _lib.FP_FP8:
             raise _lib.FoundPoseNativeError("precision='fp8' needs its static activation scales before the first forward (act_scales= / calibrate_fp8)")
-        call("fp_vit_forward_prefix" if prefix_only else "fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        self._run_backbone(images, ws, B, H, W, prefix_only)
         self.num_patches = (gh, gw)
         self._hidden = (B, gh, gw, H, W)
         return B, gh, gw
@@ -651,7 +684,7 @@ class DinoFeatureExtractor(torch.nn.Module):
 
     def _launch(self, images, ws, B, H, W, gh, gw, fmap, cls) -> None:
         """The ~125 kernel launches of one forward (C++ launch sequence) on the current stream."""
-        call("fp_vit_forward", C.byref(self._model), C.byref(ws), ptr(images), B, H, W, self.layer, stream())
+        self._run_backbone(images, ws, B, H, W, False)
         call("fp_vit_features", C.byref(self._model), C.byref(ws), B, gh * gw, int(self.apply_norm), ptr(fmap), ptr(cls), stream())
 
     def _forward_graph(self, images, ws, B, H, W, gh, gw):

@@ -38,12 +38,27 @@ class FoundPoseEngine:
         # feat_extract / grid_sample / proj / corresp (scripts/infer.py:473-544), read back with stage_times()
         self.record_stage_times = False
         self._stage_events: List[Tuple[str, "torch.cuda.Event"]] = []
+        self._sub_events: dict = {}   # name -> event, inside a stage (match_batch's "retrieval_begin" / "retrieval_end")
 
     def _mark(self, name: str) -> None:
         if self.record_stage_times:
             e = torch.cuda.Event(enable_timing=True)
             e.record()
             self._stage_events.append((name, e))
+
+    def _submark(self, name: str) -> None:
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self._sub_events[name] = e
+
+    def retrieval_time(self) -> Optional[float]:
+        """Seconds the template retrieval (fp_cosine_topk: descriptor streaming + top-n) of the last infer_batch took INSIDE the step, behind the backbone and the
+        word search -- the bank comes from HBM there, not from a warm Infinity Cache (record_stage_times=True; synchronises)."""
+        b, e = self._sub_events.get("retrieval_begin"), self._sub_events.get("retrieval_end")
+        if b is None or e is None:
+            return None
+        e.synchronize()
+        return 1e-3 * b.elapsed_time(e)
 
     def stage_times(self) -> dict:
         """Seconds per stage of the last infer_batch (whole batch), keyed like the reference's per-detection `times`
@@ -172,7 +187,8 @@ class FoundPoseEngine:
         if not self.overlap_matching:
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")
-            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order,
+                              mark=self._submark if self.record_stage_times else None)
             self._mark("corresp")
             if track_sat:
                 res.extractor, res.sat_delta = self.extractor, sat_delta   # corresp_list() reads the verdict of this batch
@@ -186,7 +202,8 @@ class FoundPoseEngine:
                 t.record_stream(side)
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")
-            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order)
+            res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order,
+                              mark=self._submark if self.record_stage_times else None)
             self._mark("corresp")
             res.ready = torch.cuda.Event()
             res.ready.record(side)

@@ -103,6 +103,7 @@ def match_batch(
     keep_debug: bool = False,
     tie_order: str = "canonical",  # "canonical": (value, lowest index);  "torch": the reference's torch.topk CPU tie order
     word_metric: Optional[str] = None,  # metric of the visual-word search; default: each object's template_desc_opts.tfidf_knn_metric
+    mark=None,  # optional callable(name): called with "retrieval_begin" / "retrieval_end" around the template retrieval (the engine records HIP events there)
 ) -> MatchResult:
     require_cuda(query_features, query_points)
     if tie_order not in ("canonical", "torch"):
@@ -189,6 +190,8 @@ def match_batch(
     max_det = max(d1 - d0 for _, d0, d1 in groups) if groups else 1
     t_scores = torch.empty(B, n, dtype=torch.float32, device=dev)
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
+    if mark is not None:
+        mark("retrieval_begin")
     if bank.prefilter_applies(max_det, tie_mode) and os.environ.get("FP_COSINE_PREFILTER", "1") != "0":  # env: A/B switch (same outputs bit for bit)
         sims = torch.empty(cosine_prefilter_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)
         call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n), ptr(bank.descs_f16()),
@@ -197,6 +200,9 @@ def match_batch(
         sims = torch.empty(cosine_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)  # finished scores [B, T] + candidate keys
         call("fp_cosine_topk", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n),
              ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())
+
+    if mark is not None:
+        mark("retrieval_end")
 
     # ---- cyclic best buddies against the retrieved templates + correspondence assembly (the kernel pads its records itself)
     pairs = B * n   # (the kernels add the object's first template to the object-local ids themselves)

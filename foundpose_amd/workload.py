@@ -49,6 +49,7 @@ class PlantedWorkload:
     K: torch.Tensor                # [3, 3] crop camera intrinsics (f64)
     R: torch.Tensor                # [B, 3, 3] planted model->camera rotations (f64)
     t: torch.Tensor                # [B, 3] planted translations (f64)
+    planted_rows: Optional[List[Tuple[int, int, int, torch.Tensor]]] = None   # (object, first feature row (object-local), detection, query points [P, 2]) of every planted template
 
 
 def _random_rotations(n: int, g: torch.Generator) -> torch.Tensor:
@@ -166,6 +167,7 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
     lo, hi = max(1, int(0.58 * q_min)), max(1, int(0.87 * q_min))   # 300..450 patches per template at the 518 px disc mask
     targets = torch.zeros(batch, dtype=torch.int64)
     repres = []
+    planted_rows = []
     b_first = 0
     for o in range(num_objects):
         n_det = n_obj_det[o]
@@ -194,6 +196,7 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
                 rows = slice(int(off[tpl]), int(off[tpl]) + P)
                 feats[rows] = qb[sub] + nz * sigma * torch.randn(P, feat_dim, generator=gd, device=dev)
                 verts[rows] = planted_vertices(pb[sub], K, R[b], t[b]).to(dev)
+                planted_rows.append((o, int(off[tpl]), b, pb[sub].clone()))
         f2t = torch.repeat_interleave(torch.arange(T, dtype=torch.int32), pcounts).to(dev)
         opts = repre_util.TemplateDescOpts()
         descs, idfs, f2c = bank_builder.calc_tfidf_descriptors(feats, f2t, words, T, opts)
@@ -202,7 +205,39 @@ def build_planted_workload(extractor, batch: int, size: int, num_objects: int, t
             feat_to_vertex_ids=torch.arange(n_f, dtype=torch.int32, device=dev), feat_cluster_centroids=words,
             feat_cluster_idfs=idfs, template_descs=descs, template_desc_opts=opts, feat_raw_projectors=[proj]))
         b_first += n_det
-    return PlantedWorkload(crops, masks, det_obj, repres, targets, K, R, t)
+    return PlantedWorkload(crops, masks, det_obj, repres, targets, K, R, t, planted_rows)
+
+
+# ---------------------------------------------------------------------------------------------------- pose-level agreement under noise
+def noisy_vertices(wl: PlantedWorkload, sigma_px: float, seed: int = 0) -> torch.Tensor:
+    """The bank's vertices [N_f, 3] (objects concatenated, DeviceBank order) with every PLANTED 3D point re-derived from its query pixel displaced by
+    N(0, sigma_px^2) per axis: the 2D-3D pairs of the planted templates then carry sigma_px of reprojection noise, as on real data, and two different
+    inlier sets give two different poses (on the noise-free workload any subset of a planted template's correspondences yields the planted pose)."""
+    g = torch.Generator().manual_seed(seed)
+    verts = [r.vertices.clone() for r in wl.repres]
+    for obj, row0, b, pts in wl.planted_rows:
+        p = pts.cpu().to(torch.float64) + sigma_px * torch.randn(pts.shape[0], 2, generator=g, dtype=torch.float64)
+        verts[obj][row0:row0 + pts.shape[0]] = planted_vertices(p, wl.K, wl.R[b], wl.t[b]).to(verts[obj].device)
+    return torch.cat(verts, 0)
+
+
+def with_vertices(res, bank, vertices: torch.Tensor, det_obj: Sequence[int]):
+    """`res` (a MatchResult of `bank`) with coord_3d re-read from another vertex table through its feature ids (which do not depend on the vertices)."""
+    import dataclasses
+    base = torch.tensor([bank.objects[o].feat_base for o in det_obj], dtype=torch.int64, device=res.feat_ids.device)
+    rows = (res.feat_ids.to(torch.int64) + base[:, None, None]).clamp_(0, vertices.shape[0] - 1)    # (entries past counts[b, j] are padding: any row)
+    return dataclasses.replace(res, coord_3d=vertices.to(res.feat_ids.device)[rows].contiguous(), extractor=None, sat_delta=None)
+
+
+def pose_agreement(best: Dict[str, torch.Tensor], ref: Dict[str, torch.Tensor]) -> Dict:
+    """Best coarse poses (pnp_util.select_best_coarse) of two runs over the same detections: north_star's tolerance is 1e-4 relative on R, t."""
+    both = (best["found"] & ref["found"]).cpu()
+    dR = (best["R"] - ref["R"]).abs().amax(dim=(1, 2)).cpu()
+    dt = ((best["t"] - ref["t"]).norm(dim=1) / ref["t"].norm(dim=1)).cpu()
+    ok = both & (dR < 1e-4) & (dt < 1e-4)
+    same = both & (dR == 0) & (dt == 0)
+    return {"detections": int(both.numel()), "found_both": int(both.sum()), "max_abs_dR": float(dR[both].max()) if bool(both.any()) else None,
+            "max_rel_dt": float(dt[both].max()) if bool(both.any()) else None, "within_1e-4": int(ok.sum()), "identical": int(same.sum())}
 
 
 # ---------------------------------------------------------------------------------------------------- agreement statistics

@@ -64,7 +64,7 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4, FP_F16 =
  * absolute error <= 3e-8 (fp16 subnormals, which the MFMA honours). */
 #define FP_GEMM_F16 (1 << 21) /* OR-ed into fp_gemm_bf16's / fp_gemm_bf16_ln's `epilogue`: A, W, the 16-bit outputs and the (xb, xl) stream are IEEE fp16 */
 
-#define FP_ABI_VERSION 16
+#define FP_ABI_VERSION 17
 int fp_abi_version(void);
 const char* fp_last_error(void);
 
@@ -350,6 +350,15 @@ int fp_vit_forward_prefix(const fp_vit_model* model, const fp_vit_workspace* ws,
                           fp_stream_t stream);
 int fp_vit_block_selected(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int H, int W, int layer, const int32_t* sel_rows,
                           const int32_t* sel_off, int num_sel, int max_sel_per_img, fp_stream_t stream);
+/* Precision schedules: blocks 0..k-1 in one model (e.g. FP_F16), blocks k..layer in another (FP_F16X3 / FP_F16F8 / FP_F32) over the same fp32 stream.
+ *   fp_vit_stream_f32      the residual stream fp_vit_forward_prefix(model, ws, .., layer = k) -- or, for a model without folded LayerNorms, fp_vit_forward(.., layer =
+ *                          k - 1) -- left in its workspace (the (xb, xl) pair of a folded-LayerNorm model, else ws->x), as fp32 rows out [B * n_tok, D]: the `x` buffer
+ *                          of the second model's workspace;
+ *   fp_vit_forward_blocks  blocks first_block..layer (prefix_only: ..layer-1) of `model` on the stream already in ws->x: no embedding; 1 <= first_block <= layer.
+ *                          fp_vit_block_selected / fp_vit_features / fp_vit_sample_features* follow as after fp_vit_forward_prefix / fp_vit_forward. */
+int fp_vit_stream_f32(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int H, int W, int layer, float* out, fp_stream_t stream);
+int fp_vit_forward_blocks(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int H, int W, int first_block, int layer, int prefix_only,
+                          fp_stream_t stream);
 int fp_vit_sample_features_selected(const fp_vit_model* model, const fp_vit_workspace* ws, int B, int grid_h, int grid_w, int apply_norm,
                                     int img_w, int img_h, const float* points, const int32_t* point_img, int num_points,
                                     const int32_t* row_map, float* out, fp_stream_t stream);

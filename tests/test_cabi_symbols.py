@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols()), "ctypes prototypes out of sync with the header"
-    assert handle.fp_abi_version() == _lib.ABI_VERSION == 16
+    assert handle.fp_abi_version() == _lib.ABI_VERSION == 17
 
 
 def test_product_never_imports_oracle():

@@ -327,3 +327,39 @@ def test_f16_mode_loud_failures():
     a, w = torch.zeros(128, 64, dtype=H, device="cuda"), torch.zeros(128, 64, dtype=torch.bfloat16, device="cuda")
     with pytest.raises(ValueError, match="two bf16 or two fp16"):
         ops.gemm_bf16(a, w, torch.zeros(128, device="cuda"))
+
+
+@pytest.mark.parametrize("head,tail", [("f16", "f16x3"), ("f16f8", "f16")])
+def test_precision_schedule_runs_two_models_over_one_stream(head, tail):
+    """head_blocks = k: blocks 0..k-1 in one precision, blocks k..layer in another, over one fp32 stream (fp_vit_stream_f32 / fp_vit_forward_blocks) -- a
+    measurement device (tools/schedule_sweep.py), not a shipped default.  The composition is exact at its seams: with the SAME precision on both sides
+    of the cut (fp32 | fp32) the features equal the single model's to the last bit; mixed precisions land between the two pure modes' distances from the fp32
+    oracle; the engine's token-selected path equals the full path bit for bit."""
+    from foundpose_amd import engine as fe, feature_util, workload
+    from foundpose_amd.bank import DeviceBank
+    arch = ARCHS["vits14-reg"]
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=6_norm=1"
+    sd = synthetic.make_vit_state_dict(arch, seed=4)
+    imgs = synthetic.make_crops(3, 224, seed=1)
+    ref = ov.extractor_forward(sd, arch, imgs, 6, True)["feature_maps"]
+    mk = lambda prec, **kw: feature_util.make_feature_extractor(name, state_dict=sd, precision=prec, **kw).to("cuda")
+    whole = mk("fp32")(imgs.cuda())["feature_maps"]
+    cut = mk("fp32", head_blocks=3, head_precision="fp32")(imgs.cuda())["feature_maps"]
+    assert torch.equal(whole, cut)
+    e = {p: rel_err(mk(p)(imgs.cuda())["feature_maps"].cpu(), ref) for p in (head, tail)}
+    ex = mk(tail, head_blocks=3, head_precision=head)
+    got = rel_err(ex(imgs.cuda())["feature_maps"].cpu(), ref)
+    assert got < 1.5 * max(e.values()) + 1e-5, (got, e)
+    wl = workload.build_planted_workload(mk("fp32"), 3, 224, 1, 60, seed=3, crop_seed=2)
+    bank = DeviceBank(wl.repres)
+    import os
+    outs = []
+    for sel in ("1", "0"):
+        os.environ["FP_TOKEN_SELECT"] = sel
+        try:
+            outs.append(fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj))
+        finally:
+            os.environ.pop("FP_TOKEN_SELECT", None)
+    for f in ("template_ids", "counts", "q_ids", "feat_ids", "dists", "coord_3d"):
+        x, y = getattr(outs[0], f), getattr(outs[1], f)
+        assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), f
