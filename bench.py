@@ -181,8 +181,8 @@ def main():
         extractor.calibrate_fp8(images)  # static activation scales are part of the fp8 model (no implicit calibration)
     eng = fe.FoundPoseEngine(extractor, bank, 14.0, 5, 300, tie_order=args.tie_order, overlap_matching=args.overlap)
     if args.no_token_select:
-        os.environ["FP_TOKEN_SELECT"] = "0"
-    select_on = extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0" and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"
+        eng.select_tokens = False
+    select_on = extractor.supports_token_selection and eng.select_tokens and eng.fused_sample
 
     def step(e=eng, inp=None):
         res = e.infer_batch(*(inp if inp is not None else (images, masks, det_obj)))
@@ -273,10 +273,10 @@ def main():
     sel_total = B * n_tok_img
     if select_on:
         sel_total = eng._query_points_end(*eng._query_points_begin(masks, select_tokens=True))[3][3]
-        os.environ["FP_TOKEN_SELECT"] = "0"
+        eng.select_tokens = False
         step()
         el_ns, _ = timed(eng, 5)
-        os.environ["FP_TOKEN_SELECT"] = "1"
+        eng.select_tokens = True
         sel_info.update({"selected_tokens_per_crop": round(sel_total / B, 1), "tokens_per_crop": n_tok_img,
                          "ms_per_step_all_tokens": round(1e3 * el_ns / 5, 3),
                          "note": "the hooked block computes attention queries, proj and the MLP for the patch tokens under the sampling taps of the query "
@@ -329,7 +329,7 @@ def main():
         # ---- roofline of the dominant kernel = the largest time bucket of a step: the LayerScale+residual GEMM template
         # (gemm_bf16_kernel<LS_RESID>), launched twice per block: attn.proj (K = D) and mlp.fc2 (K = hidden)
         fold = getattr(extractor, "fold_layernorm", False)   # bf16: the block LayerNorms live inside these GEMMs (fp_vit_model.ln_fold)
-        hilo = fold and (os.environ.get("FP_RESID_HILO", "1") != "0" or args.precision == "f16")   # ... and the residual stream in front of the hooked block is a (hi, lo) 16-bit pair
+        hilo = fold and getattr(extractor, "resid_hilo", False)   # ... and the residual stream in front of the hooked block is a (hi, lo) 16-bit pair
         from foundpose_amd._lib import call as _call, ptr as _ptr, stream as _stream
 
         dt16 = torch.float16 if args.precision == "f16" else torch.bfloat16
@@ -350,7 +350,7 @@ def main():
                 col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
                 return time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=out, epilogue=epi, m_valid=mv))
             if fold and epi == 3:   # the kernel the pipeline launches 36 times per step: the residual update on the (hi, lo) bf16 stream + LayerNorm row
-                xb = torch.zeros(M, n, dtype=dt16, device=dev)   # sums (epilogue 8; FP_RESID_HILO=0: fp32 stream + bf16 copy, epilogue 7)
+                xb = torch.zeros(M, n, dtype=dt16, device=dev)   # sums (epilogue 8; resid_hilo=False: fp32 stream + bf16 copy, epilogue 7)
                 st = torch.zeros(n // 128, M, 2, device=dev)
                 if hilo:
                     xl = torch.zeros(M, n, dtype=dt16, device=dev)

@@ -16,9 +16,10 @@ LIB_PATH = os.environ.get("FOUNDPOSE_AMD_LIB") or os.path.join(_HERE, "lib", "li
 
 FP_F32, FP_BF16, FP_FP8, FP_F16X3, FP_F16F8, FP_F16 = 0, 1, 2, 3, 4, 5
 GEMM_SPLIT_F16F8 = 1 << 20   # FP_GEMM_SPLIT_F16F8 of the header
+VIT_NO_TALL_TILES = 1        # FP_VIT_NO_TALL_TILES of the header (fp_vit_model.flags)
 GEMM_F16 = 1 << 21           # FP_GEMM_F16 of the header: IEEE fp16 operands / outputs in fp_gemm_bf16, fp_gemm_bf16_ln
 SPLIT_SCALE_ACT, SPLIT_SCALE_QKV, SPLIT_SCALE_HID = 16.0, 16.0, 4.0  # FP_SPLIT_SCALE_* of the header
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 vp, i32, i64, f32, f64, u64 = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_double, C.c_uint64
 
@@ -35,7 +36,7 @@ class VitModel(C.Structure):
         ("dim", i32), ("depth", i32), ("heads", i32), ("hidden", i32), ("registers", i32), ("patch", i32),
         ("ffn_swiglu", i32), ("weight_dtype", i32),
         ("patch_w", vp), ("patch_k_pad", i32), ("patch_b", vp), ("pos_patch", vp), ("prefix", vp),
-        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("patch_stride", i32), ("patch_acc_scale", f32), ("ln_fold", i32),
+        ("norm_w", vp), ("norm_b", vp), ("blocks", C.POINTER(VitBlock)), ("ld_w_dim", i32), ("ld_w_hidden", i32), ("patch_stride", i32), ("patch_acc_scale", f32), ("ln_fold", i32), ("flags", i32),
     ]
 
 
@@ -48,6 +49,7 @@ class VitWorkspace(C.Structure):
 
 _PROTOS = {
     "fp_abi_version": [],
+    "fp_build_experiments": [],
     "fp_sqnorm_rows": [vp, i64, i32, vp, vp],
     "fp_normalize_rows": [vp, i64, i32, f32, vp, vp],
     "fp_knn_l2": [vp, vp, i32, vp, vp, i32, i32, i32, vp, vp, vp, vp],

@@ -13,7 +13,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(HERE, "lib", "obj")
 SO = os.path.join(LIBDIR, "libfoundpose_amd.so")
-SOURCES = ["api.cpp", "f32_tile.hip", "knn_cand.hip", "match.hip", "gemm_bf16.hip", "gemm_fp8.hip", "gemm_split.hip", "gemm_splitx.hip", "gemm_f16.hip", "attn.hip", "vit.hip", "crop.hip", "pnp.hip"]
+SOURCES = ["api.cpp", "f32_tile.hip", "match.hip", "gemm_bf16.hip", "gemm_fp8.hip", "gemm_split.hip", "gemm_splitx.hip", "gemm_f16.hip", "attn.hip", "vit.hip", "crop.hip", "pnp.hip"]
 HEADERS = ["common.hpp", "kernels.hpp", "stl_order.hpp", "stl_wave.hpp", "gemm_bf16.hip", os.path.join("..", "..", "include", "foundpose_amd.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=on", "-Wno-unused-value",
          # MFMA results feed VALU epilogues/softmax directly: keep accumulators in the VGPR half of the unified
@@ -25,12 +25,19 @@ def _newer(a, b):
     return not os.path.exists(b) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+EXPERIMENT_SOURCES = ["knn_cand.hip"]   # measured-slower kernels kept for A/B runs: FP_EXPERIMENTS=1 python -m foundpose_amd.build [--force]
+
+
 def build(force: bool = False, verbose: bool = True) -> str:
+    """The shipped library.  FP_EXPERIMENTS=1 in the environment of THIS BUILD TOOL (never read by the library) compiles every source with -DFP_EXPERIMENTS
+    and adds the experiment kernels (include/foundpose_amd.h fp_build_experiments); switching between the two needs --force."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    experiments = os.environ.get("FP_EXPERIMENTS", "0") not in ("", "0")
     os.makedirs(OBJDIR, exist_ok=True)
     hdr_paths = [os.path.join(CSRC, h) for h in HEADERS]
     jobs = []
-    for src in SOURCES:
+    flags = FLAGS + (["-DFP_EXPERIMENTS"] if experiments else [])
+    for src in SOURCES + (EXPERIMENT_SOURCES if experiments else []):
         sp = os.path.join(CSRC, src)
         obj = os.path.join(OBJDIR, os.path.splitext(src)[0] + ".o")
         stale = force or _newer(sp, obj) or any(_newer(h, obj) for h in hdr_paths)
@@ -40,7 +47,7 @@ def build(force: bool = False, verbose: bool = True) -> str:
         sp, obj, stale = job
         if not stale:
             return
-        cmd = [hipcc, *FLAGS, "-x", "hip", "-c", sp, "-o", obj]
+        cmd = [hipcc, *flags, "-x", "hip", "-c", sp, "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

@@ -42,6 +42,13 @@ static F32TileArgs zero_tile_args() {
 extern "C" {
 
 int fp_abi_version(void) { return FP_ABI_VERSION; }
+int fp_build_experiments(void) {
+#ifdef FP_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char* fp_last_error(void) { return g_err; }
 
 // ------------------------------------------------------------------ matching half
@@ -57,12 +64,15 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
 
 // The two-stage search of csrc/knn_cand.hip (fp16-MFMA candidate pass with a derived bound + exact re-scoring; outputs bit-identical to
 // the all-pairs exact tile) is built and tested but NOT the default: measured on the bench shapes it is slower than the exact-fp32 tile it
-// was meant to replace (word 3-NN 234 vs 221 us, cyclic searches 419 vs 338 us: profiles/EXPERIMENTS.md "Two-stage k-NN").  FP_KNN_CAND=1
-// switches it on (read per call, so a test can compare both paths in one process).
+// was meant to replace (word 3-NN 234 vs 221 us, cyclic searches 419 vs 338 us: profiles/EXPERIMENTS.md "Two-stage k-NN").  It is compiled into
+// FP_EXPERIMENTS builds only (FP_EXPERIMENTS=1 python -m foundpose_amd.build), where FP_KNN_CAND=1 switches it on (read per call, so a test can compare
+// both paths in one process); the shipped library has neither the kernels nor the switch.
+#ifdef FP_EXPERIMENTS
 static bool knn_cand_enabled() {
   const char* e = getenv("FP_KNN_CAND");
   return e != nullptr && atoi(e) != 0;
 }
+#endif
 
 int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, const float* db_sqnorm, int n, int d,
               int k, void* scratch, float* out_d2, int32_t* out_idx, fp_stream_t stream) {
@@ -71,6 +81,7 @@ int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, con
   if (m == 0) return FP_OK;
   // 2 <= k <= 4 against a database of some size (the visual-word search: k = 3, 2048 words), opt-in (FP_KNN_CAND=1): fp16-MFMA candidate
   // pass + exact fp32 chains on the candidates (knn_cand.hip) -- the same d2 / indices as the all-pairs exact tile below, bit for bit.
+#ifdef FP_EXPERIMENTS
   if (k >= 2 && n >= 256 && knn_cand_enabled() && knn_cand_supported(k, d) && out_d2) {
     KnnCandArgs c;
     memset(&c, 0, sizeof(c));
@@ -78,6 +89,7 @@ int fp_knn_l2(const float* q, const float* q_sqnorm, int m, const float* db, con
     c.k = k; c.pairs = 1; c.row_stride = m; c.out_d2 = out_d2; c.out_idx = out_idx;
     return knn_cand_launch(c, m, n, scratch, ST(stream));
   }
+#endif
   F32TileArgs a = zero_tile_args();
   a.A = q; a.lda = d; a.B = db; a.ldb = d; a.K = d; a.M = m; a.N = n;
   a.a_sqnorm = q_sqnorm; a.b_sqnorm = db_sqnorm;
@@ -180,7 +192,13 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
   if (pairs == 0) return FP_OK;
   CyclicArgs c;
   memset(&c, 0, sizeof(c));
-  if (knn_cand_enabled() && knn_cand_supported(1, d) && pairs <= KNN_CAND_MAX_PAIRS) {  // beyond the launch's grid limits: the all-pairs tile below, same keys
+#ifdef FP_EXPERIMENTS
+  const bool use_cand = knn_cand_enabled() && knn_cand_supported(1, d) && pairs <= KNN_CAND_MAX_PAIRS;   // beyond the launch's grid limits: the all-pairs tile below, same keys
+#else
+  constexpr bool use_cand = false;
+#endif
+  if (use_cand) {
+#ifdef FP_EXPERIMENTS
     // the two 1-NN searches of a pair (corresp_util.py:46-47) by candidate pass + exact re-scoring (knn_cand.hip): query patch -> nearest
     // template patch into row_best [pairs, q_max], template patch -> nearest query patch into col_best [pairs, p_max]; the same keys
     // (d2, index; ties -> lowest index) the all-pairs tile below leaves, so everything downstream is unchanged
@@ -197,6 +215,7 @@ int fp_cyclic_buddies(const float* query_feats, const float* query_sqnorm, const
     kc.swap = 1; kc.row_stride = p_max; kc.out_keys = col_best;
     TRY(knn_cand_launch(kc, p_max, q_max, cand, ST(stream)));
     c.row_best = row_best; c.row_stride = q_max; c.col_best = col_best; c.col_stride = p_max; c.row_parts = 1; c.col_parts = 1;
+#endif
   } else {
   // partial nearest-neighbour tables, one slice per distance tile (no atomics, no preset): [pairs, col tiles, q_max] + [pairs, row tiles, p_max]
   const int row_parts = (p_max + 127) / 128, col_parts = (q_max + 127) / 128;
@@ -359,14 +378,14 @@ int fp_gemm_bf16_timeline(const void* A, int lda, const void* W, int ldw, int M,
 #endif
 
 static int gemm_fp8_impl(const void* A, int lda, const void* W, int ldw, int M, int N, int K, int M_valid, const float* bias,
-                         const float* col_scale, void* out, int ldo, int epilogue, float out_scale, int* sat, fp_stream_t stream) {
+                         const float* col_scale, void* out, int ldo, int epilogue, float out_scale, int* sat, fp_stream_t stream, int no_tall = 0) {
   FP_REQUIRE(A && W && out, "fp_gemm_fp8: null pointer");
   FP_REQUIRE(out_scale >= 0.f, "fp_gemm_fp8: out_scale must be >= 0");
   GemmBf16Args a;
   memset(&a, 0, sizeof(a));
   a.A = reinterpret_cast<const __bf16*>(A); a.lda = lda; a.W = reinterpret_cast<const __bf16*>(W); a.ldw = ldw;
   a.M = M; a.N = N; a.K = K; a.M_valid = M_valid; a.bias = bias; a.gamma = col_scale; a.out = out; a.ldo = ldo;
-  a.out_scale = out_scale; a.sat = sat;
+  a.out_scale = out_scale; a.sat = sat; a.no_tall = no_tall;
   a.tile_override = (epilogue >> 8) & 0xfff;  // tuning bits: 256 / 320 force that block tile (benchmarks, tests)
   FP_REQUIRE(a.tile_override == 0 || a.tile_override == 256 || a.tile_override == 320, "fp_gemm_fp8: bad tile override %d", a.tile_override);
   return gemm_fp8_launch(epilogue & 0xff, a, ST(stream));
@@ -402,7 +421,9 @@ int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B
   out_dtype &= 0xff;
   FP_REQUIRE(out_dtype == FP_DTYPE_F16X3 || out_dtype == FP_DTYPE_F16F8, "fp_attention_split: the output is a split-fp16 row (FP_F16X3) or an f16f8 row (FP_F16F8)");
   FP_REQUIRE(variant <= 2, "fp_attention_split: unknown kernel variant %d", variant);
-  FP_REQUIRE(in_scale > 0.f && out_scale > 0.f, "fp_attention_split: scales must be positive");
+  // in_scale >= 1: the kernel's lazy-rescale threshold is a constant in raw score units (1 / (0.125 log2 e), attn.hip SPLIT_LAZY_TH) and the scores carry
+  // in_scale^2 -- in exponent units the reference trails the maximum by at most 1 / in_scale^2, so p' = 2^14 p <= 2^15 fits fp16 for in_scale >= 1 only
+  FP_REQUIRE(in_scale >= 1.f && out_scale > 0.f, "fp_attention_split: in_scale must be >= 1 (the split P is packed unclamped: p' <= 2^15 needs it) and out_scale positive");
   AttnArgs a;
   memset(&a, 0, sizeof(a));
   a.variant = variant;
@@ -592,6 +613,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
     memset(&g, 0, sizeof(g));
     g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
     g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
+    g.no_tall = (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0;
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
     if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; g.xl = reinterpret_cast<__bf16*>(ws->xl); }
     return h16 ? gemm_f16_launch(epi, g, st) : gemm_bf16_launch(epi, g, st);
@@ -708,7 +730,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       LayerNormArgs l8 = ln;
       l8.out = ws->a8; l8.ld_out = ld8y; l8.out_dtype = FP_DTYPE_FP8; l8.out_scale = b.act_scale[0];
       TRY(layernorm_launch(l8, st));
-      TRY(gemm_fp8_impl(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, ws->sat, stream));
+      TRY(gemm_fp8_impl(ws->a8, ld8y, b.qkv_w, ld8wd, ws->m_pad, 3 * D, D, Mtok, b.qkv_b, b.qkv_s, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, 0.f, ws->sat, stream, (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0));
       AttnArgs a8 = at;
       a8.out = ws->a8; a8.ld_out = ld8y; a8.out_fp8_scale = b.act_scale[1];
       float* xr = ws->x;  // the residual rows the rest of the block updates
@@ -724,14 +746,14 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       } else {
         TRY(attn_launch(a8, FP_DTYPE_BF16, st));
       }
-      TRY(gemm_fp8_impl(ws->a8, ld8y, b.proj_w, ld8wd, rp, D, D, rv, b.proj_b, b.proj_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
+      TRY(gemm_fp8_impl(ws->a8, ld8y, b.proj_w, ld8wd, rp, D, D, rv, b.proj_b, b.proj_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream, (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0));
       l8.weight = b.ln2_w; l8.bias = b.ln2_b; l8.out_scale = b.act_scale[2];
       TRY(layernorm_launch(l8, st));
       if (m->ffn_swiglu)
-        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, 2 * m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], ws->sat, stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, 2 * m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_SWIGLU_BF16, b.act_scale[3], ws->sat, stream, (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0));
       else
-        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], ws->sat, stream));
-      TRY(gemm_fp8_impl(ws->h, ld8h, b.fc2_w, ld8wh, rp, D, m->hidden, rv, b.fc2_b, b.fc2_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream));
+        TRY(gemm_fp8_impl(ws->a8, ld8y, b.fc1_w, ld8wd, rp, m->hidden, D, rv, b.fc1_b, b.fc1_s, ws->h, ld8h, GEMM_EPI_GELU_BF16, b.act_scale[3], ws->sat, stream, (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0));
+      TRY(gemm_fp8_impl(ws->h, ld8h, b.fc2_w, ld8wh, rp, D, m->hidden, rv, b.fc2_b, b.fc2_s, xr, D, GEMM_EPI_LS_RESID_F32, 0.f, ws->sat, stream, (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0));
       continue;
     }
     TRY(layernorm_launch(ln, st));

@@ -609,7 +609,11 @@ __global__ __launch_bounds__(NW * 64, 2) void attn_bf16_w64_kernel(AttnArgs a) {
 //   K image [64 keys][256 B]: 16-B chunk p of row r holds chunk p ^ (r & 15)        (b128 fragment reads: 16 lanes, 16 rows, 16 slots)
 //   V image [64 keys][256 B]: 64-B unit  u of row r holds unit  u ^ (r & 3)         (transpose reads: a half-wave's four keys x 64 B
 //                                                                                    fall into the four bank quarters)
-constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);  // 1 in the exponent, in score units
+// 1 in the exponent for UNSCALED scores, in score units.  The scores carry in_scale^2 (c = 0.125 log2 e / in_scale^2), so in exponent units the reference
+// trails the running maximum by at most 1 / in_scale^2 (1/256 at the pipeline's in_scale = 16: the rescale fires on most increases of the maximum -- kept,
+// because the threshold is part of the mode's recorded arithmetic).  p <= 2 -- what the unclamped packing of p' = 2^14 p relies on -- holds for in_scale >= 1,
+// which attn_launch / fp_attention_split require.
+constexpr float SPLIT_LAZY_TH = 1.f / (0.125f * 1.44269504088896340736f);
 
 // Per-wave state and the three per-tile phases both split-fp16 kernels run (the schedules differ, the arithmetic does not: bit-identical outputs).
 //   scores():  S^T = K Q^T for 64 keys.  A-row i of a 32-key half holds key i with bits 2 and 3 swapped, so that output register r of lane
@@ -1041,7 +1045,8 @@ __global__ __launch_bounds__(512, 2) void attn_split_kernel(AttnArgs a) {
   if (active) split_attn_store(a, w.oacc, w.l_run, q0, l31, kh, NQ, sel_base, img, N, head);
 }
 
-// ---------------------------------------------------------------- split-fp16, role-split ("ping-pong") form: the default of the f16x3 / f16f8 modes
+#ifdef FP_EXPERIMENTS   // built, bit-identical and ~3 % SLOWER than attn_split_kernel (profiles/EXPERIMENTS.md round 5): measurement builds only
+// ---------------------------------------------------------------- split-fp16, role-split ("ping-pong") form (AttnArgs.variant 2 of the split kernels)
 // The same arithmetic as attn_split_kernel, instruction for instruction per query (same MFMA order per accumulator, same softmax, same
 // epilogue: bit-identical outputs), on another schedule.  In the lock-step kernel the two waves a 512-thread workgroup places on each SIMD
 // (waves w and w + 4) walk S -> softmax -> P V together behind one barrier per key tile, so the SIMD's matrix pipe idles while both waves are
@@ -1284,6 +1289,7 @@ __global__ __launch_bounds__(512, 2) void attn_split_pp_kernel(AttnArgs a) {
 #endif
   if (active) split_attn_store(a, w.oacc, w.l_run, q0, l31, kh, NQ, sel_base, img, N, head);
 }
+#endif  // FP_EXPERIMENTS
 
 // ---------------------------------------------------------------- fp32 parity-mode attention
 // qkv fp32 [B*N, 3D]; one thread per query row; keys/values of the (image, head) streamed through LDS.
@@ -1500,7 +1506,11 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
     FP_REQUIRE(!h16 || (a.variant == 0 && a.out_fp8_scale <= 0.f && (size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull),
                "attention(f16): the default kernel only (no work-split variants, no fp8 output), one image's qkv rows within 4 GiB");
     FP_REQUIRE(a.ld_qkv % 8 == 0 && (a.out_fp8_scale > 0.f ? a.ld_out % 4 == 0 : a.ld_out % 8 == 0), "attention(bf16): leading dims must keep 16-byte alignment");
+#ifdef FP_EXPERIMENTS
     FP_REQUIRE(a.variant >= 0 && a.variant <= 4, "attention: unknown kernel variant %d", a.variant);
+#else   // the shipped library: the default work split and its 32-queries-per-wave cross-check; 2, 3, 4 (measured slower) live in FP_EXPERIMENTS builds
+    FP_REQUIRE(a.variant == 0 || a.variant == 1, "attention: kernel variant %d exists in FP_EXPERIMENTS builds only (0 = default, 1 = the cross-check kernel)", a.variant);
+#endif
 #ifdef FP_ATTN_DEFAULT_VARIANT  // (measurement build for same-box A/B runs of the whole pipeline: that split where 0 was asked for)
     const int variant = a.variant == 0 ? FP_ATTN_DEFAULT_VARIANT : a.variant;
 #else
@@ -1516,13 +1526,15 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
       // Block order: the last query tile of an (image, head) pair is short (1374 tokens = 5 x 256 + 94: the QC = 1 tail block ends in about half
       // the time).  Interleaved with the full blocks the short ones leave the final round of the launch as long as a full block; at the END of
       // each XCD's sequence the launch drains through half-length blocks: 343.6 -> 335.9 us in isolation, pipeline 1107.2 vs 1101.1 detections/s
-      // (same box, three alternations).  FP_ATTN_TAIL_LAST=0 is the A/B switch.
-      static const int tail_last = getenv("FP_ATTN_TAIL_LAST") ? atoi(getenv("FP_ATTN_TAIL_LAST")) : 1;
-      a.tail_last = tail_last;
+      // (same box, three alternations; AttnArgs.tail_last = 0 is the other order).
+      a.tail_last = 1;
+#ifdef FP_EXPERIMENTS
       if (variant == 3) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 8>), dim3(grid), dim3(512), 0, st, a);
       else if (variant == 4) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, true>), dim3(grid), dim3(256), 0, st, a);
       else if (w64 == 2) hipLaunchKernelGGL(attn_bf16_w64_kernel<1>, dim3(grid), dim3(512), 0, st, a);
-      else if (h16) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
+      else
+#endif
+      if (h16) hipLaunchKernelGGL((attn_bf16_w64_kernel<2, 4, false, true>), dim3(grid), dim3(256), 0, st, a);
       else hipLaunchKernelGGL(attn_bf16_w64_kernel<2>, dim3(grid), dim3(256), 0, st, a);
     } else {
       hipLaunchKernelGGL(attn_bf16_kernel, dim3(cdiv(a.n_tok, 128) * a.heads * a.batch), dim3(256), 0, st, a);
@@ -1530,16 +1542,18 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
   } else if (dtype == FP_DTYPE_F16X3) {
     FP_REQUIRE(!a.sel_off || (a.sel_rows && a.max_sel >= 1), "attention: query selection needs sel_rows, sel_off and max_sel >= 1");
     FP_REQUIRE(a.ld_qkv % 8 == 0 && a.ld_qkv >= 6 * a.dim && a.ld_out % 8 == 0 && a.ld_out >= 2 * a.dim, "attention(f16x3): rows are split-fp16 (6D / 2D halves), 16-byte aligned");
-    FP_REQUIRE(a.in_scale > 0.f && a.out_scale > 0.f, "attention(f16x3): the operand and output scales must be positive");
+    FP_REQUIRE(a.in_scale >= 1.f && a.out_scale > 0.f, "attention(f16x3): in_scale must be >= 1 (SPLIT_LAZY_TH is a constant in raw score units; p' = 2^14 p must stay <= 2^15) and out_scale positive");
     FP_REQUIRE((size_t)a.n_tok * a.ld_qkv * 2 < 0xffffffffull, "attention(f16x3): one image's qkv rows must fit a 4-GiB buffer resource");
-    static const int tail_last = getenv("FP_ATTN_TAIL_LAST") ? atoi(getenv("FP_ATTN_TAIL_LAST")) : 1;
-    a.tail_last = tail_last;
+    a.tail_last = 1;
     const dim3 grid((unsigned)(cdiv(a.sel_off ? a.max_sel : a.n_tok, 256) * a.heads * a.batch));
-    // variant 1 = the lock-step kernel, 2 = the role-split kernel (attn_split_pp_kernel's header; bit-identical), 0 = the default of the two
-    static const int pp_default = getenv("FP_ATTN_SPLIT_PP") ? atoi(getenv("FP_ATTN_SPLIT_PP")) : 0;
-    if (a.variant == 1 || (a.variant == 0 && !pp_default)) {
+    // variant 0 / 1 = the lock-step kernel (what the pipeline runs), 2 = the role-split kernel (attn_split_pp_kernel's header; bit-identical, FP_EXPERIMENTS builds)
+    if (a.variant != 2) {
       hipLaunchKernelGGL(attn_split_kernel, grid, dim3(512), 0, st, a);
     } else {
+#ifndef FP_EXPERIMENTS
+      fp_set_error("attention(f16x3): the role-split kernel (variant 2) exists in FP_EXPERIMENTS builds only");
+      return FP_ERR_UNSUPPORTED;
+#else
       static FpDeviceOnce once;
 #ifndef SPP_TIMELINE
       fp_allow_dynamic_lds(once, attn_split_pp_kernel, SPP_LDS);
@@ -1552,6 +1566,7 @@ int attn_launch(const AttnArgs& a_in, int dtype, hipStream_t st) {
 #else
       hipLaunchKernelGGL(attn_split_pp_kernel, grid, dim3(512), SPP_LDS, st, a);
 #endif
+#endif  // FP_EXPERIMENTS
     }
   } else if (dtype == FP_DTYPE_F32) {
     FP_REQUIRE(!a.sel_off, "attention: query selection exists in the bf16 and f16x3 kernels");

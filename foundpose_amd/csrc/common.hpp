@@ -138,7 +138,11 @@ FP_DEVICE int split16_pos(int c) { return ((c >> 5) << 6) + (c & 31); }
 // The e4m3 copies carry 4 significant bits of hi and of lo: a cross term is good to 2^-3 of 2^-11 of the product, so a product
 // carries ~14 mantissa bits at the worst and the sum over K far more on average (measured on fc2, K = 4096: max error 1.3e-5 of the
 // output scale, rms 2.5e-6 -- tools/sp_fp8cross.py) at 8 instead of 12 fp16-MFMA units per 64 k: 1.34x the three-fp16-MFMA form.
-constexpr float FP_SX_HI_SCALE = 0.0078125f, FP_SX_LO_SCALE = 16.f;     // 2^-7 and 2^4: hi (<= 65504) and lo (<= 16) into e4m3's range (<= 448)
+constexpr float FP_SX_HI_SCALE = 0.0078125f, FP_SX_LO_SCALE = 16.f;     // 2^-7 and 2^4: hi and lo (<= 16) into e4m3's range (<= 448)
+// (hi 2^-7 <= 448 holds for |hi| <= 57344 only: between there and the fp16 limit 65504 the e4m3 copy of hi would clamp -- up to 12 % of that cross
+//  term -- while the fp16 row itself is still exact.  Producers of f16f8 rows therefore report saturation from 57344 on: the head room of the mode is
+//  +-3584 for LayerNorm / attention outputs and +-14336 for hidden activations, an eighth less than the split-fp16 rows'.)
+constexpr float FP_SX_MAX = 57344.f;
 constexpr unsigned FP_SX_MFMA_SCALE = 0x82828282u;                       // E8M0 127 + 3 in every byte: the block scale 2^3 that undoes 2^-7 x 2^4
 FP_DEVICE int splitx_pos(int c) { return ((c >> 6) << 7) + (c & 63); }   // halves index of hi(column c), the row viewed as halves
 FP_DEVICE int splitx_hi8(int c) { return ((c >> 6) << 8) + 128 + (c & 63); }  // byte offset of e4m3(hi) of column c; its e4m3(lo) sits 64 bytes further

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
       }
       if (!TWO_SLABS && tm + 1 < TM) __syncthreads();
     }
-    if constexpr (SPOUT) report_saturation(a.sat, 0, sat_amax, FP_F16_MAX);
+    if constexpr (SPOUT) report_saturation(a.sat, 0, sat_amax, (SX && EPI != GEMM_EPI_BIAS_BF16) ? FP_SX_MAX : FP_F16_MAX);   // (f16f8 output rows: the e4m3 copy's range, common.hpp)
     if constexpr (F8OUT) report_saturation(a.sat, 1, sat_amax, FP_E4M3_MAX);
     } else {
     float4 bias[TN][4], gam[TN][4];
@@ -779,15 +779,19 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
 }
 
 // The super-tile raster of a launch (0 x 0: none -- row-major tile ids in one contiguous chunk per XCD).
-// FP_GEMM_RAST: 0 = off, 1 = the default below, "RxG" = another super-tile of R m-tiles x G n-tiles (R * G = 32; measurements:
+// FP_GEMM_RAST (FP_EXPERIMENTS builds only): 0 = off, 1 = the default below, "RxG" = another super-tile of R m-tiles x G n-tiles (R * G = 32; measurements:
 // profiles/EXPERIMENTS.md "super-tile shapes" -- 4x8 / 2x16 / 16x2 all lose to 8x4: only a 4-n-tile W panel (2 MiB) survives in a 4-MiB L2
 // next to the streaming A slab, and the A re-fetch per n-group that remains is what a wider group would remove).
 // Default: 4 x 8 when the output is a multiple of 8 n-tiles wide (fc1: 16), else 8 x 4 (qkv: 12) -- same-box pipeline A/B, three
 // alternations: 1043.0 detections/s against 1038.2 with 8 x 4 everywhere (profiles/EXPERIMENTS.md)
 struct GemmRaster { int r, gn; };
 static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
+#ifdef FP_EXPERIMENTS   // (measurement builds: the super-tile shape of the sweep, read once)
   static const int env_rast = getenv("FP_GEMM_RAST") ? atoi(getenv("FP_GEMM_RAST")) : 1;
   static const int env_gn = (getenv("FP_GEMM_RAST") && strchr(getenv("FP_GEMM_RAST"), 'x')) ? atoi(strchr(getenv("FP_GEMM_RAST"), 'x') + 1) : 0;
+#else
+  constexpr int env_rast = 1, env_gn = 0;
+#endif
   const int wide8 = n_tiles % 8 == 0;
   const int rr = env_gn ? env_rast : (wide8 ? 4 : 8), gn = env_gn ? env_gn : (wide8 ? 8 : 4);
   if (env_rast && rr * gn == 32 && bm >= 256 && n_tiles % gn == 0 && n_tiles > 4 && grid >= 512) return {rr, gn};
@@ -829,7 +833,7 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
 // "320 x 256 block tiles") shows steps exactly at these counts: qkv at the bench batch, 256^2: 22 x 3 = 66 super-tiles = 9 rounds of 31 us;
 // 320 x 256: 18 x 3 = 54 = 7 rounds of 37.5 us.  A round of the taller tile takes 1.21x (not 1.25x) the time: cost = rounds x height x 0.97.
 // The estimate picks the faster tile in 32 of the 36 cases of the recorded sweep (profiles/r4_gemm_tile_sweep.txt; three misses within 1 %, one
-// of 3 %) and 256 rows for the residual GEMMs of the bench batch (3 rounds either way).  FP_GEMM_TILE320=0 is the A/B switch.
+// of 3 %) and 256 rows for the residual GEMMs of the bench batch (3 rounds either way).  GemmBf16Args.no_tall (fp_vit_model.flags & FP_VIT_NO_TALL_TILES) is the A/B switch.
 static int xcd_rounds(int bm, int m_valid, int n_tiles) {
   const int m_tiles = (m_valid + bm - 1) / bm, xcds = 8, per_xcd = fp_num_cus() / xcds > 0 ? fp_num_cus() / xcds : 32;
   const GemmRaster ra = pick_raster(bm, n_tiles, (unsigned)(m_tiles * n_tiles));
@@ -838,8 +842,7 @@ static int xcd_rounds(int bm, int m_valid, int n_tiles) {
   return (chunk + per_xcd - 1) / per_xcd;
 }
 static bool tall_tile_wins(const GemmBf16Args& a) {
-  static const bool off = getenv("FP_GEMM_TILE320") && atoi(getenv("FP_GEMM_TILE320")) == 0;
-  if (off || a.M % 320 != 0 || a.M % 256 != 0 || a.N % 256 != 0) return false;
+  if (a.no_tall || a.M % 320 != 0 || a.M % 256 != 0 || a.N % 256 != 0) return false;
   return (float)(xcd_rounds(320, a.M_valid, a.N / 256) * 320) * 0.97f < (float)(xcd_rounds(256, a.M_valid, a.N / 256) * 256);
 }
 

@@ -131,6 +131,7 @@ struct GemmBf16Args {
   const float* pos;           // [Np, ldo] fp32 pos-embed rows of the patch tokens
   int tok_np, tok_n, tok_skip;  // patches / tokens per image, first patch token index (1 + registers)
   int tile_override;          // 0 = auto, 64 (x 128) / 128 / 256 / 320 = force that block tile (benchmarks, tests)
+  int no_tall;                // 1 = the automatic choice never takes the 320-row tile (fp_vit_model.flags & FP_VIT_NO_TALL_TILES: the A/B switch of a whole forward)
   int m_tiles;                // set by the launcher: row tiles that hold live rows (tiles of padding rows only are not launched)
   unsigned rast_r, rast_gn;
   float out_scale;            // fp8 kernels: > 0 -> the GELU / SwiGLU result leaves as e4m3(value * out_scale) bytes; f16x3: scale of a split-fp16 output

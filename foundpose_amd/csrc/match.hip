@@ -1361,7 +1361,11 @@ int launch_cosine_topk(const CosineArgs& a_in, int num_det, int num_obj, int max
     else hipLaunchKernelGGL(cosine_fused_kernel<2>, grid, dim3(512), lds, st, a);
     FP_CHECK_LAUNCH("cosine_fused");
     if (want_cand) {
-      static const bool two_launches = getenv("FP_COSINE_MERGE_REPLAY") && atoi(getenv("FP_COSINE_MERGE_REPLAY")) == 0;  // A/B switch
+#ifdef FP_EXPERIMENTS
+      static const bool two_launches = getenv("FP_COSINE_MERGE_REPLAY") && atoi(getenv("FP_COSINE_MERGE_REPLAY")) == 0;  // A/B switch of measurement builds
+#else
+      constexpr bool two_launches = false;
+#endif
       if (tie_mode == 1 && !two_launches && n_top <= 32) {  // merge + the replay of tied rows in one launch (torch order)
         hipLaunchKernelGGL(cand_merge_replay_kernel, dim3(num_det), dim3(256), 0, st, a.cand, gx * n_emit, num_det, n_top, out_scores, out_ids,
                            a.need_replay, a.sims, a.ld_sims, det_num_templates, max_templates);

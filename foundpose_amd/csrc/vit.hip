@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
         }
       }
   }
-  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8) report_saturation(a.sat, 0, amax, FP_F16_MAX);
+  if (a.out_dtype == FP_DTYPE_F16X3 || a.out_dtype == FP_DTYPE_F16F8) report_saturation(a.sat, 0, amax, a.out_dtype == FP_DTYPE_F16F8 ? FP_SX_MAX : FP_F16_MAX);
   else if (a.out_dtype == FP_DTYPE_F32) report_saturation(a.sat, 0, amax, 3.0e38f);
   else if (a.out_dtype == FP_DTYPE_FP8) report_saturation(a.sat, 1, amax, FP_E4M3_MAX);
 }

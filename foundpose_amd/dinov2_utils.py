@@ -61,11 +61,16 @@ def _interpolate_pos_embed_strided(pos_embed: torch.Tensor, patch: int, stride: 
 class DinoFeatureExtractor(torch.nn.Module):
     def __init__(self, model_name: str, state_dict: Optional[Dict[str, torch.Tensor]] = None, weights: Optional[str] = None,
                  random_init_seed: Optional[int] = None, precision: str = "bf16", arch: Optional[VitArch] = None, use_graph: bool = False,
-                 act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True, head_blocks: int = 0, head_precision: str = "f16") -> None:
+                 act_scales: Optional[torch.Tensor] = None, fold_layernorm: bool = True, head_blocks: int = 0, head_precision: str = "f16",
+                 resid_hilo: bool = True, ld_pad: int = 64, ld_pad_qkv: int = 0, ld_pad8: int = 0, tall_tiles: bool = True, sat_check: bool = True) -> None:
         """Weights (the reference: hub model with pretrained=True, dinov2_utils.py:81-84): `state_dict=` (upstream key names), `weights=` (checkpoint
         file, or directory holding the upstream file name), else $FOUNDPOSE_DINOV2_WEIGHTS, else the torch hub cache the reference's own call fills;
         none of them -> FoundPoseWeightsError.  Random weights only on an explicit `random_init_seed=` (tests, benchmarks).  Every dict is checked
-        like load_state_dict(strict=True) (weights.validate_state_dict)."""
+        like load_state_dict(strict=True) (weights.validate_state_dict).
+        Tuning arguments (A/B switches of measurements; none changes what is computed beyond rounding points, the defaults are what the benchmarks run):
+        fold_layernorm (bf16: the block LayerNorms folded into the GEMMs), resid_hilo (the residual stream in front of the hooked block as a (hi, lo) 16-bit
+        pair), ld_pad / ld_pad_qkv / ld_pad8 (row-stride padding of the operands, elements / bytes), tall_tiles (320-row GEMM tiles), sat_check (forward()
+        raises on a saturation report: one host sync per call).  No environment variable is read."""
         super().__init__()
         self.use_graph = use_graph  # replay the forward's launch sequence as one hipGraph (static buffers per batch shape)
         if arch is not None:  # non-hub architecture (unit tests use a tiny one)
@@ -120,7 +125,10 @@ class DinoFeatureExtractor(torch.nn.Module):
         # bf16 mode: the two LayerNorms of every block folded into the GEMMs around them (fp_vit_model.ln_fold): gain into the
         # qkv / fc1 matrices, shift into their biases, LayerScale into the proj / fc2 matrices -- no LayerNorm kernel runs
         # inside the blocks (they were 6.5 % of a step).  fold_layernorm=False keeps the kernel-per-LayerNorm sequence.
-        self.fold_layernorm = (bool(fold_layernorm) and precision == "bf16" and os.environ.get("FP_LN_FOLD", "1") != "0") or precision == "f16"  # FP_LN_FOLD=0: A/B switch (bf16)
+        self.fold_layernorm = (bool(fold_layernorm) and precision == "bf16") or precision == "f16"
+        self.resid_hilo = bool(resid_hilo) or precision == "f16"
+        self.tall_tiles, self.sat_check = bool(tall_tiles), bool(sat_check)
+        self._ld_pad_arg, self._ld_pad_qkv_arg, self._ld_pad8_arg = int(ld_pad), int(ld_pad_qkv), int(ld_pad8)
         self._sd, self.weights_source = _weights.resolve(self.model_base_name, self.arch, state_dict, weights, random_init_seed)
         # Precision schedule: blocks 0 .. head_blocks-1 run in `head_precision`, blocks head_blocks .. layer in this extractor's own precision, over one
         # fp32 stream (fp_vit_stream_f32 / fp_vit_forward_blocks): the fast "f16" pipeline in front of a near-exact tail, or the other way round.
@@ -170,15 +178,15 @@ class DinoFeatureExtractor(torch.nn.Module):
 
         # Row strides of the block matrices and of the y / h activation buffers are padded by `pad` elements so that a
         # stride is never a multiple of 2 KiB: the 8 rows one staging instruction of the GEMM fetches then spread over
-        # the L2 channels instead of queueing on one (FP_LD_PAD overrides; 0 = dense; fp8 mode stays dense).
-        pad = int(os.environ.get("FP_LD_PAD", "64")) if self.precision != "fp8" else 0
-        self._ld_pad8 = int(os.environ.get("FP_LD_PAD8", "0")) if self.precision == "fp8" else 0  # bytes, fp8 operands (measured: no effect at 128, 1425 detections/s either way)
+        # the L2 channels instead of queueing on one (ld_pad; 0 = dense; fp8 mode stays dense).
+        pad = self._ld_pad_arg if self.precision != "fp8" else 0
+        self._ld_pad8 = self._ld_pad8_arg if self.precision == "fp8" else 0  # bytes, fp8 operands (measured: no effect at 128, 1425 detections/s either way)
         if pad % 8:
-            raise ValueError("FP_LD_PAD must be a multiple of 8")
+            raise ValueError("ld_pad must be a multiple of 8")
         self._ld_pad = pad
-        # the qkv buffer's stride can be padded too (FP_LD_PAD_QKV): in isolation the attention kernel and the qkv GEMM gain
+        # the qkv buffer's stride can be padded too (ld_pad_qkv): in isolation the attention kernel and the qkv GEMM gain
         # 5-9 % from +64..128 elements, inside the pipeline nothing (998 detections/s at 0 / 64 / 128 / 256) -> dense
-        self._ld_pad_qkv = int(os.environ.get("FP_LD_PAD_QKV", "0"))
+        self._ld_pad_qkv = self._ld_pad_qkv_arg
 
         def padded(t2d):  # [N, K] -> view of an [N, K + pad] buffer
             if pad == 0:
@@ -274,6 +282,7 @@ class DinoFeatureExtractor(torch.nn.Module):
         m.blocks = C.cast(blocks, C.POINTER(_lib.VitBlock))
         m.ld_w_dim, m.ld_w_hidden = (a.dim + pad, a.hidden + pad) if pad else (0, 0)  # fp8: set by _to_fp8
         m.ln_fold = int(fold)
+        m.flags = 0 if self.tall_tiles else _lib.VIT_NO_TALL_TILES
         self._w, self._model, self._blocks, self._device = w, m, blocks, dev
         self._grids.clear()
         self._ws.clear()
@@ -287,9 +296,9 @@ class DinoFeatureExtractor(torch.nn.Module):
         from . import ops
         a, sd = self.arch, self._sd
         w: Dict[str, torch.Tensor] = {}
-        pad = int(os.environ.get("FP_LD_PAD", "64"))
+        pad = self._ld_pad_arg
         if pad % 8:
-            raise ValueError("FP_LD_PAD must be a multiple of 8")
+            raise ValueError("ld_pad must be a multiple of 8")
         self._ld_pad, self._ld_pad8, self._ld_pad_qkv = pad, 0, 0
 
         def f32(key):
@@ -433,7 +442,7 @@ class DinoFeatureExtractor(torch.nn.Module):
                 bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev))
                 bufs.append(torch.zeros(a.dim // 128 + 1, m_pad, 2, dtype=torch.float32, device=dev))
                 ws.xb, ws.stats = ptr(bufs[-2]), ptr(bufs[-1])
-                if os.environ.get("FP_RESID_HILO", "1") != "0" or self.precision == "f16":   # low halves of the (hi, lo) residual stream of the blocks in front of the hooked one (A/B switch)
+                if self.resid_hilo:   # low halves of the (hi, lo) residual stream of the blocks in front of the hooked one (A/B switch)
                     bufs.append(torch.zeros(m_pad, a.dim + self._ld_pad, dtype=adt, device=dev))
                     ws.xl = ptr(bufs[-1])
             ws.patches, ws.x, ws.y, ws.qkv, ws.h = (ptr(t) for t in bufs[:5])
@@ -713,7 +722,7 @@ class DinoFeatureExtractor(torch.nn.Module):
     def forward(self, images: torch.Tensor) -> Dict[str, torch.Tensor]:
         B, _, H, W = images.shape
         fmap, cls = self.forward_tokens(images)
-        if self.precision in ("f16", "f16x3", "f16f8", "fp8") and os.environ.get("FP_SAT_CHECK", "1") != "0":
+        if self.precision in ("f16", "f16x3", "f16f8", "fp8") and self.sat_check:
             self.check_saturation()   # one host sync; the reference's forward is synchronous too (CPU tensors)
         if self.precision == "f16" and (not self.apply_norm or self.facet != "token") and not bool(torch.isfinite(fmap).all()):
             # (no final-norm kernel ran on this output: raw hidden states or a q / k / v facet -- the same verdict, checked here)

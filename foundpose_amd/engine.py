@@ -20,8 +20,11 @@ from .matching import MatchResult, match_batch
 
 class FoundPoseEngine:
     def __init__(self, extractor: DinoFeatureExtractor, bank: DeviceBank, grid_cell_size: float = 14.0,
-                 top_n_templates: int = 5, top_k_buddies: int = 300, tie_order: str = "canonical", overlap_matching: bool = False) -> None:
-        """overlap_matching: the matching stage of a batch (projection, retrieval, cyclic buddies: ~1 ms of small, latency-bound
+                 top_n_templates: int = 5, top_k_buddies: int = 300, tie_order: str = "canonical", overlap_matching: bool = False,
+                 select_tokens: bool = True, fused_sample: bool = True, prefilter: bool = True) -> None:
+        """select_tokens / fused_sample / prefilter: A/B switches of measurements and of the bit-identity tests (the hooked block on the sampled tokens only;
+        final norm + sampling in one kernel; the two-stage template retrieval where it applies) -- same outputs bit for bit, attributes of the engine.
+        overlap_matching: the matching stage of a batch (projection, retrieval, cyclic buddies: ~1 ms of small, latency-bound
         launches) is enqueued on a second stream behind an event, so the next infer_batch's backbone -- enqueued on the
         caller's stream -- runs beside it: the small launches fill the CUs the big GEMMs leave idle in their tail rounds.
         infer_batch then returns a MatchResult whose tensors are complete when `result.ready` has fired: call
@@ -29,6 +32,7 @@ class FoundPoseEngine:
         overlapped under `with torch.cuda.stream(engine.side_stream)`."""
         self.extractor, self.bank = extractor, bank
         self.overlap_matching = overlap_matching
+        self.select_tokens, self.fused_sample, self.prefilter = bool(select_tokens), bool(fused_sample), bool(prefilter)
         self._side = None
         self.cell = grid_cell_size
         self.top_n, self.top_k = top_n_templates, top_k_buddies
@@ -146,11 +150,11 @@ class FoundPoseEngine:
                     keep_debug: bool = False) -> MatchResult:
         B, _, H, W = images.shape
         det_obj = [0] * B if det_obj is None else list(det_obj)
-        fused = self.extractor.facet == "token" and not self.extractor.use_graph and os.environ.get("FP_FUSED_SAMPLE", "1") != "0"  # env: A/B switch
+        fused = self.extractor.facet == "token" and not self.extractor.use_graph and self.fused_sample
         # The reference samples the hooked block's feature map at the query points and nowhere else (infer.py:452-466), so
         # that block only has to produce the patch tokens under the sampling taps: its attention queries, proj and MLP run on
-        # those tokens (keys / values: all tokens).  Same sampled features bit for bit; FP_TOKEN_SELECT=0 is the A/B switch.
-        select = fused and self.extractor.supports_token_selection and os.environ.get("FP_TOKEN_SELECT", "1") != "0"
+        # those tokens (keys / values: all tokens).  Same sampled features bit for bit; engine.select_tokens = False is the A/B switch.
+        select = fused and self.extractor.supports_token_selection and self.select_tokens
         self._stage_events = []
         self._mark("start")
         # f16x3 / fp8: clamped activations are reported per BATCH -- the sticky device counters are snapshotted before and after the backbone
@@ -188,7 +192,7 @@ class FoundPoseEngine:
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")
             res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order,
-                              mark=self._submark if self.record_stage_times else None)
+                              mark=self._submark if self.record_stage_times else None, prefilter=self.prefilter)
             self._mark("corresp")
             if track_sat:
                 res.extractor, res.sat_delta = self.extractor, sat_delta   # corresp_list() reads the verdict of this batch
@@ -203,7 +207,7 @@ class FoundPoseEngine:
             feats = self._project(raw, counts, det_obj)
             self._mark("proj")
             res = match_batch(self.bank, feats, q_pts, counts, det_obj, self.top_n, self.top_k, keep_debug, self.tie_order,
-                              mark=self._submark if self.record_stage_times else None)
+                              mark=self._submark if self.record_stage_times else None, prefilter=self.prefilter)
             self._mark("corresp")
             res.ready = torch.cuda.Event()
             res.ready.record(side)

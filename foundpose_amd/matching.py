@@ -103,6 +103,7 @@ def match_batch(
     keep_debug: bool = False,
     tie_order: str = "canonical",  # "canonical": (value, lowest index);  "torch": the reference's torch.topk CPU tie order
     word_metric: Optional[str] = None,  # metric of the visual-word search; default: each object's template_desc_opts.tfidf_knn_metric
+    prefilter: bool = True,  # the two-stage template retrieval where it applies (same outputs bit for bit; False: always the single-pass exact kernel)
     mark=None,  # optional callable(name): called with "retrieval_begin" / "retrieval_end" around the template retrieval (the engine records HIP events there)
 ) -> MatchResult:
     require_cuda(query_features, query_points)
@@ -145,12 +146,9 @@ def match_batch(
     # (pinned staging + asynchronous copy: a pageable upload blocks the host until the stream has drained -- the whole backbone of this batch --
     #  and the launches behind it would then reach an idle GPU one launch latency at a time; the caching host allocator keeps the pinned
     #  block alive until the copy has run)
-    if os.environ.get("FP_TABS_BLOCKING") == "1":   # A/B switch: the pageable, blocking upload
-        tabs = torch.tensor(tabs_h, dtype=torch.int32, device=dev)
-    else:
-        tabs_host = torch.empty(len(tabs_h), dtype=torch.int32, pin_memory=True)
-        tabs_host.copy_(torch.tensor(tabs_h, dtype=torch.int32))
-        tabs = tabs_host.to(dev, non_blocking=True)
+    tabs_host = torch.empty(len(tabs_h), dtype=torch.int32, pin_memory=True)
+    tabs_host.copy_(torch.tensor(tabs_h, dtype=torch.int32))
+    tabs = tabs_host.to(dev, non_blocking=True)
     o1 = B + 1
     o2 = o1 + bank.num_objects + 1
     q_off, det_seg, det_nt, tpl_base, feat_base = tabs[:o1], tabs[o1:o2], tabs[o2:o2 + B], tabs[o2 + B:o2 + 2 * B], tabs[o2 + 2 * B:o2 + 3 * B]
@@ -192,7 +190,7 @@ def match_batch(
     t_ids = torch.empty(B, n, dtype=torch.int32, device=dev)
     if mark is not None:
         mark("retrieval_begin")
-    if bank.prefilter_applies(max_det, tie_mode) and os.environ.get("FP_COSINE_PREFILTER", "1") != "0":  # env: A/B switch (same outputs bit for bit)
+    if prefilter and bank.prefilter_applies(max_det, tie_mode):
         sims = torch.empty(cosine_prefilter_scratch_floats(B, bank.max_templates), dtype=torch.float32, device=dev)
         call("fp_cosine_topk_prefiltered", ptr(desc_n), ptr(det_seg), ptr(det_nt), B, max_det, ptr(bank.descs_n), ptr(bank.descs_f16()),
              ptr(bank.obj_tpl_off), bank.num_objects, bank.max_templates, W, n, ptr(sims), ptr(t_scores), ptr(t_ids), tie_mode, stream())

@@ -64,8 +64,13 @@ enum { FP_F32 = 0, FP_BF16 = 1, FP_FP8 = 2, FP_F16X3 = 3, FP_F16F8 = 4, FP_F16 =
  * absolute error <= 3e-8 (fp16 subnormals, which the MFMA honours). */
 #define FP_GEMM_F16 (1 << 21) /* OR-ed into fp_gemm_bf16's / fp_gemm_bf16_ln's `epilogue`: A, W, the 16-bit outputs and the (xb, xl) stream are IEEE fp16 */
 
-#define FP_ABI_VERSION 17
+#define FP_ABI_VERSION 18
 int fp_abi_version(void);
+/* 1 if the library was compiled with -DFP_EXPERIMENTS (FP_EXPERIMENTS=1 python -m foundpose_amd.build): the measured-slower kernels kept for A/B runs -- the
+ * role-split split-fp16 attention (fp_attention_split variant 2), the bf16 attention work splits 2 / 3 / 4, the two-stage k-NN of csrc/knn_cand.hip -- and
+ * their environment switches (FP_KNN_CAND, FP_GEMM_RAST, FP_COSINE_MERGE_REPLAY) exist in such builds only.  The shipped library (0) reads NO environment
+ * variable and keeps no mutable state beyond its idempotent per-device launch caches. */
+int fp_build_experiments(void);
 const char* fp_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------
@@ -260,7 +265,9 @@ typedef struct {
                               diag(LayerScale) W and proj_b / fc2_b hold LayerScale * b (ls1 / ls2 are then unused); the
                               residual GEMMs (proj, fc2) also emit bf16(x) and per-row (sum x, sum x^2), and the qkv / fc1
                               epilogues compute rstd * (acc - mean * colsum) + bias.  Needs workspace xb / stats. */
+  int flags;               /* tuning bits of a whole forward (results are bit-identical either way): FP_VIT_NO_TALL_TILES */
 } fp_vit_model;
+#define FP_VIT_NO_TALL_TILES 1 /* the wide bf16 / f16 GEMMs never take their 320-row block tile (A/B switch; the tiles walk k in the same order) */
 
 typedef struct {
   void* patches; /* [m_patch_pad, patch_k_pad] activation dtype */

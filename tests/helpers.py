@@ -93,3 +93,13 @@ def assert_features_close(key, got, ref, scale, tol, lossy):
     else:
         assert err <= tol, f"{key}: {err:.3e} > {tol:.1e} of the feature scale"
     return err
+
+
+def experiments_build() -> bool:
+    """True when the library under test was compiled with -DFP_EXPERIMENTS (FP_EXPERIMENTS=1 python -m foundpose_amd.build --force): the measured-slower kernels
+    kept for A/B runs (role-split split-fp16 attention, bf16 attention work splits 2 / 3, the two-stage k-NN) exist in such builds only."""
+    try:
+        from foundpose_amd import _lib
+        return bool(_lib.lib().fp_build_experiments())
+    except Exception:
+        return False

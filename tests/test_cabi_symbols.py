@@ -18,7 +18,7 @@ def test_library_exports_every_declared_symbol():
     for name in sorted(declared):
         assert hasattr(handle, name), f"{name} declared in the header but not exported"
     assert declared == set(_lib.exported_symbols()), "ctypes prototypes out of sync with the header"
-    assert handle.fp_abi_version() == _lib.ABI_VERSION == 17
+    assert handle.fp_abi_version() == _lib.ABI_VERSION == 18
 
 
 def test_product_never_imports_oracle():
@@ -87,3 +87,23 @@ def test_graft_entry_build_runs():
     """The driver's "does it build" hook: compiles what is stale (nothing, normally), loads the library, checks the ABI."""
     import __graft_entry__ as entry
     entry.build()
+
+
+def test_shipped_library_reads_no_environment_variable():
+    """the library keeps no global mutable state and has no hidden switches.  The shipped build does not even IMPORT getenv (the A/B
+    switches of measurements are explicit arguments -- fp_vit_model.flags, the variant bits of fp_attention* -- or live in FP_EXPERIMENTS builds,
+    fp_build_experiments() == 1), and the Python host mirror reads no FP_* variable either (extractor / engine constructor arguments instead)."""
+    import subprocess
+    import torch  # noqa: F401
+    from foundpose_amd import _lib
+    handle = _lib.lib()
+    if handle.fp_build_experiments():
+        pytest.skip("an FP_EXPERIMENTS build is under test")
+    syms = subprocess.run(["nm", "-D", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "getenv" not in syms and "knn_cand" not in syms
+    pkg = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "foundpose_amd")
+    for fn in sorted(os.listdir(pkg)):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            for m in re.findall(r"environ(?:\.get)?\W+[\"'](FP_[A-Z0-9_]+)[\"']", src):
+                assert fn == "build.py", f"{fn} reads ${m}"    # (the build tool's FP_EXPERIMENTS selects what is compiled; the library never sees it)

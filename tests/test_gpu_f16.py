@@ -233,15 +233,8 @@ def test_extractor_f16_batch_invariance_token_selection_and_swiglu():
     assert ex.supports_token_selection
     wl = workload.build_planted_workload(ex, 4, 224, 1, 60, seed=3, crop_seed=2)
     bank = DeviceBank(wl.repres)
-    import os
-    outs = []
-    for sel in ("1", "0"):
-        os.environ["FP_TOKEN_SELECT"] = sel
-        try:
-            res = fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj, keep_debug=True)
-        finally:
-            os.environ.pop("FP_TOKEN_SELECT", None)
-        outs.append(res)
+    outs = [fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch", select_tokens=sel).infer_batch(wl.crops, wl.masks, wl.det_obj, keep_debug=True)
+            for sel in (True, False)]
     for f in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d", "query_tfidf"):
         x, y = getattr(outs[0], f), getattr(outs[1], f)
         assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), f
@@ -352,14 +345,7 @@ def test_precision_schedule_runs_two_models_over_one_stream(head, tail):
     assert got < 1.5 * max(e.values()) + 1e-5, (got, e)
     wl = workload.build_planted_workload(mk("fp32"), 3, 224, 1, 60, seed=3, crop_seed=2)
     bank = DeviceBank(wl.repres)
-    import os
-    outs = []
-    for sel in ("1", "0"):
-        os.environ["FP_TOKEN_SELECT"] = sel
-        try:
-            outs.append(fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch").infer_batch(wl.crops, wl.masks, wl.det_obj))
-        finally:
-            os.environ.pop("FP_TOKEN_SELECT", None)
+    outs = [fe.FoundPoseEngine(ex, bank, 14.0, 5, 300, tie_order="torch", select_tokens=sel).infer_batch(wl.crops, wl.masks, wl.det_obj) for sel in (True, False)]
     for f in ("template_ids", "counts", "q_ids", "feat_ids", "dists", "coord_3d"):
         x, y = getattr(outs[0], f), getattr(outs[1], f)
         assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), f

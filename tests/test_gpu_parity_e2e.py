@@ -256,8 +256,8 @@ def test_default_backbone_dinov2_vitl14_vs_oracle_a():
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16x3", "f16f8"])
-def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
-    """The engine's default path computes the hooked block for the sampled tokens only; with FP_TOKEN_SELECT=0 it runs the
+def test_token_selection_changes_nothing_end_to_end(precision):
+    """The engine's default path computes the hooked block for the sampled tokens only; with engine.select_tokens = False it runs the
     block on every token.  Same templates, scores, correspondences, distances -- tensor for tensor -- at the benchmark
     geometry (ViT-L/14-reg layer 18, 518 px) with masks of different sizes in one batch (one of them empty: an image
     without a selected token), in the bf16 mode and in the f16x3 mode."""
@@ -273,10 +273,9 @@ def test_token_selection_changes_nothing_end_to_end(monkeypatch, precision):
     masks[5] = 0                    # no query point at all: the detection selects no token
     exbf = feature_util.make_feature_extractor(NAME, random_init_seed=1234, precision=precision).to("cuda")
     eng = fe.FoundPoseEngine(exbf, bank, 14.0, 5, 300, tie_order="torch")
-    assert exbf.supports_token_selection
-    monkeypatch.setenv("FP_TOKEN_SELECT", "1")
+    assert exbf.supports_token_selection and eng.select_tokens
     a = eng.infer_batch(wl.crops, masks, wl.det_obj)
-    monkeypatch.setenv("FP_TOKEN_SELECT", "0")
+    eng.select_tokens = False
     b = eng.infer_batch(wl.crops, masks, wl.det_obj)
     for name in ("template_ids", "template_scores", "counts", "q_ids", "feat_ids", "dists", "conf", "coord_2d", "coord_3d"):
         x, y = getattr(a, name), getattr(b, name)

@@ -11,6 +11,7 @@ import torch
 from foundpose_amd import _lib, ops, synthetic
 from foundpose_amd.vit_config import ARCHS, VitArch
 from oracle import vit as ov
+from tests.helpers import experiments_build
 
 pytestmark = pytest.mark.gpu
 
@@ -144,6 +145,7 @@ def test_attention_split_vs_fp64(B, N, heads):
 
 @pytest.mark.parametrize("B,N,heads", [(2, 77, 2), (1, 1374, 4), (3, 905, 2), (1, 256, 1), (2, 257, 3), (1, 64, 16), (1, 33, 1), (2, 129, 8), (1, 2305, 2)])
 @pytest.mark.parametrize("f16f8_out", [False, True])
+@pytest.mark.skipif(not experiments_build(), reason="attn_split_pp_kernel (measured ~3 % slower) is compiled into FP_EXPERIMENTS builds only")
 def test_attention_split_role_split_kernel_equals_lock_step_kernel(B, N, heads, f16f8_out):
     """attn_split_pp_kernel (variant 2: the two waves of a SIMD half a key tile apart, three-slot K / V ring) issues the same MFMAs in the
     same order per accumulator and the same softmax as attn_split_kernel (variant 1): every output bit equal -- one tile, ragged last tiles
@@ -158,43 +160,6 @@ def test_attention_split_role_split_kernel_equals_lock_step_kernel(B, N, heads, 
     assert torch.equal(a.view(torch.int16), b.view(torch.int16))
     for _ in range(3):   # the role-split schedule has more ways to race than the lock-step one: the same bits on every launch
         assert torch.equal(ops.attention_split(packed, B, N, D, heads, 64.0, 128.0, f16f8_out=f16f8_out, variant=2).view(torch.int16), a.view(torch.int16))
-
-
-_PP_FEATURES = """
-import hashlib, sys, torch
-sys.path.insert(0, {root!r})
-from foundpose_amd import feature_util, synthetic
-ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=3_norm=1", random_init_seed=8, precision={prec!r}).to("cuda")
-fm = ex(synthetic.make_crops(3, 224, seed=5).cuda())["feature_maps"]
-print("SHA", hashlib.sha256(fm.float().cpu().numpy().tobytes()).hexdigest())
-"""
-
-
-@pytest.mark.parametrize("prec", ["f16x3", "f16f8"])
-def test_role_split_attention_drives_the_pipeline_bit_identically(prec):
-    """FP_ATTN_SPLIT_PP=1 (read once per process) makes attn_split_pp_kernel the attention of the f16x3 / f16f8 pipelines: the feature maps of a
-    whole extractor forward carry the same bits as with the lock-step kernel (this process), and -- in the same child environment -- the hooked
-    block on the selected tokens only (the kernel's sel_rows / sel_off path, which no direct call reaches) still equals the full forward."""
-    import hashlib
-    import os
-    import subprocess
-    import sys
-    if os.environ.get("FP_ATTN_SPLIT_PP"):
-        pytest.skip("already inside a role-split environment")
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    from foundpose_amd import feature_util
-    ex = feature_util.make_feature_extractor("dinov2_version=vits14-reg_stride=14_facet=token_layer=3_norm=1", random_init_seed=8, precision=prec).to("cuda")
-    fm = ex(synthetic.make_crops(3, 224, seed=5).cuda())["feature_maps"]
-    want = hashlib.sha256(fm.float().cpu().numpy().tobytes()).hexdigest()
-    env = dict(os.environ, FP_ATTN_SPLIT_PP="1")
-    out = subprocess.run([sys.executable, "-c", _PP_FEATURES.format(root=root, prec=prec)], env=env, capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-2000:]
-    got = [ln.split()[1] for ln in out.stdout.splitlines() if ln.startswith("SHA")]
-    assert got == [want], (got, want)
-    if prec == "f16x3":
-        sel = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_vit.py"), "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                              "-k", "selected_tokens_in_hooked_block_bit_identical and f16x3"], env=env, capture_output=True, text=True, timeout=900, cwd=root)
-        assert sel.returncode == 0 and " passed" in sel.stdout, sel.stdout[-2000:] + sel.stderr[-1000:]
 
 
 def test_attention_split_forced_rescale_and_constant_rows():
