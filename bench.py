@@ -92,6 +92,42 @@ def self_launch(n):
     return subprocess.call(cmd, env=env)
 
 
+def gemm_probe_ms(precision, M, mv, n, k, epi, fold, hilo, dev, iters=20):
+    """Average launch duration (ms, HIP events) of one block GEMM of the ViT at M padded / mv live rows in `precision`'s own kernel: epi 0 = qkv (bias), 1 = fc1
+    (GELU), 6 = fc1 (SwiGLU), 3 = the residual GEMMs proj / fc2 -- with folded LayerNorms (fold) the launch the pipeline issues: epilogue 8 on the (hi, lo) stream
+    (hilo) or 7, and the normalising epilogues of qkv / fc1."""
+    from foundpose_amd import ops
+    from foundpose_amd._lib import call as _call, ptr as _ptr, stream as _stream
+    dt16 = torch.float16 if precision == "f16" else torch.bfloat16
+    f16_bit = (1 << 21) if precision == "f16" else 0   # FP_GEMM_F16
+    a = torch.randn(M, k, device=dev).to(dt16)
+    w = (torch.randn(n, k, device=dev) * 0.02).to(dt16)
+    bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
+    out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else dt16, device=dev)
+    if precision in ("f16x3", "f16f8"):   # split operands: the algorithmic FLOPs are those of the fp32 product
+        pack = ops.splitx_pack if precision == "f16f8" else ops.split16_pack
+        a3, w3 = pack(a.float(), 128.0, 64), pack(w.float(), ops.pow2_scale(w.float()), 64)
+        o3 = torch.zeros(M, n, dtype=torch.float32, device=dev) if epi == 3 else torch.zeros(M, n if epi == 6 else 2 * n, dtype=torch.float16, device=dev)
+        return time_kernel(lambda: ops.gemm_split(a3, w3, bias, 1e-6, gamma=gamma, out=o3, epilogue=epi, out_scale=64.0, m_valid=mv, f16f8=precision == "f16f8"), iters)
+    if precision == "fp8":
+        a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
+        col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
+        return time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=out, epilogue=epi, m_valid=mv), iters)
+    if fold and epi == 3:   # the kernel the pipeline launches 36 times per step: the residual update on the (hi, lo) 16-bit stream + LayerNorm row
+        xb = torch.zeros(M, n, dtype=dt16, device=dev)   # sums (epilogue 8; resid_hilo=False: fp32 stream + bf16 copy, epilogue 7)
+        st = torch.zeros(n // 128, M, 2, device=dev)
+        if hilo:
+            xl = torch.zeros(M, n, dtype=dt16, device=dev)
+            return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(xl), n, 8 | f16_bit,
+                                             None, None, _ptr(xb), n, _ptr(st), _stream()), iters)
+        return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(out), n, 7 | f16_bit,
+                                         None, None, _ptr(xb), n, _ptr(st), _stream()), iters)
+    if fold:                # ... and the normalising epilogues of qkv / fc1
+        cs, ln_row = torch.zeros(n, device=dev), torch.ones(M, 2, device=dev)
+        return time_kernel(lambda: ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, out=out, m_valid=mv), iters)
+    return time_kernel(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi, m_valid=mv), iters)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -333,35 +369,7 @@ def main():
         from foundpose_amd._lib import call as _call, ptr as _ptr, stream as _stream
 
         dt16 = torch.float16 if args.precision == "f16" else torch.bfloat16
-        f16_bit = (1 << 21) if args.precision == "f16" else 0   # FP_GEMM_F16
-
-        def gemm_ms(n, k, epi):
-            a = torch.randn(M, k, device=dev).to(dt16)
-            w = (torch.randn(n, k, device=dev) * 0.02).to(dt16)
-            bias, gamma = torch.zeros(n, device=dev), torch.ones(n, device=dev)
-            out = torch.zeros(M, n // 2 if epi == 6 else n, dtype=torch.float32 if epi == 3 else dt16, device=dev)
-            if args.precision in ("f16x3", "f16f8"):   # split operands: the algorithmic FLOPs are those of the fp32 product
-                pack = ops.splitx_pack if args.precision == "f16f8" else ops.split16_pack
-                a3, w3 = pack(a.float(), 128.0, 64), pack(w.float(), ops.pow2_scale(w.float()), 64)
-                o3 = torch.zeros(M, n, dtype=torch.float32, device=dev) if epi == 3 else torch.zeros(M, n if epi == 6 else 2 * n, dtype=torch.float16, device=dev)
-                return time_kernel(lambda: ops.gemm_split(a3, w3, bias, 1e-6, gamma=gamma, out=o3, epilogue=epi, out_scale=64.0, m_valid=mv, f16f8=args.precision == "f16f8"))
-            if args.precision == "fp8":
-                a8, w8 = ops.quantize_fp8(a, 50.0), ops.quantize_fp8(w, 5000.0)
-                col = torch.full((n,), 1.0 / (50.0 * 5000.0), device=dev)
-                return time_kernel(lambda: ops.gemm_fp8(a8, w8, bias, col, out=out, epilogue=epi, m_valid=mv))
-            if fold and epi == 3:   # the kernel the pipeline launches 36 times per step: the residual update on the (hi, lo) bf16 stream + LayerNorm row
-                xb = torch.zeros(M, n, dtype=dt16, device=dev)   # sums (epilogue 8; resid_hilo=False: fp32 stream + bf16 copy, epilogue 7)
-                st = torch.zeros(n // 128, M, 2, device=dev)
-                if hilo:
-                    xl = torch.zeros(M, n, dtype=dt16, device=dev)
-                    return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(xl), n, 8 | f16_bit,
-                                                     None, None, _ptr(xb), n, _ptr(st), _stream()))
-                return time_kernel(lambda: _call("fp_gemm_bf16_ln", _ptr(a), a.stride(0), _ptr(w), w.stride(0), M, n, k, mv, _ptr(bias), _ptr(out), n, 7 | f16_bit,
-                                                 None, None, _ptr(xb), n, _ptr(st), _stream()))
-            if fold:                # ... and the normalising epilogues of qkv / fc1
-                cs, ln_row = torch.zeros(n, device=dev), torch.ones(M, 2, device=dev)
-                return time_kernel(lambda: ops.gemm_bf16_ln(a, w, bias, cs, ln_row, epilogue=epi, out=out, m_valid=mv))
-            return time_kernel(lambda: ops.gemm_bf16(a, w, bias, gamma=gamma, out=out, epilogue=epi, m_valid=mv))
+        gemm_ms = lambda n, k, epi: gemm_probe_ms(args.precision, M, mv, n, k, epi, fold, hilo, dev)
         hid = arch.hidden
         ms_proj, ms_fc2 = gemm_ms(arch.dim, arch.dim, 3), gemm_ms(arch.dim, hid, 3)
         ms_fc1 = gemm_ms(hid if arch.ffn == "mlp" else 2 * hid, arch.dim, 1 if arch.ffn == "mlp" else 6)
@@ -945,7 +953,28 @@ def other_config(label, args, dev, rank, steps=5, parity_steps=3):
     if c["precision"] == "fp8":
         ex.calibrate_fp8(wl.crops)
     val, ms, lists = run(ex, steps, 2)
-    out = {"what": c["what"], "value": val, "unit": "detections/s", "ms_per_step": ms, "steps": steps, "warmup": 2, "dtype": c["precision"], "n_gpus": 1,
+    # roofline of the configuration's dominant kernel template (the residual GEMMs proj + fc2 of one block, as for the headline), measured live at ITS shapes
+    n_tok = 1 + arch.registers + (args.size // 14) ** 2
+    mv = B * n_tok
+    Mp = ex.padded_rows(mv)
+    fold = getattr(ex, "fold_layernorm", False)
+    hilo = fold and getattr(ex, "resid_hilo", False)
+    ms_proj = gemm_probe_ms(c["precision"], Mp, mv, arch.dim, arch.dim, 3, fold, hilo, dev, iters=5)
+    ms_fc2 = gemm_probe_ms(c["precision"], Mp, mv, arch.dim, arch.hidden, 3, fold, hilo, dev, iters=5)
+    ms_fc1 = gemm_probe_ms(c["precision"], Mp, mv, arch.hidden if arch.ffn == "mlp" else 2 * arch.hidden, arch.dim, 1 if arch.ffn == "mlp" else 6, fold, hilo, dev, iters=5)
+    peak = PEAK_FP8_TFLOPS if c["precision"] == "fp8" else PEAK_BF16_TFLOPS
+    fl = lambda n, k: 2.0 * mv * n * k
+    ls_tf = (fl(arch.dim, arch.dim) + fl(arch.dim, arch.hidden)) / ((ms_proj + ms_fc2) * 1e-3) / 1e12
+    fc1_tf = fl(arch.hidden if arch.ffn == "mlp" else 2 * arch.hidden, arch.dim) / (ms_fc1 * 1e-3) / 1e12
+    flops_det = vit_flops_per_crop(arch, args.size, c["layer"])
+    roof = {"kernel": ("gemm_bf16_kernel<..., F8> LS_RESID" if c["precision"] == "fp8" else "gemm_bf16_kernel<RESID_HILO>") + " (attn.proj + mlp.fc2 of one block, this configuration's rows)",
+            "bound": "mfma", "achieved": round(ls_tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(ls_tf / peak, 4), "launch_ms": round((ms_proj + ms_fc2) / 2, 4),
+            "launch_ms_proj": round(ms_proj, 4), "launch_ms_fc2": round(ms_fc2, 4), "flops_per_launch": (fl(arch.dim, arch.dim) + fl(arch.dim, arch.hidden)) / 2,
+            "fc1": {"launch_ms": round(ms_fc1, 4), "achieved": round(fc1_tf, 1), "frac": round(fc1_tf / peak, 4)},
+            "vit_end_to_end": {"achieved": round(flops_det * val / 1e12, 1), "frac": round(flops_det * val / 1e12 / peak, 4), "flops_per_detection_all_tokens": flops_det,
+                               "note": "all-token FLOPs of the executed blocks x detections/s (the hooked block runs on the sampled tokens only: an upper bound on the executed fraction)"},
+            "profile": f"profiles/r6_{label}_per_step_kernels.csv (tools/profile_bench.sh), profiles/r6_{label}_pmc_mfma.txt (tools/pmc_mfma.sh)"}
+    out = {"what": c["what"], "roofline": roof, "value": val, "unit": "detections/s", "ms_per_step": ms, "steps": steps, "warmup": 2, "dtype": c["precision"], "n_gpus": 1,
            "workload": f"{c['version']} layer {c['layer']}, {args.size}x{args.size} crops, batch {B}, {c['objects']} object(s) x {c['templates']} templates (N_f={bank.feats.shape[0]}), "
                        f"2048 words, disc masks, tie order '{args.tie_order}', planted like the headline workload",
            "planted": workload.planted_stats(lists, wl.targets.tolist()), "vs_fp32_mode": workload.parity_stats(lists, lists32)}

@@ -510,7 +510,7 @@ struct VitSelection { const int32_t* rows; const int32_t* off; int num, max_per_
 int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const float* images, int B, int H, int W, int layer, int mode,
                      const VitSelection* sel, fp_stream_t stream, int first_block = 0) {
   FP_REQUIRE(m && ws && (images || mode == VIT_LAST_SELECTED || first_block > 0) && m->blocks, "fp_vit_forward: null pointer");
-  FP_REQUIRE(first_block >= 0 && first_block <= layer, "fp_vit_forward_blocks: first_block %d out of range (layer %d)", first_block, layer);
+  FP_REQUIRE(first_block == 0 || (first_block >= 1 && first_block <= layer), "fp_vit_forward_blocks: first_block %d out of range (layer %d)", first_block, layer);
   FP_REQUIRE(layer >= -1 && layer < m->depth, "fp_vit_forward: layer %d out of range (depth %d)", layer, m->depth);  // -1: token embedding only
   const int pstride = m->patch_stride > 0 ? m->patch_stride : m->patch;  // the conv stride of the patch embedding (dinov2_utils.py:364-389)
   FP_REQUIRE(pstride != m->patch || (H % m->patch == 0 && W % m->patch == 0), "fp_vit_forward: image size must be a multiple of the patch size");

@@ -70,20 +70,24 @@ class MatchResult:
                 self._sat_error = e
         if self._sat_error is not None:
             raise self._sat_error
-        counts = self.counts[b].tolist()
-        tids = self.template_ids[b].tolist()
+        # one host copy for the slot table (counts | template ids) and one widening per index array -- the per-slot form (two .tolist() waits, three
+        # casts per slot) was ~60 us of the per-detection loop; the dict entries are views, as the reference's are
+        n = self.counts.shape[1]
+        tab = torch.cat([self.counts[b], self.template_ids[b]]).tolist()
+        counts, tids = tab[:n], tab[n:]
+        tid64, q64, f64 = self.template_ids[b].to(torch.int64), self.q_ids[b].to(torch.int64), self.feat_ids[b].to(torch.int64)
         out = []
         for j, (c, tid) in enumerate(zip(counts, tids)):
             if tid < 0:
                 continue
             d = {
-                "template_id": self.template_ids[b, j].to(torch.int64),
+                "template_id": tid64[j],
                 "template_score": self.template_scores[b, j],
                 "coord_2d": self.coord_2d[b, j, :c],
-                "coord_2d_ids": self.q_ids[b, j, :c].to(torch.int64),
+                "coord_2d_ids": q64[j, :c],
                 "coord_3d": self.coord_3d[b, j, :c],
                 "coord_conf": self.conf[b, j, :c],
-                "nn_vertex_ids": self.feat_ids[b, j, :c].to(torch.int64),
+                "nn_vertex_ids": f64[j, :c],
             }
             if debug:
                 d["nn_dists"] = self.dists[b, j, :c]

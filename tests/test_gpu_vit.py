@@ -129,7 +129,8 @@ def test_attention_bf16_lazy_rescale_staircase(step):
     """The exponent's reference moves only when a tile's maximum exceeds it by more than 8 (csrc/attn.hip, lazy rescale).  Keys whose
     scores climb by `step` (in the exponent, per 64-key tile) walk through every regime: never more than 8 above the reference for long
     stretches (p up to 2^8, no rescale), a rescale every few tiles, a rescale every tile; queries of different gain see different regimes
-    in one wave, so lanes that move and lanes that do not share the rescale branch.  All four work splits stay bit-identical."""
+    in one wave, so lanes that move and lanes that do not share the rescale branch.  The work splits (0 and its cross-check 1; 2 and 3 in FP_EXPERIMENTS
+    builds) stay bit-identical."""
     from foundpose_amd import ops
     N, D, heads = 64 * 9 + 17, 64, 1
     g = torch.Generator().manual_seed(int(step * 10))
@@ -141,7 +142,8 @@ def test_attention_bf16_lazy_rescale_staircase(step):
     q16 = qkv.to(torch.bfloat16)
     q, k, v = q16.double().reshape(1, N, 3, heads, 64).permute(2, 0, 3, 1, 4)
     ref = (torch.softmax(q @ k.transpose(-1, -2) * 0.125, -1) @ v).transpose(1, 2).reshape(N, D)
-    outs = [ops.attention(q16.cuda(), 1, N, D, heads, variant=v_).clone() for v_ in (0, 1, 2, 3)]
+    from tests.helpers import experiments_build
+    outs = [ops.attention(q16.cuda(), 1, N, D, heads, variant=v_).clone() for v_ in ((0, 1, 2, 3) if experiments_build() else (0, 1))]
     torch.cuda.synchronize()
     for o in outs[1:]:
         assert torch.equal(outs[0].view(torch.int16), o.view(torch.int16))
@@ -266,6 +268,8 @@ def test_extractor_tiny_noreg_vs_reference_wrapper_fixture(precision, tol):
 @pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("f16x3", 5e-5), ("bf16", 8e-2)])
 @pytest.mark.parametrize("version,S", NOREG_CASES)
 def test_extractor_noreg_hub_archs_vs_reference_wrapper_fixture(version, S, precision, tol):
+    if version == "vitg14" and precision == "f16x3":
+        pytest.skip("22 s for a case the fp32 / bf16 runs of the same architecture and five other f16x3 cases cover (GPU suite budget)")
     """The reference's DEFAULT backbone family (InferOpts.extractor_name = "dinov2_vitl14", scripts/infer.py:75: no register tokens,
     short form -> layer 9, dinov2_utils.py:62-64) and its ViT-S / ViT-B siblings (D = 768 / 12 heads) at 518 (N = 1370) and at the
     LM-O crop size 420 (N = 901, interpolated table), against the reference wrapper's own output."""
@@ -883,10 +887,13 @@ def test_query_select_equals_filter_points_by_mask(dtype):
         masks = m.to(dtype).cuda()
         eng = FoundPoseEngine(ex, None, grid_cell_size=cell)
         pts, img, counts = eng.query_points(masks)
-        grid = feature_util.generate_grid_points(size_wh, cell).cuda()
+        grid = feature_util.generate_grid_points(size_wh, cell)
+        rnd = torch.rand(300, 2, generator=g) * torch.tensor([size_wh[0] + 20.0, size_wh[1] + 20.0]) - 10.0   # arbitrary points, some outside the canvas
         off = 0
         for b in range(B):
-            ref = feature_util.filter_points_by_mask(grid, m[b].cuda())
+            ref = feature_util.filter_points_by_mask(grid, m[b].to(dtype)).cuda()     # CPU tensors: the reference's tensor-indexing form
+            assert torch.equal(feature_util.filter_points_by_mask(grid.cuda(), masks[b]), ref)    # device tensors: the drop-in's fp_query_select form
+            assert torch.equal(feature_util.filter_points_by_mask(rnd.cuda(), masks[b]), feature_util.filter_points_by_mask(rnd, m[b].to(dtype)).cuda())
             assert counts[b] == ref.shape[0], (size, b)
             assert torch.equal(pts[off:off + counts[b]], ref)
             assert bool((img[off:off + counts[b]] == b).all())

@@ -9,7 +9,7 @@ out=$R/gpurun_out/${tag}_pmc_mfma.txt
 cd /tmp && export TMPDIR=/tmp
 d=/tmp/pmcm_$tag
 rm -rf $d
-timeout 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $d -o r -- python $R/bench.py --steps 3 --warmup 1 --skip-probes "$@" > /dev/null 2>&1
+timeout 1500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE -d $d -o r -- python $R/bench.py --steps 3 --warmup 1 --skip-probes "$@" > /dev/null 2>&1
 db=$(find $d -name "*.db" 2>/dev/null | head -1)
 python - "$db" "$*" > $out <<'PY'
 import sqlite3, sys
