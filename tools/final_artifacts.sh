@@ -5,12 +5,15 @@ tag=${1:-rX}
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 python -m pytest tests -q -m gpu 2>&1 | tail -15 > gpurun_out/${tag}_pytest_gpu.log
+python tools/f16_probe.py 2>&1 | grep "^1 " > gpurun_out/${tag}_f16_probe.txt
 python bench.py < /dev/null 2>/dev/null | tail -1 > gpurun_out/${tag}_bench_final.json
 bash tools/profile_bench.sh ${tag}_final > /dev/null 2>&1
+bash tools/profile_bench.sh ${tag}_f16 --precision f16 --parity-precision none > /dev/null 2>&1
 bash tools/profile_bench.sh ${tag}_f16x3 --precision f16x3 --parity-precision none > /dev/null 2>&1
 bash tools/profile_bench.sh ${tag}_f16f8 --precision f16f8 --parity-precision none > /dev/null 2>&1
 bash tools/pmc_bench.sh ${tag} > /dev/null 2>&1
 bash tools/pmc_mfma.sh ${tag}_bf16 > /dev/null 2>&1
+bash tools/pmc_mfma.sh ${tag}_f16 --precision f16 > /dev/null 2>&1
 bash tools/pmc_mfma.sh ${tag}_f16x3 --precision f16x3 > /dev/null 2>&1
 tail -3 gpurun_out/${tag}_pytest_gpu.log
 python -c "import json; d=json.load(open('gpurun_out/${tag}_bench_final.json')); print(d['value'], d['ms_per_step'], d['roofline']); print(d.get('parity_mode',{}).get('value'))"
