@@ -31,24 +31,27 @@ PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
 # HBM-side bytes of one launch of the dominant kernel template from the rocprofv3 --pmc passes of THIS code (per the
 # guide's gfx950 corrections); keyed by (version, size, batch, precision).  Source file + commit are reported next to it.
 PMC_TRAFFIC = {
-    # gemm_bf16_kernel<RESID_HILO> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 328.0 KiB + WRITE_SIZE 178 620.8 KiB) x 1024
-    # (round 4, same kernel: 730 395 136; the fp32-stream kernel it replaced wrote 266 565 KiB: 6 B per element of the stream against 4 now)
-    ("vitl14-reg", 518, 32, "bf16"): 730395443,
+    # gemm_bf16_kernel<RESID_HILO> (256^2 tiles), average over the proj and fc2 launches of the pipeline's steps: (2 x FETCH_SIZE 267 327.5 KiB + WRITE_SIZE 178 620.8 KiB) x 1024
+    # (rounds 4 and 5, same kernel: 730 395 136 / 730 395 443; the fp32-stream kernel it replaced wrote 266 565 KiB: 6 B per element of the stream against 4 now)
+    ("vitl14-reg", 518, 32, "bf16"): 730394419,
 }
-PMC_TRAFFIC_SOURCE = ("profiles/r5_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
-                      "final round-5 artefact pass; round 4: 730.4 MB, rounds 2-3 with the fp32-stream RESID kernel: 819.7 / 820.6 MB)")
+PMC_TRAFFIC_SOURCE = ("profiles/r6_pmc_traffic.txt (tools/pmc_bench.sh: rocprofv3 --pmc over `python bench.py --skip-probes`, every counted launch belongs to a step; "
+                      "the round-6 artefact pass; rounds 4 / 5: 730.4 MB, rounds 2-3 with the fp32-stream RESID kernel: 819.7 / 820.6 MB)")
 
 # Matrix-pipe utilisation of the ViT forward as the counters report it: sum of SQ_VALU_MFMA_BUSY_CYCLES over the bf16 step's ViT launches /
 # (1024 SIMDs x their GRBM_GUI_ACTIVE / 8 cycles), from the rocprofv3 --pmc pass of THIS code over `python bench.py --skip-probes`.  It is
 # higher than the FLOP fraction of the nominal 2.5 PFLOP/s because the chip holds ~2.0 of its 2.4 GHz under this load (DVFS).  A duty cycle of the
 # matrix pipe, NOT north_star's "MFMA utilisation" (that is roofline_vit_end_to_end.frac, by FLOPs: 0.36, target 0.40 not met).
 PMC_MFMA_UTIL = {
-    # per kernel (tools/pmc_mfma_aggregate.py): RESID_HILO 0.429 (144 launches x 512.8 k cycles), fc1 on 320-row tiles 0.469 (72 x 753.7 k; the hooked block's,
+    # per kernel (tools/pmc_mfma_aggregate.py; round 5: RESID_HILO 0.429 (144 launches x 512.8 k cycles), fc1 on 320-row tiles 0.469 (72 x 753.7 k; the hooked block's,
     # 256 rows: 0.447), attention 0.408 (76 x 563.7 k; 0.388 x 593.5 k before the K-row permutation took the lane exchanges out), qkv on 320-row tiles 0.499
-    # (76 x 530.6 k), hooked block's 128^2 launches 0.268, patch embed 0.223, ln_finalize / rowstats_cast / hilo_rows 0
-    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.430, "resid_gemm": 0.429, "fc1": 0.469, "qkv": 0.499, "attention": 0.408},
+    # (76 x 530.6 k), hooked block's 128^2 launches 0.268, patch embed 0.223, ln_finalize / rowstats_cast / hilo_rows 0; round 6 below: the same within a count)
+    ("vitl14-reg", 518, 32, "bf16"): {"vit_forward": 0.426, "resid_gemm": 0.431, "fc1": 0.469, "qkv": 0.500, "attention": 0.409},
+    # the f16 mode's kernels take the SAME cycle counts (RESID 504.8 k against 510.7 k, fc1 760.7 k / 753.1 k, attention 565.8 k / 562.1 k, qkv 529.2 k / 530.0 k):
+    # its 3.5-4 % longer launches are a lower clock under the fp16 multipliers' power draw, not more cycles
+    ("vitl14-reg", 518, 32, "f16"): {"vit_forward": 0.427, "resid_gemm": 0.436, "fc1": 0.464, "qkv": 0.501, "attention": 0.407},
 }
-PMC_MFMA_UTIL_SOURCE = "profiles/r5_bf16_pmc_mfma.txt (tools/pmc_mfma.sh, final round-5 artefact pass)"
+PMC_MFMA_UTIL_SOURCE = "profiles/r6_bf16_pmc_mfma.txt, profiles/r6_f16_pmc_mfma.txt (tools/pmc_mfma.sh, the round-6 artefact pass)"
 
 
 def synthetic_disc_patches(size):

@@ -608,12 +608,13 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
   // (the residual GEMM files its partial sums with a stride of ITS row count: rows_pad)
   auto finalize = [&]() -> int { return ln_finalize_launch(stats, ln_parts, rows_pad, rows_valid, D, 1e-6f, ln_row, st); };
   auto gemm = [&](const void* A, int lda, const void* Wt, int ldw, int N, int K, const float* bias, const float* gamma, void* out, int ldo, int epi,
-                  const float* colsum, bool produce) -> int {
+                  const float* colsum, bool produce, float w_inv_scale = 0.f) -> int {
     GemmBf16Args g;
     memset(&g, 0, sizeof(g));
     g.A = reinterpret_cast<const __bf16*>(A); g.lda = lda; g.W = reinterpret_cast<const __bf16*>(Wt); g.ldw = ldw;
     g.M = rows_pad; g.N = N; g.K = K; g.M_valid = rows_valid; g.bias = bias; g.gamma = gamma; g.out = out; g.ldo = ldo;
     g.no_tall = (m->flags & FP_VIT_NO_TALL_TILES) ? 1 : 0;
+    g.acc_scale = h16 ? w_inv_scale : 0.f;   // FP_F16: 1 / (power-of-two scale of this weight matrix), fp_vit_block.act_scale[j]; 0 = unscaled
     if (colsum) { g.ln_stats = ln_row; g.ln_parts = ln_parts; g.ln_eps = 1e-6f; g.colsum = colsum; }
     if (produce) { g.xb = reinterpret_cast<__bf16*>(ws->xb); g.ld_xb = ldy; g.stats_out = stats; g.xl = reinterpret_cast<__bf16*>(ws->xl); }
     return h16 ? gemm_f16_launch(epi, g, st) : gemm_bf16_launch(epi, g, st);
@@ -630,7 +631,7 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       // so the selected rows carry the bits the full block would have given them.
       FP_REQUIRE(b.qkv_colsum && b.fc1_colsum, "fp_vit_forward: ln_fold needs the column sums of qkv_w / fc1_w");
       TRY(finalize());
-      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
+      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false, b.act_scale[0]));
       AttnArgs as = at;
       as.sel_rows = sel->rows; as.sel_off = sel->off; as.max_sel = sel->max_per_img;
       TRY(attn_launch(as, attn_dt, st));
@@ -639,13 +640,13 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       else TRY(gather_rows_launch(ws->x, sel->rows, sel->num, D, xs, st));
       rows_valid = sel->num;
       rows_pad = (sel->num + 255) / 256 * 256 < ws->m_pad ? (sel->num + 255) / 256 * 256 : ws->m_pad;
-      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, true));
+      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, true, b.act_scale[1]));
       TRY(finalize());
       if (m->ffn_swiglu)
-        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false));
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false, b.act_scale[2]));
       else
-        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false));
-      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, false));
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false, b.act_scale[2]));
+      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, xs, D, GEMM_EPI_RESID_F32, nullptr, false, b.act_scale[3]));
       continue;
     }
     if (fold) {
@@ -655,16 +656,16 @@ int vit_forward_impl(const fp_vit_model* m, const fp_vit_workspace* ws, const fl
       const int resid = pair ? GEMM_EPI_RESID_HILO : GEMM_EPI_RESID_F32;
       if (hilo && i == layer && i > 0) TRY(hilo_rows_launch(ws->xb, ws->xl, ldy, nullptr, Mtok, D, ws->x, st, h16));   // VIT_FULL: the hooked block's fp32 stream, all rows
       TRY(finalize());
-      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false));
+      TRY(gemm(ws->xb, ldy, b.qkv_w, ldwd, 3 * D, D, b.qkv_b, nullptr, ws->qkv, ldq, GEMM_EPI_BIAS_BF16, b.qkv_colsum, false, b.act_scale[0]));
       TRY(attn_launch(at, attn_dt, st));
-      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, resid, nullptr, true));
+      TRY(gemm(ws->y, ldy, b.proj_w, ldwd, D, D, b.proj_b, nullptr, ws->x, D, resid, nullptr, true, b.act_scale[1]));
       // x += ls2 * fc2(act(fc1(ln2(x))))
       TRY(finalize());
       if (m->ffn_swiglu)
-        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false));
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, 2 * m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_SWIGLU_BF16, b.fc1_colsum, false, b.act_scale[2]));
       else
-        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false));
-      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, ws->x, D, resid, nullptr, i < layer));
+        TRY(gemm(ws->xb, ldy, b.fc1_w, ldwd, m->hidden, D, b.fc1_b, nullptr, ws->h, ldh, GEMM_EPI_GELU_BF16, b.fc1_colsum, false, b.act_scale[2]));
+      TRY(gemm(ws->h, ldh, b.fc2_w, ldwh, D, m->hidden, b.fc2_b, nullptr, ws->x, D, resid, nullptr, i < layer, b.act_scale[3]));
       continue;
     }
     // x += ls1 * proj(attn(ln1(x)))

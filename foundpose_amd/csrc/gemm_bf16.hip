@@ -266,6 +266,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float2 st = a.ln_stats[m0 + wm * (BM / WM) + i * 32 + l31];
           ln_rs[i] = st.x;
           ln_mrs[i] = st.y;
+          if constexpr (H16) {  // W (and with it acc and colsum) carries the matrix's power-of-two scale: rstd (acc - mean colsum) / s_w, exactly
+            ln_rs[i] *= a.acc_scale;
+            ln_mrs[i] *= a.acc_scale;
+          }
         }
       }
     }
@@ -541,7 +545,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
-          if constexpr (SP) {  // undo the power-of-two operand scales (exact), then the bias
+          if constexpr (SP || H16) {  // undo the power-of-two operand scales (exact), then the bias  (H16: the weight matrix's scale, 1 when the caller gave none)
             const float as = a.acc_scale;
             v0 = fmaf(acc[tm][tn][4 * g + 0], as, bs.x); v1 = fmaf(acc[tm][tn][4 * g + 1], as, bs.y);
             v2 = fmaf(acc[tm][tn][4 * g + 2], as, bs.z); v3 = fmaf(acc[tm][tn][4 * g + 3], as, bs.w);
@@ -738,7 +742,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           const float4 bs = bias[tn][g];
           float v0 = acc[tm][tn][4 * g + 0] + bs.x, v1 = acc[tm][tn][4 * g + 1] + bs.y;
           float v2 = acc[tm][tn][4 * g + 2] + bs.z, v3 = acc[tm][tn][4 * g + 3] + bs.w;
-          if constexpr (SP) {
+          if constexpr (SP || H16) {
             const float as = a.acc_scale;
             v0 = fmaf(acc[tm][tn][4 * g + 0], as, bs.x); v1 = fmaf(acc[tm][tn][4 * g + 1], as, bs.y);
             v2 = fmaf(acc[tm][tn][4 * g + 2], as, bs.z); v3 = fmaf(acc[tm][tn][4 * g + 3], as, bs.w);
@@ -801,6 +805,9 @@ static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
 template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
+  if constexpr (H16) {
+    if (!(a.acc_scale > 0.f)) a.acc_scale = 1.f;   // fp16 weights without a scale (the plain entry points)
+  }
   // M is padded to whole tiles of every shape in use; tiles of padding rows only are not launched (they would all sit at the end of the
   // tile order, i.e. in the last XCD's chunk, and leave that XCD short of work)
   a.m_tiles = a.M / BM;

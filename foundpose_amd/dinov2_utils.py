@@ -217,18 +217,30 @@ class DinoFeatureExtractor(torch.nn.Module):
         def f32(key):
             return sd[key].to(dev, torch.float32)
 
-        def folded_in(wkey, bkey, nkey, wmat=None, bvec=None):
-            """LayerNorm (gain g, shift s) in front of a Linear (W, b): W' = W diag(g) in bf16, b' = b + W s, colsum of W'."""
+        # f16 mode: every folded matrix carries a power-of-two scale s_w that brings its largest entry to ~2^14 (exact; undone in the epilogue through
+        # fp_vit_block.act_scale[j] = 1 / s_w): fp16 keeps 11 significant bits only down to 6e-5, and a LayerScale-folded matrix diag(gamma) W of a checkpoint
+        # whose gammas are small (DINOv2 initialises them at 1e-5) would otherwise sit in the subnormal range, where fp16 is WORSE than bf16
+        h16 = self.precision == "f16"
+        scales = {}
+
+        def scaled(Wf32, name):
+            from . import ops
+            sw = ops.pow2_scale(Wf32) if h16 else 1.0
+            scales[name] = sw
+            return padded((Wf32 * sw).to(wdt)) if h16 else padded(Wf32.to(wdt))
+
+        def folded_in(wkey, bkey, nkey, wmat=None, bvec=None, name=None):
+            """LayerNorm (gain g, shift s) in front of a Linear (W, b): W' = W diag(g) in bf16 (f16: s_w W'), b' = b + W s, colsum of the stored W'."""
             W = f32(wkey) if wmat is None else wmat
             bb = f32(bkey) if bvec is None else bvec
             g, sh = f32(nkey + ".weight"), f32(nkey + ".bias")
-            Wf = padded((W * g[None, :]).to(wdt))
+            Wf = scaled(W * g[None, :], name)
             return Wf, (bb + W @ sh).contiguous(), Wf.float().sum(dim=1).contiguous()
 
-        def folded_out(wkey, bkey, gkey):
-            """LayerScale gamma behind a Linear: W'' = diag(gamma) W in bf16, b'' = gamma * b."""
+        def folded_out(wkey, bkey, gkey, name=None):
+            """LayerScale gamma behind a Linear: W'' = diag(gamma) W in bf16 (f16: s_w W''), b'' = gamma * b."""
             gm = f32(gkey)
-            return padded((f32(wkey) * gm[:, None]).to(wdt)), (gm * f32(bkey)).contiguous()
+            return scaled(f32(wkey) * gm[:, None], name), (gm * f32(bkey)).contiguous()
 
         for i in range(a.depth):
             p = f"blocks.{i}."
@@ -237,22 +249,24 @@ class DinoFeatureExtractor(torch.nn.Module):
                 b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
                 b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))
                 b.ls1, b.ls2 = ptr(vec(p + "ls1.gamma")), ptr(vec(p + "ls2.gamma"))
-                w[p + "qkv.wf"], w[p + "qkv.bf"], w[p + "qkv.cs"] = folded_in(p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1")
-                w[p + "proj.wf"], w[p + "proj.bf"] = folded_out(p + "attn.proj.weight", p + "attn.proj.bias", p + "ls1.gamma")
+                w[p + "qkv.wf"], w[p + "qkv.bf"], w[p + "qkv.cs"] = folded_in(p + "attn.qkv.weight", p + "attn.qkv.bias", p + "norm1", name=0)
+                w[p + "proj.wf"], w[p + "proj.bf"] = folded_out(p + "attn.proj.weight", p + "attn.proj.bias", p + "ls1.gamma", name=1)
                 if a.ffn == "mlp":
-                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2")
-                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.fc2.weight", p + "mlp.fc2.bias", p + "ls2.gamma")
+                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(p + "mlp.fc1.weight", p + "mlp.fc1.bias", p + "norm2", name=2)
+                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.fc2.weight", p + "mlp.fc2.bias", p + "ls2.gamma", name=3)
                 else:  # SwiGLU: rows of w12 interleaved (x1_j, x2_j), see below
                     w12, b12 = f32(p + "mlp.w12.weight"), f32(p + "mlp.w12.bias")
                     hdn = w12.shape[0] // 2
                     w12i = torch.stack([w12[:hdn], w12[hdn:]], 1).reshape(2 * hdn, -1)
                     b12i = torch.stack([b12[:hdn], b12[hdn:]], 1).reshape(-1)
-                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(None, None, p + "norm2", w12i, b12i)
-                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.w3.weight", p + "mlp.w3.bias", p + "ls2.gamma")
+                    w[p + "fc1.wf"], w[p + "fc1.bf"], w[p + "fc1.cs"] = folded_in(None, None, p + "norm2", w12i, b12i, name=2)
+                    w[p + "fc2.wf"], w[p + "fc2.bf"] = folded_out(p + "mlp.w3.weight", p + "mlp.w3.bias", p + "ls2.gamma", name=3)
                 b.qkv_w, b.qkv_b, b.qkv_colsum = ptr(w[p + "qkv.wf"]), ptr(w[p + "qkv.bf"]), ptr(w[p + "qkv.cs"])
                 b.proj_w, b.proj_b = ptr(w[p + "proj.wf"]), ptr(w[p + "proj.bf"])
                 b.fc1_w, b.fc1_b, b.fc1_colsum = ptr(w[p + "fc1.wf"]), ptr(w[p + "fc1.bf"]), ptr(w[p + "fc1.cs"])
                 b.fc2_w, b.fc2_b = ptr(w[p + "fc2.wf"]), ptr(w[p + "fc2.bf"])
+                for j in range(4):
+                    b.act_scale[j] = 1.0 / scales[j] if h16 else 0.0
                 continue
             b.ln1_w, b.ln1_b = ptr(vec(p + "norm1.weight")), ptr(vec(p + "norm1.bias"))
             b.ln2_w, b.ln2_b = ptr(vec(p + "norm2.weight")), ptr(vec(p + "norm2.bias"))

@@ -235,6 +235,9 @@ typedef struct {
   /* weight_dtype == FP_F16X3 (FP_F16F8: the same with f16f8 rows): the four matrices are split-fp16 rows ([N, 2K] halves) of s_w W with a power-of-two s_w per
    * matrix, and act_scale[0..3] = 1 / (scale of the GEMM's input rows x s_w) for qkv, proj, fc1, fc2: the epilogue computes
    * acc * act_scale + bias.  ls1 / ls2 are applied as usual. */
+  /* weight_dtype == FP_F16: the four (folded) matrices may be stored times a power of two s_w each -- fp16 keeps its 11 bits only down to 6e-5, which a
+   * LayerScale-folded matrix of small gammas would undershoot -- with act_scale[0..3] = 1 / s_w for qkv, proj, fc1, fc2 (0 = unscaled); colsum is then the
+   * row sum of the STORED matrix. */
   /* fp_vit_model.ln_fold only: fp32 [N] sums of the rows of the (gain-folded, bf16-rounded) qkv_w / fc1_w */
   const float *qkv_colsum, *fc1_colsum;
 } fp_vit_block;

@@ -349,3 +349,31 @@ def test_precision_schedule_runs_two_models_over_one_stream(head, tail):
     for f in ("template_ids", "counts", "q_ids", "feat_ids", "dists", "coord_3d"):
         x, y = getattr(outs[0], f), getattr(outs[1], f)
         assert torch.equal(x, y) or bool(((x == y) | (x.isnan() & y.isnan())).all()), f
+
+
+def test_f16_weight_matrices_carry_power_of_two_scales():
+    """LayerScale is folded into proj / fc2 (fp_vit_model.ln_fold): with the small gammas DINOv2 starts from, diag(gamma) W would sit in fp16's subnormal range,
+    where the format has FEWER significant bits than bf16.  Every folded matrix is therefore stored times a power of two that brings its largest entry to
+    [2^13, 2^14] and the epilogue undoes it exactly (fp_vit_block.act_scale): with gammas of 1e-3 the mode stays several times closer to the fp32 oracle than
+    bf16, and the stored matrices are where they should be."""
+    arch = ARCHS["vits14-reg"]
+    name = "dinov2_version=vits14-reg_stride=14_facet=token_layer=5_norm=1"
+    sd = {k: v.clone() for k, v in synthetic.make_vit_state_dict(arch, seed=5).items()}
+    for i in range(arch.depth):
+        sd[f"blocks.{i}.ls1.gamma"] *= 1e-3
+        sd[f"blocks.{i}.ls2.gamma"] *= 1e-3
+        sd[f"blocks.{i}.attn.proj.weight"] *= 30.0      # (so that the blocks still move the stream: contributions ~3e-2 of what they were)
+        sd[f"blocks.{i}.mlp.fc2.weight"] *= 30.0
+    imgs = synthetic.make_crops(2, 224, seed=2)
+    ref = ov.extractor_forward(sd, arch, imgs, 5, True)["feature_maps"]
+    e = {}
+    for prec in ("bf16", "f16"):
+        ex = _mk(arch, name, sd, prec)
+        e[prec] = rel_err(ex(imgs.cuda())["feature_maps"].cpu(), ref)
+    assert e["f16"] < e["bf16"] / 3, e
+    for j, key in enumerate(("qkv.wf", "proj.wf", "fc1.wf", "fc2.wf")):
+        wmax = float(ex._w["blocks.2." + key].float().abs().max())
+        assert 2.0 ** 13 <= wmax <= 2.0 ** 14, (key, wmax)
+        inv = float(ex._blocks[2].act_scale[j])
+        assert inv > 0 and abs(np.log2(inv) - round(np.log2(inv))) < 1e-9       # a power of two
+    assert float(ex._blocks[2].act_scale[1]) < 2.0 ** -15                       # proj: gamma 1e-3 x W 0.6 -> scaled up by >= 2^15
