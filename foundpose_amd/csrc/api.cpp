@@ -502,7 +502,7 @@ enum { VIT_FULL = 0, VIT_PREFIX = 1, VIT_LAST_SELECTED = 2 };
 struct VitSelection { const int32_t* rows; const int32_t* off; int num, max_per_img; };
 
 // VIT_FULL: embedding + blocks 0..layer.  VIT_PREFIX: embedding + blocks 0..layer-1, leaving what block `layer` starts from:
-// the fp32 stream ws->x, its bf16 copy and the LayerNorm row sums -- or, with ws->xl set (the default, FP_RESID_HILO=1) and layer > 0,
+// the fp32 stream ws->x, its bf16 copy and the LayerNorm row sums -- or, with ws->xl set (the extractor's default, resid_hilo=True) and layer > 0,
 // the (xb, xl) pair and the row sums ONLY: ws->x is then stale (it holds the token embedding) and must not be read by a caller.  VIT_LAST_SELECTED: block `layer` alone, computed for the selected
 // tokens only (queries of the attention, rows of proj / fc1 / fc2) on top of a VIT_PREFIX run -- keys and values are all tokens.
 // first_block > 0 (precision schedules, fp_vit_forward_blocks): no embedding -- the fp32 stream of blocks 0..first_block-1 is already in ws->x (another model's

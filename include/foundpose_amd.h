@@ -88,7 +88,7 @@ int fp_normalize_rows(const float* x, int64_t n, int d, float eps, float* out, f
  * q [m,d], db [n,d], precomputed squared norms of both.  Scratch: FP_KNN_SCRATCH_BYTES(m, n, k): k == 1: m*8 bytes; 2 <= k <= 8:
  * m * max(ceil(n/128) * k * 8, 704) bytes (candidate keys, no distance matrix); k > 8: m*n*4 bytes.  out_d2 [m,k] (squared),
  * out_idx [m,k] int32, ascending, ties -> lowest index, (inf, -1) past the database size.
- * Opt-in (environment FP_KNN_CAND=1; measured slower than the all-pairs tile on the benchmark shapes, so not the default): 2 <= k <= 4
+ * FP_EXPERIMENTS builds only (fp_build_experiments() == 1, there with FP_KNN_CAND=1 in the environment; measured slower than the all-pairs tile on the benchmark shapes): 2 <= k <= 4
  * with d = 64 / 128 / 256, n >= 256 (the visual-word search: k = 3, d = 256) runs in two stages -- an fp16-MFMA candidate pass whose
  * error bound is derived from the operands' norms (csrc/knn_cand.hip), then the exact fp32 chain on the candidates -- with outputs
  * bit-identical to the all-pairs exact-fp32 tile that serves every other case; rows the bound cannot cover (values beyond the fp16
@@ -159,7 +159,7 @@ int fp_cosine_topk_prefiltered(const float* desc_n, const int32_t* det_seg_off, 
  *   feat_base [B]: first feature row of the detection's object (reported feature ids are object-local)
  *   scratch: FP_CYCLIC_SCRATCH_BYTES(B * n_slots, q_max, p_max) bytes (nearest-neighbour keys of both directions + the candidate
  *   lists of the two-stage search, or one slice of keys per 128 x 128 distance tile of the all-pairs form; nothing has to be preset)
- *   FP_KNN_CAND=1 (opt-in, see fp_knn_l2) and d = 64 / 128 / 256: the two 1-NN searches run as fp16-MFMA candidate pass + exact re-scoring
+ *   FP_EXPERIMENTS builds with FP_KNN_CAND=1 (see fp_knn_l2) and d = 64 / 128 / 256: the two 1-NN searches run as fp16-MFMA candidate pass + exact re-scoring
  *   (csrc/knn_cand.hip, same keys bit for bit); otherwise the all-pairs exact-fp32 tile
  * outputs, padded to k_max >= top_k per (detection, slot): count, query ids, object feature ids (= the
  * reference's nn_vertex_ids), cycle distances, confidences, coord_2d, coord_3d.  tie_mode as in fp_cosine_topk: 1 makes
@@ -417,8 +417,9 @@ int fp_gemm_split(const void* A, int lda, const void* W, int ldw, int M, int N, 
                   void* out, int ldo, int epilogue, float acc_scale, float out_scale, fp_stream_t stream);
 /* Attention on split rows: qkv [B*N, 6D] halves (q | k | v, each 2D, split-fp16 rows of scale in_scale) -> out [B*N, 2D] halves (scale out_scale);
  * out_dtype FP_F16X3: a split-fp16 row, FP_F16F8: an f16f8 row (the f16f8 mode's proj operand); optionally OR-ed with FP_ATTN_VARIANT(v), test bits as in
- * fp_attention: 0 = the kernel the pipeline runs (the lock-step kernel; the role-split one with FP_ATTN_SPLIT_PP=1 in the environment), 1 = the lock-step kernel,
- * 2 = the role-split kernel (the two waves of a SIMD half a key tile apart; measured not faster, profiles/EXPERIMENTS.md section 0).  All bit-identical. */
+ * fp_attention: 0 = the kernel the pipeline runs (the lock-step kernel), 1 = the lock-step kernel,
+ * 2 = the role-split kernel (the two waves of a SIMD half a key tile apart; measured not faster, profiles/EXPERIMENTS.md section 0b: FP_EXPERIMENTS builds only, the shipped
+ * library returns FP_ERR_UNSUPPORTED; in_scale >= 1).  All bit-identical. */
 int fp_attention_split(const void* qkv, int ld_qkv, void* out, int ld_out, int B, int n_tok, int dim, int heads, float in_scale, float out_scale,
                        int out_dtype, fp_stream_t stream);
 /* LayerNorm whose output carries a scale: out_dtype FP_FP8 (e4m3(y * out_scale) bytes), FP_F16X3 (split row of y * out_scale) or FP_F16F8 (f16f8 row) */
@@ -429,9 +430,9 @@ int fp_quantize_fp8(const void* in, int in_dtype, int64_t n, float scale, void* 
 int fp_gemm_f32(const float* A, int lda, const float* W, int ldw, int M, int N, int K, const float* bias,
                 const float* gamma, float* out, int ldo, int epilogue, fp_stream_t stream);
 /* qkv [B*N, 3D] (q | k | v column blocks, head-major inside) -> out [B*N, D].
- * dtype: FP_F32 / FP_BF16 (+ FP_F16X3, see fp_vit_forward), optionally OR-ed with FP_ATTN_VARIANT(v) to pick a bf16 work split
- * (all bit-identical): 0 = 64 queries per wave, K/V by LDS-DMA (default), 1 = 32 queries per wave with register staging,
- * 2 = the DMA kernel with 8 waves per 256-query block, 3 = 8 waves x 64 queries (512-query blocks).
+ * dtype: FP_F32 / FP_BF16 / FP_F16 (IEEE fp16 q | k | v and output: the "f16" mode's kernel, variant 0 only), optionally OR-ed with FP_ATTN_VARIANT(v) to pick a
+ * bf16 work split (all bit-identical): 0 = 64 queries per wave, K/V by LDS-DMA (default), 1 = 32 queries per wave with register staging (the cross-check);
+ * FP_EXPERIMENTS builds only (measured slower): 2 = the DMA kernel with 8 waves per 256-query block, 3 = 8 waves x 64 queries (512-query blocks), 4 = K prefetch.
  * FP_F32: 0 = flash attention on the fp32 MFMA (default), 1 = one thread per query with one fma chain per score (its cross-check;
  * the two agree to fp32 rounding, not bit for bit). */
 #define FP_ATTN_VARIANT(v) ((v) << 8)
