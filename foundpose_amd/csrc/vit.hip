@@ -13,9 +13,12 @@ namespace {
 // the rows) and fetch their next row before reducing the current one, so the 12 dependent shuffle steps of the two
 // reductions overlap with HBM latency instead of following it.
 // VEC = floats per lane and access: 4 (16-B loads, 8-B bf16 stores; needs D % 256 == 0: ViT-B/L/g) or 2 (ViT-S).
-template <int VEC>
+// MAXI = vectors a lane may hold of one row (dim <= 64 * VEC * MAXI), a compile-time bound on the two row images a wave keeps in registers (the current row
+// and the next one, in flight): sized for dim 2048 the kernel needed 171 VGPRs = 2 waves per SIMD, and with 8 waves per CU x one prefetched row each the
+// launch kept 12 MB in flight -- 3.9 TB/s at the ~3 us loaded latency (config 5: 80 launches x 349 us = 9 % of the step).  Instantiated per row length, the
+// ViT-L / ViT-g rows take 4 / 6 vectors: ~70 / ~95 VGPRs, 5-7 waves per SIMD.  Same loops, same order: the same bits.
+template <int VEC, int MAXI>
 __global__ __launch_bounds__(256) void layernorm_kernel(LayerNormArgs a) {
-  constexpr int MAXI = 2048 / (64 * VEC);
   typedef __attribute__((ext_vector_type(VEC))) float vec_t;
   const int lane = threadIdx.x & 63;
   const int wstride = gridDim.x * 4;
@@ -592,15 +595,21 @@ int layernorm_launch(const LayerNormArgs& a, hipStream_t st) {
   FP_REQUIRE(a.ld_x % 2 == 0 && a.ld_out % 2 == 0, "layernorm: leading dims must be even");
   if (a.out_rows == 0) return FP_OK;
   const int wgs = cdiv(a.out_rows, 4);
-  const int grid = wgs < 2048 ? wgs : 2048;  // 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
+  const int grid = wgs < 2048 ? wgs : 2048;  // up to 8 workgroups (32 waves) per CU, each wave walks out_rows / 8192 rows
   FP_REQUIRE(a.out_dtype != FP_DTYPE_FP8 || (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0 && a.out_scale > 0.f),
              "layernorm: fp8 output needs dim %% 256 == 0 and a positive scale");
   FP_REQUIRE((a.out_dtype != FP_DTYPE_F16X3 && a.out_dtype != FP_DTYPE_F16F8) || (a.ld_out >= 2 * a.dim && a.ld_out % 4 == 0 && a.out_scale > 0.f),
              "layernorm: a split-fp16 / f16f8 output row is 2 * dim halves and needs a positive scale");
-  if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0)
-    hipLaunchKernelGGL(layernorm_kernel<4>, dim3(grid), dim3(256), 0, st, a);
-  else
-    hipLaunchKernelGGL(layernorm_kernel<2>, dim3(grid), dim3(256), 0, st, a);
+  if (a.dim % 256 == 0 && a.ld_x % 4 == 0 && a.ld_out % 4 == 0) {
+    if (a.dim <= 512) hipLaunchKernelGGL((layernorm_kernel<4, 2>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.dim <= 1024) hipLaunchKernelGGL((layernorm_kernel<4, 4>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.dim <= 1536) hipLaunchKernelGGL((layernorm_kernel<4, 6>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<4, 8>), dim3(grid), dim3(256), 0, st, a);
+  } else {
+    if (a.dim <= 384) hipLaunchKernelGGL((layernorm_kernel<2, 3>), dim3(grid), dim3(256), 0, st, a);
+    else if (a.dim <= 768) hipLaunchKernelGGL((layernorm_kernel<2, 6>), dim3(grid), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((layernorm_kernel<2, 16>), dim3(grid), dim3(256), 0, st, a);
+  }
   FP_CHECK_LAUNCH("layernorm");
   return FP_OK;
 }
