@@ -1,3 +1,5 @@
+"""LayerNorm kernel at the shapes of the modes that run it per block (fp8: ViT-g rows of config 5's share; split modes: ViT-L rows): us per launch and bytes/s.
+The ViT-L inputs (180 MB) fit the 256 MiB Infinity Cache when launched back to back: only the ViT-g figure is an HBM rate.   gpurun -- python tools/ln_probe.py"""
 import sys, os, torch
 sys.path.insert(0, os.getcwd())
 from foundpose_amd import _lib
