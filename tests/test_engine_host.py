@@ -81,3 +81,43 @@ def test_f16f8_row_packing_host_side():
     # values beyond the fp16 range saturate in the high half and in its e4m3 copy (the device reports them: saturation counters)
     sat = ops.splitx_pack(torch.full((1, 64), 1.0e6), 1.0)
     assert float(sat[0, 0]) == 65504.0 and int(sat.view(torch.uint8)[0, 128]) == int(torch.tensor(448.0).to(torch.float8_e4m3fn).view(torch.uint8))
+
+
+def test_pose_agreement_counts_identical_and_within_tolerance():
+    """workload.pose_agreement (bench.py parity.hard.pose_under_noise): detections found by both runs, identical poses, poses within north_star's 1e-4 on R AND t."""
+    import torch
+    from foundpose_amd import workload
+    R = torch.eye(3, dtype=torch.float64).repeat(4, 1, 1)
+    t = torch.tensor([[0.0, 0.0, 1000.0]] * 4, dtype=torch.float64)
+    ref = {"found": torch.tensor([True, True, True, False]), "R": R, "t": t}
+    R2, t2 = R.clone(), t.clone()
+    R2[1, 0, 1] += 5e-5            # within 1e-4, not identical
+    t2[2, 2] += 1.0                # 1e-3 relative: outside
+    got = {"found": torch.tensor([True, True, True, True]), "R": R2, "t": t2}
+    st = workload.pose_agreement(got, ref)
+    assert st["detections"] == 4 and st["found_both"] == 3 and st["identical"] == 1 and st["within_1e-4"] == 2
+    assert abs(st["max_abs_dR"] - 5e-5) < 1e-12 and abs(st["max_rel_dt"] - 1e-3) < 1e-9
+
+
+def test_update_bars_merges_and_keeps_untouched_keys(tmp_path, monkeypatch):
+    """tools/update_bars.py folds a (possibly partial) run into measured_bars.json: keys the run did not touch keep their bar, changes are printed old -> new,
+    --only-new leaves every recorded bar alone."""
+    import json
+    import os
+    import runpy
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "repo"
+    (fake / "tests" / "golden").mkdir(parents=True)
+    (fake / "tools").mkdir()
+    (fake / "tools" / "update_bars.py").write_text(open(os.path.join(root, "tools", "update_bars.py")).read())
+    bars = fake / "tests" / "golden" / "measured_bars.json"
+    bars.write_text(json.dumps({"a": 1.0, "b": 2.0}))
+    run = tmp_path / "run.jsonl"
+    run.write_text("\n".join(json.dumps(r) for r in [{"key": "b", "measured": 3.0}, {"key": "b", "measured": 2.5}, {"key": "c", "measured": 0.5}]))
+    monkeypatch.setattr(sys, "argv", ["update_bars.py", str(run), "--only-new"])
+    runpy.run_path(str(fake / "tools" / "update_bars.py"), run_name="__main__")
+    assert json.loads(bars.read_text()) == {"a": 1.0, "b": 2.0, "c": 0.5}
+    monkeypatch.setattr(sys, "argv", ["update_bars.py", str(run)])
+    runpy.run_path(str(fake / "tools" / "update_bars.py"), run_name="__main__")
+    assert json.loads(bars.read_text()) == {"a": 1.0, "b": 3.0, "c": 0.5}
