@@ -170,9 +170,14 @@ typedef __attribute__((ext_vector_type(4))) int i32x4;
 // (common.hpp pack_h2 / unpack_h2), GELU by the nine-coefficient polynomial gelu_pk9 (3.8e-5 absolute; the seven-coefficient one of the bf16 epilogue, 4e-4, sits
 // below a bf16 half-ulp, not below an fp16 one).  An fp16 output beyond +-65504 becomes inf, and an inf poisons everything behind it (the row's residual stream, then --
 // through the keys and values -- every token of the image): the pipeline's LAST kernel (final norm / sampling) reports non-finite features, nothing is tracked here.
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
+// NSTAGE (the 64 x 128 tile of a one-crop batch only): K-tiles in flight per workgroup -- four instead of two, three tiles in flight behind the one being multiplied.
+// Worth 4 % on the launch it was built for (fc2 at B = 1: 45.3 -> 43.5 us, tools/b1_gemm_probe.py): that launch is NOT latency-bound, as assumed -- 172 workgroups
+// re-stream the 8 MB weight matrix 22 times (one pass per 64-row tile) at the ~35 GB/s one CU's LDS-DMA path sustains, 0.7 us per K-tile whatever the depth.
+// The MFMA order per accumulator is untouched: the same bits.
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false, int NSTAGE = 2>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args a) {
   static_assert(!SX || SP, "f16f8 rows are a form of the split operands");
+  static_assert(NSTAGE == 2 || (NSTAGE == 4 && !F8 && !SP && WM * WN != 8), "the deep pipeline exists for the small bf16 / fp16 tiles");
   static_assert(!H16 || (!F8 && !SP), "plain fp16 operands exclude the fp8 and the split forms");
   static_assert(!F8OUT || (F8 && (EPI == GEMM_EPI_GELU_BF16 || EPI == GEMM_EPI_SWIGLU_BF16)), "fp8 output: GELU / SwiGLU epilogues of the fp8 kernels");
   static_assert(!(SP && F8) && (!SPOUT || SP), "split-fp16 and fp8 operands exclude each other; a split output needs split operands");
@@ -252,6 +257,14 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     };
 #pragma unroll
     for (int q = 0; q < PIECES; ++q) stage_piece(q, kb, smem);
+    if constexpr (NSTAGE > 2) {   // ... and the next NSTAGE - 2 K-tiles behind it
+#pragma unroll
+      for (int d = 1; d < NSTAGE - 1; ++d)
+        if (kb + d < ke) {
+#pragma unroll
+          for (int q = 0; q < PIECES; ++q) stage_piece(q, kb + d, smem + d * STAGE);
+        }
+    }
 
     // Folded LayerNorm (consumer side): (rstd, mean * rstd) of the TM rows this lane will finish (ln_finalize's table).
     // Loaded here, behind the first K-tile's DMA, so the round trip hides under the main loop (fetched in the epilogue it
@@ -277,14 +290,22 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
     {
       // ---- main loop: one barrier per K-tile, the next tile's DMA issued in four slices ahead of each k-step's MFMAs
       for (int t = kb; t < ke; ++t) {
-        const int cur = (t - kb) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t have landed
-        __syncthreads();                                  // ... everyone's have; the other stage has no readers left
+        const int cur = NSTAGE == 2 ? ((t - kb) & 1) : ((t - kb) % NSTAGE);
+        if constexpr (NSTAGE == 2) {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces of tile t have landed
+        } else {
+          // tiles t + 1 .. t + NSTAGE - 2 may still be in flight behind tile t (loads retire in order): PIECES instructions each.  In the tail fewer are
+          // outstanding than the count would allow, so it waits for everything (conservative for the last NSTAGE - 2 tiles)
+          static_assert((NSTAGE - 2) * PIECES == 12, "s_waitcnt immediate below");
+          if (t + NSTAGE - 2 < ke) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();                                  // ... everyone's have; the stage refilled below (tile t - 1's) has no readers left
 #ifdef FP_GEMM_TIMELINE
         if (a.dbg && t == 0) ts1 = __builtin_readcyclecounter();
 #endif
-        char* nxt = smem + (cur ^ 1) * STAGE;
-        const bool more = t + 1 < ke;
+        char* nxt = smem + (NSTAGE == 2 ? (cur ^ 1) : ((t - kb + NSTAGE - 1) % NSTAGE)) * STAGE;
+        const bool more = t + (NSTAGE - 1) < ke;          // the tile staged during this iteration: t + NSTAGE - 1
         const char* As = smem + cur * STAGE;
         const char* Ws = As + A_BYTES;
         if constexpr (F8) {
@@ -420,7 +441,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_bf16_kernel(GemmBf16Args
           } else
           if (more) {
 #pragma unroll
-            for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + 1, nxt);
+            for (int q = (ks * PIECES) / 4; q < ((ks + 1) * PIECES) / 4; ++q) stage_piece(q, t + (NSTAGE - 1), nxt);
           }
           const int chunk = ks * 2 + kh;
           // the compiler's MFMA / LDS-read interleaving strategy 1 for this scheduling region: +0.75 % on the pipeline in same-box A/B
@@ -802,7 +823,7 @@ static GemmRaster pick_raster(int bm, int n_tiles, unsigned grid) {
   return {0, 0};
 }
 
-template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false>
+template <int EPI, int BM, int BN, int WM, int WN, bool F8 = false, bool F8OUT = false, bool SP = false, bool SPOUT = false, bool SX = false, bool H16 = false, int NSTAGE = 2>
 int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
   GemmBf16Args a = a_in;
   if constexpr (H16) {
@@ -824,10 +845,12 @@ int launch_cfg(const GemmBf16Args& a_in, hipStream_t st) {
     a.rast_r = ra.r; a.rast_gn = ra.gn;
     grid = ((a.m_tiles + ra.r - 1) / ra.r) * ((a.N / BN) / ra.gn) * 32;
   }
-  const size_t lds = (size_t)(BM + BN) * BK * 2 * 2;
+  const size_t lds = (size_t)(BM + BN) * BK * 2 * NSTAGE;
+  // (Measured and dropped: asking for > 80 KiB of LDS when a launch has no more tiles than CUs, so that every workgroup takes a CU of its own -- the dispatcher
+  //  already spreads them: fc2 of a two-crop batch 51.4 us either way, tools/b1_gemm_probe.py.)
   static FpDeviceOnce attr;
-  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16>, (int)lds);
-  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
+  fp_allow_dynamic_lds(attr, &gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16, NSTAGE>, (int)lds);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, F8, F8OUT, SP, SPOUT, SX, H16, NSTAGE>), dim3(grid), dim3(WM * WN * 64), lds, st, a);
   FP_CHECK_LAUNCH("gemm_bf16_kernel");
   return FP_OK;
 }
@@ -876,7 +899,10 @@ int launch(const GemmBf16Args& a, hipStream_t st) {
   if constexpr (!SP && (EPI == GEMM_EPI_RESID_HILO || EPI == GEMM_EPI_RESID_F32 || EPI == GEMM_EPI_LS_RESID_F32)) {
     const int tiles_128 = (a.M_valid > 0 ? (a.M_valid + 127) / 128 : a.M / 128) * (a.N / 128);
     if ((force == 64 && a.M % 64 == 0) || (force == 0 && a.M % 64 == 0 && tiles_128 <= cus / 2))
-      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT, false, H16>(a, st);
+#ifdef FP_GEMM_SMALL_2STAGE   // (measurement build: the double-buffered loop in the small tile)
+      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT, false, H16, 2>(a, st);
+#endif
+      return launch_cfg<EPI, 64, 128, 2, 2, false, false, SP, SPOUT, false, H16, 4>(a, st);   // four K-tiles in flight: one workgroup per CU has nothing else to hide the fetch latency behind
   }
   return launch_cfg<EPI, 128, 128, 2, 2, false, false, SP, SPOUT, SX, H16>(a, st);
 }
