@@ -654,7 +654,8 @@ def test_gemm_320_row_tile_equals_256_row_tile(M, N, K, m_valid):
         assert torch.equal(f256[:m_valid], f320[:m_valid])
 
 
-@pytest.mark.parametrize("M,N,K,m_valid", [(1536, 1024, 1024, 1374), (1536, 1024, 4096, 1374), (256, 384, 1536, 200), (2816, 1024, 1024, 2748)])
+@pytest.mark.parametrize("M,N,K,m_valid", [(1536, 1024, 1024, 1374), (1536, 1024, 4096, 1374), (256, 384, 1536, 200), (2816, 1024, 1024, 2748),
+                                           (128, 128, 64, 100), (256, 256, 128, 250), (256, 128, 192, 256), (128, 256, 256, 70)])   # 1 .. 4 K-tiles: shorter than the 64-row tile's four-stage pipeline
 def test_gemm_64_row_tile_equals_128_row_tile(M, N, K, m_valid):
     """The 64 x 128 block tile the residual GEMMs (proj, fc2) of a batch of one or two crops launch -- the reference loop's shape, one detection
     at a time -- walks k in the same order per output element as the 128^2 tile: the fp32 LayerScale-residual stream (epilogue 3), the fp32
